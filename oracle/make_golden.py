@@ -1,0 +1,251 @@
+"""Pin the oracle against the REAL reference and freeze golden vectors.
+
+Runs only in the build container (needs /root/reference).  It
+  1. imports the reference's own modules (stubbing boto3/botocore, which
+     layers/bert/file_utils.py:19-21 imports but this path never uses),
+  2. assembles CaptioningModel exactly like get_git_model (model.py:9-61) minus
+     clip.load (network) -- VisualTransformer is constructed directly with the
+     ViT-B/16 / ViT-L/14 hyper-parameters and output_grid=grid_after_ln=True,
+  3. loads the oracle's seeded weights into it via load_state_dict(strict=True),
+  4. runs reference and oracle on the same inputs, ASSERTS they agree, and
+  5. writes the reference's outputs to tests/golden/*.npz.
+
+Usage:  python oracle/make_golden.py [--only NAME]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import git_oracle as O  # noqa: E402
+
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    for name in ("boto3", "botocore", "botocore.exceptions"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["botocore.exceptions"].ClientError = Exception
+    sys.modules["botocore"].exceptions = sys.modules["botocore.exceptions"]
+    sys.path.insert(0, REF)
+    from generativeimage2text.layers.CLIP.model import VisualTransformer
+    from generativeimage2text.layers import decoder as D
+    return VisualTransformer, D
+
+
+def build_reference(cfg: O.GitConfig, w: O.Weights, search: O.SearchConfig, tie: bool):
+    VisualTransformer, D = import_reference()
+    vit = VisualTransformer(cfg.image_size, cfg.patch, cfg.vit_width, cfg.vit_layers, cfg.vit_heads, 512)
+    vit.output_grid = True          # model.py:73-74
+    vit.grid_after_ln = True
+    head = D.TransformerDecoderTextualHead(
+        visual_feature_size=cfg.vfs, vocab_size=cfg.vocab, hidden_size=cfg.dec_hidden,
+        num_layers=cfg.dec_layers, attention_heads=cfg.dec_heads, feedforward_size=cfg.dec_ffn,
+        max_caption_length=cfg.max_pos, mask_future_positions=True, padding_idx=0,
+        decoder_type="bert_en", visual_projection_type="linearLn", not_tie_weight=(not tie))
+    if search.kind == "greedy":
+        dec = D.AutoRegressiveBeamSearch(eos_index=cfg.eos, max_steps=search.max_steps,
+                                         beam_size=search.beam_size,
+                                         per_node_beam_size=search.per_node_beam_size,
+                                         fix_missing_prefix=True)
+    else:
+        dec = D.GeneratorWithBeamSearch(eos_index=cfg.eos, max_steps=search.max_steps,
+                                        beam_size=search.beam_size,
+                                        per_node_beam_size=search.per_node_beam_size,
+                                        length_penalty=search.length_penalty)
+    model = D.CaptioningModel(vit, head, decoder=dec, sos_index=cfg.sos, eos_index=cfg.eos,
+                              tokenizer=None, use_history_for_infer=True, loss_type="smooth",
+                              num_image_with_embedding=cfg.num_frames or None)
+    sd = {k: v.clone() for k, v in w.items()}
+    sd["image_encoder.proj"] = model.image_encoder.proj.data.clone()   # present in checkpoints, unused
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(m.endswith("attn_mask") for m in missing), missing
+    model.eval()
+    return model
+
+
+CASES = {
+    # name: (config, weights kw, batch, frames, search, prefix, atol_feat)
+    "tiny_greedy": ("TINY", dict(seed=11, eos_bias=2.5), 3, 1, O.GREEDY, None),
+    "tiny_greedy_untied": ("TINY", dict(seed=12, tie_output=False, eos_bias=1.0), 4, 1, O.GREEDY, None),
+    "tiny_beam4": ("TINY", dict(seed=13, eos_bias=2.0), 3, 1, O.BEAM4, None),
+    "tiny_beam4_noeos": ("TINY", dict(seed=14), 2, 1, O.BEAM4, None),
+    "tiny_beam3_pn3": ("TINY", dict(seed=15, eos_bias=1.5), 2, 1, O.SearchConfig("beam", 12, 3, 3, 1.0), None),
+    "tiny_ar_beam3": ("TINY", dict(seed=16, eos_bias=2.0), 3, 1, O.SearchConfig("greedy", 16, 3, 2), None),
+    "tiny_prefix_greedy": ("TINY", dict(seed=17, eos_bias=1.0), 1, 1, O.GREEDY, [101, 7, 44, 512, 9]),
+    "tiny_prefix_beam4": ("TINY", dict(seed=18, eos_bias=1.5), 1, 1, O.BEAM4, [101, 300, 2]),
+    "tiny_video_greedy": ("TINY_VIDEO", dict(seed=19, eos_bias=1.0), 2, 3, O.GREEDY, None),
+    "tiny_video_beam4": ("TINY_VIDEO", dict(seed=20, eos_bias=1.5), 2, 3, O.BEAM4, None),
+    "tinyl_greedy": ("TINY_L", dict(seed=21, eos_bias=1.0), 3, 1, O.GREEDY, None),
+    "base_greedy": ("GIT_BASE", dict(seed=1234), 2, 1, O.GREEDY, None),
+    "base_greedy_eos": ("GIT_BASE", dict(seed=1235, tie_output=False, eos_bias=0.25), 2, 1, O.GREEDY, None),
+    "base_beam4": ("GIT_BASE", dict(seed=1234, eos_bias=0.2), 2, 1, O.BEAM4, None),
+    "base_prefix_beam4": ("GIT_BASE", dict(seed=1236, eos_bias=0.2), 1, 1, O.BEAM4, [101, 2054, 2003, 2023, 1029]),
+    "large_greedy": ("GIT_LARGE", dict(seed=1237), 1, 1, O.GREEDY, None),
+    "vatex_greedy": ("GIT_BASE_VATEX", dict(seed=1238), 1, 6, O.SearchConfig("greedy", 8, 1, 1), None),
+}
+
+
+def run_case(name: str):
+    cfg_name, wkw, B, F, search, prefix = CASES[name]
+    cfg = O.CONFIGS[cfg_name]
+    w = O.make_weights(cfg, **wkw)
+    frames = O.make_images(cfg, B, F, seed=hash(name) % 1000 if False else sum(map(ord, name)))
+    tie = wkw.get("tie_output", True)
+    model = build_reference(cfg, w, search, tie)
+    batch = {"image": frames if F > 1 else frames[0]}
+    pfx = None
+    if prefix is not None:
+        pfx = torch.tensor(prefix, dtype=torch.long)[None]
+        batch["prefix"] = pfx
+    t0 = time.time()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = model(batch)
+        # reference internals for tighter pins
+        ref_feat = (torch.cat([f + e for f, e in zip([model.image_encoder(im) for im in frames],
+                                                     model.img_temperal_embedding)], dim=1)
+                    if cfg.num_frames else model.image_encoder(frames[0]))
+        # teacher-forced logits on a fixed token sequence (exercises `textual` directly)
+        g = torch.Generator().manual_seed(5)
+        tf_tokens = torch.randint(0, cfg.vocab, (B, 5), generator=g)
+        tf_tokens[:, 0] = cfg.sos
+        ref_tf = model.textual(ref_feat, tf_tokens)[:, -1, :].float()
+    t_ref = time.time() - t0
+
+    t0 = time.time()
+    with torch.no_grad():
+        ora = O.caption(cfg, w, frames, search, prefix=pfx, cached=False)
+        ora_tf = O.textual_logits_full(cfg, w, ora["visual_features"], tf_tokens)[:, -1, :]
+        ora_c = O.caption(cfg, w, frames, search, prefix=pfx, cached=True, feats=ora["visual_features"])
+    t_ora = time.time() - t0
+
+    # ---- pin: oracle == reference ------------------------------------------------
+    feat_err = (ora["visual_features"] - ref_feat).abs().max().item()
+    tf_err = (ora_tf - ref_tf).abs().max().item()
+    assert feat_err < 2e-4, (name, "features", feat_err)
+    assert tf_err < 2e-4, (name, "teacher-forced logits", tf_err)
+    assert ora["predictions"].shape == ref["predictions"].shape, (name, ora["predictions"].shape, ref["predictions"].shape)
+    assert torch.equal(ora["predictions"], ref["predictions"]), (name, ora["predictions"], ref["predictions"])
+    assert ora["logprobs"].shape == ref["logprobs"].shape
+    lp_err = (ora["logprobs"] - ref["logprobs"]).abs().max().item()
+    assert lp_err < 1e-4, (name, "logprobs", lp_err)
+    assert torch.equal(ora_c["predictions"], ref["predictions"]), (name, "cached variant tokens")
+    assert (ora_c["logprobs"] - ref["logprobs"]).abs().max().item() < 1e-4
+    print(f"[{name}] OK  ref {t_ref:.1f}s oracle {t_ora:.1f}s  feat_err {feat_err:.2e} tf_err {tf_err:.2e} "
+          f"lp_err {lp_err:.2e}  pred shape {tuple(ref['predictions'].shape)}  "
+          f"row0 {ref['predictions'][0].tolist()}")
+
+    # ---- freeze the REFERENCE outputs ------------------------------------------
+    big = cfg.vocab > 5000
+    np.savez_compressed(
+        os.path.join(GOLD, name + ".npz"),
+        config=cfg_name, weights_kw=repr(wkw), batch=B, frames=F, image_seed=sum(map(ord, name)),
+        search=repr(dataclass_tuple(search)), prefix=np.array(prefix if prefix is not None else [], dtype=np.int64),
+        predictions=ref["predictions"].numpy(), logprobs=ref["logprobs"].numpy(),
+        # features: full for tiny, strided sample for big models
+        feat_sample=(ref_feat[:, ::7, ::5] if big else ref_feat).numpy().astype(np.float32),
+        feat_abs_mean=np.float32(ref_feat.abs().mean().item()),
+        tf_tokens=tf_tokens.numpy(),
+        tf_logits=(ref_tf[:, ::3] if big else ref_tf).numpy().astype(np.float32),
+        tf_argmax=ref_tf.argmax(-1).numpy(),
+        tf_top2_margin=(ref_tf.topk(2).values[:, 0] - ref_tf.topk(2).values[:, 1]).numpy(),
+    )
+
+
+def dataclass_tuple(s: O.SearchConfig):
+    return (s.kind, s.max_steps, s.beam_size, s.per_node_beam_size, s.length_penalty)
+
+
+# ---- scripted-step search cases (no model): reference search classes vs oracle --------
+def scripted_step_factory(seed: int, V: int, eos: int, eos_boost_at=(), eos_boost: float = 8.0,
+                          table: int = 251):
+    """Deterministic logits that depend on the whole row history (so beam reordering matters)."""
+    g = torch.Generator().manual_seed(seed)
+    G = torch.randn(table, V, generator=g) * 2.0
+
+    def step(tokens: torch.Tensor) -> torch.Tensor:
+        t = tokens.shape[1]
+        wts = torch.arange(1, t + 1, dtype=torch.long)
+        key = (tokens.long() * wts).sum(dim=1) % table
+        logits = G[key].clone()
+        if t in eos_boost_at:
+            logits[:, eos] += eos_boost
+        return logits
+
+    return step
+
+
+SCRIPTED = {
+    # name: (kind, B, P, V, eos, max_steps, k, pn, lenpen, seed, eos_boost_at, boost)
+    "s1_plain": ("greedy", 4, 1, 50, 2, 12, 1, 1, 0.0, 1, tuple(range(1, 20)), -30.0),   # EOS never wins
+    "s1_eos_first": ("greedy", 3, 1, 50, 2, 12, 1, 1, 0.0, 2, (1,), 50.0),       # all EOS at step 1 -> early return
+    "s1_eos_mid": ("greedy", 4, 1, 50, 2, 14, 1, 1, 0.0, 3, (4, 5), 6.0),
+    "s1_prefix": ("greedy", 1, 4, 50, 2, 12, 1, 1, 0.0, 4, (7,), 5.0),
+    "s1_beam3": ("greedy", 3, 1, 50, 2, 10, 3, 2, 0.0, 5, (4,), 4.0),
+    "s2_plain": ("beam", 3, 1, 60, 2, 10, 4, 2, 0.6, 6, tuple(range(1, 20)), -30.0),
+    "s2_eos_mid": ("beam", 3, 1, 60, 2, 12, 4, 2, 0.6, 7, (3, 4), 5.0),
+    "s2_eos_top1_early": ("beam", 2, 1, 60, 2, 12, 4, 2, 0.6, 8, (1, 2), 12.0),   # done early -> padding rule
+    "s2_forced_finish": ("beam", 2, 1, 60, 2, 5, 4, 2, 0.6, 9, tuple(range(1, 20)), -30.0),          # cur_len+1 == max_length
+    "s2_prefix": ("beam", 1, 3, 60, 2, 10, 4, 2, 0.6, 10, (6,), 4.0),
+    "s2_k1": ("beam", 2, 1, 60, 2, 9, 1, 2, 1.0, 11, (3,), 5.0),
+    "s2_k3_pn3": ("beam", 2, 1, 60, 2, 9, 3, 3, 0.8, 12, (4,), 3.0),
+}
+
+
+def run_scripted():
+    _, D = import_reference()
+    out = {}
+    for name, (kind, B, P, V, eos, T, k, pn, lpn, seed, at, boost) in SCRIPTED.items():
+        g = torch.Generator().manual_seed(100 + seed)
+        start = torch.randint(3, V, (1 if P > 1 else B, P), generator=g)
+        step = scripted_step_factory(seed, V, eos, at, boost)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if kind == "greedy":
+                ref_dec = D.AutoRegressiveBeamSearch(eos_index=eos, max_steps=T, beam_size=k,
+                                                     per_node_beam_size=pn, fix_missing_prefix=True)
+                rp, rl = ref_dec.search(start, step)
+                op, ol = O.search_autoregressive(start, step, eos, T, k, pn)
+            else:
+                ref_dec = D.GeneratorWithBeamSearch(eos_index=eos, max_steps=T, beam_size=k,
+                                                    per_node_beam_size=pn, length_penalty=lpn)
+                rp, rl = ref_dec.search(start, step)
+                op, ol = O.search_generator(start, step, eos, T, k, pn, lpn)
+        assert rp.shape == op.shape and torch.equal(rp, op), (name, rp, op)
+        assert rl.shape == ol.shape and (rl - ol).abs().max().item() < 1e-5, (name, rl, ol)
+        print(f"[scripted {name}] OK shape {tuple(rp.shape)} row0 {rp[0].tolist()} lp {rl.flatten()[:2].tolist()}")
+        out[name + ".start"] = start.numpy()
+        out[name + ".pred"] = rp.numpy()
+        out[name + ".logprob"] = rl.numpy()
+    np.savez_compressed(os.path.join(GOLD, "scripted_search.npz"), **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    if args.only in (None, "scripted"):
+        run_scripted()
+    for name in CASES:
+        if args.only in (None, name):
+            run_case(name)
+
+
+if __name__ == "__main__":
+    main()
