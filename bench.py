@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Headline benchmark: captions/s for the GIT hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path (ViT encode -> decoder prefill -> 19 KV-cached greedy
+decode steps with on-device search) over one batch of B=64 synthetic 224x224 images per GPU that are
+already resident in HBM (BASELINE.json configs[1]: GIT_BASE bf16 bs=64 greedy max_len=20), plus -- for
+N > 1 -- the RCCL gather of the token ids to rank 0.  Images shard data-parallel across ranks with no
+collective on the data path ("scaling": "weak").
+
+Rank 0 prints ONE JSON line.  `value` is whole-job captions/s.  `roofline` describes the dominant
+kernel (the bf16 MFMA GEMM inside the image encoder, MFMA-bound) from a separate HIP-event-instrumented
+pass of the same workload; `roofline_decode` the HBM-bound decode step; `cpu_baseline` times the CPU
+oracle (a port of the reference algorithm, full recompute like the reference) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0         # HBM3E spec peak
+
+
+def gather_results(tokens: torch.Tensor, logprobs: torch.Tensor):
+    """The only collective of the path: token ids + log-probs of every rank to rank 0
+    (replaces the shared-filesystem poll/concat of reference inference.py:214-225)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return tokens, logprobs
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t_list = [torch.empty_like(tokens) for _ in range(world)] if rank == 0 else None
+    l_list = [torch.empty_like(logprobs) for _ in range(world)] if rank == 0 else None
+    dist.gather(tokens, t_list, dst=0)
+    dist.gather(logprobs, l_list, dst=0)
+    if rank != 0:
+        return None, None
+    return torch.cat(t_list, 0), torch.cat(l_list, 0)
+
+
+def cpu_baseline(sample_batch: int, max_steps: int):
+    """Reference algorithm on the host cores: oracle (fp32, full recompute exactly like the reference's
+    CaptioningModel.infer as shipped), greedy, GIT_BASE.  Bounded sample."""
+    from oracle import git_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.CONFIGS["GIT_BASE"]
+    w = O.make_weights(cfg, seed=1234)
+    frames = O.make_images(cfg, sample_batch, 1, seed=0)
+    search = O.SearchConfig("greedy", max_steps, 1, 1)
+    t0 = time.time()
+    with torch.no_grad():
+        out = O.caption(cfg, w, frames, search, cached=False)
+    dt = time.time() - t0
+    steps = out["predictions"].shape[1] - 1
+    return {"value": round(sample_batch / dt, 4), "unit": "captions/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"GIT_BASE fp32 bs={sample_batch} greedy {steps} decode steps, full recompute per step "
+                      f"(reference semantics), {dt:.1f}s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--model", default="GIT_BASE")
+    ap.add_argument("--search", default="greedy", choices=["greedy", "beam"])
+    ap.add_argument("--max-steps", type=int, default=20)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--frames", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8)
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path to benchmark")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")     # RCCL on ROCm
+
+    from generativeimage2text_amd.configs import config_for_model
+    from generativeimage2text_amd.engine import Engine
+    from generativeimage2text_amd.synthetic import random_state_dict, random_frames
+
+    cfg = config_for_model(args.model)
+    beams = 1 if args.search == "greedy" else 4
+    eng = Engine(cfg, precision=args.precision, max_batch=args.batch, max_beams=beams,
+                 max_frames=max(1, args.frames), max_text_len=args.max_steps)
+    eng.load_state_dict(random_state_dict(cfg, seed=1234))
+    if args.no_graph:
+        eng.set_graph(False)
+    frames = random_frames(cfg, args.batch, args.frames, seed=rank)     # resident in HBM before timing
+    if args.search == "greedy":
+        search = Engine.make_search("greedy", args.max_steps, 1, 1)
+    else:
+        search = Engine.make_search("beam", args.max_steps, 4, 2, 0.6)
+
+    def step():
+        tokens, logprobs, info = eng.generate(frames, search, sync=False)
+        if world > 1:
+            gather_results(tokens, logprobs)
+        return tokens, info
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tokens, info = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # fixed-work check: no caption ended early (every caption ran max_steps-1 decode steps)
+    info_h = info.tolist()
+    steps_run = info_h[2]
+
+    result = None
+    if rank == 0:
+        value = world * args.batch * args.steps / elapsed
+        result = {
+            "metric": "captions/sec whole-node (GIT_BASE 224px bs=64/GPU greedy len=20)",
+            "value": round(value, 2), "unit": "captions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic (random-init weights, N(0,1) images resident in HBM)",
+            "config": {"workload": f"{args.model} {cfg.image_size}px bs={args.batch}/GPU {args.search} "
+                                   f"max_len={args.max_steps} frames={args.frames}",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "decode_steps_per_caption": steps_run, "seq_len_returned": info_h[0],
+                       "hip_graph": not args.no_graph},
+        }
+
+    # ---- roofline pass (rank 0 of N=1 only): HIP events around phases and every GEMM launch ----
+    if rank == 0 and world == 1:
+        eng.profile_enable(True)
+        for _ in range(2):
+            eng.generate(frames, search, sync=True)
+            prof = eng.profile_read()
+        eng.profile_enable(False)
+        n = max(1, prof["vit_gemm_launches"])
+        flops_per_launch = prof["vit_gemm_flops"] / n
+        avg_ms = prof["vit_gemm_ms"] / n
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        result["roofline"] = {
+            "kernel": "gitmi::gemm_kernel<bf16> (image-encoder launches)" if args.precision == "bf16"
+                      else "gitmi::gemm_kernel<f32>",
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "launches_per_step": prof["vit_gemm_launches"], "avg_launch_ms": round(avg_ms, 4),
+            "flops_per_launch": flops_per_launch,
+            "method": "HIP events around each launch on the launch stream, eager (no graph) pass after the timed region",
+        }
+        step_gbs = prof["decode_step_bytes"] / (prof["decode_step_ms"] * 1e-3) / 1e9 if prof["decode_step_ms"] > 0 else 0.0
+        result["roofline_decode"] = {
+            "bound": "hbm", "achieved": round(step_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(step_gbs / PEAK_HBM_GBS, 4), "traffic": None,
+            "bytes_per_step": prof["decode_step_bytes"], "avg_step_ms": round(prof["decode_step_ms"], 4),
+            "steps": prof["decode_steps"],
+        }
+        result["phases_ms"] = {k: round(prof[k], 3) for k in ("vit_ms", "prefill_ms", "decode_ms", "total_ms", "gemm_ms")}
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.max_steps)
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

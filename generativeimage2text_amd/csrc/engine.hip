@@ -1,0 +1,916 @@
+// Host side of the GIT engine: weight ingest/repack, workspaces, the forward schedule
+// (ViT encode -> decoder prefill over image tokens -> KV-cached decode steps -> device search)
+// and the C ABI of include/gitmi.h.
+//
+// Schedule vs. the reference (SURVEY.md headline facts 2/3): the reference re-runs the visual
+// projection and all decoder layers over [image | text] tokens at every decode step and for every
+// beam copy.  Image rows never attend to text (mask top-right = -inf) and text is causal, so
+// computing the image rows once per image and caching K/V is exact; this engine does that.
+#include "../../include/gitmi.h"
+#include "launchers.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace gitmi;
+
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+static int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+#define HIPCK(expr)                                                                                   \
+    do {                                                                                              \
+        hipError_t e__ = (expr);                                                                      \
+        if (e__ != hipSuccess) return fail("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+    } while (0)
+#define RCK(expr)                 \
+    do {                          \
+        int r__ = (expr);         \
+        if (r__ != 0) return r__; \
+    } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
+};
+
+struct VitLayerW {
+    void *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+    float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+    float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+};
+struct DecLayerW {
+    void *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+    float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+    float *lnag = nullptr, *lnab = nullptr, *lnog = nullptr, *lnob = nullptr;
+};
+
+struct TimedSpan { hipEvent_t a, b; int tag; double flops; };
+enum { TAG_VIT = 0, TAG_PREFILL = 1, TAG_DECODE = 2, TAG_GEMM_VIT = 10, TAG_GEMM_OTHER = 11, TAG_STEP = 20 };
+
+struct gitmi_engine {
+    gitmi_config cfg{};
+    int device = 0;
+    bool f32 = false;
+    size_t esz = 2;
+    bool finalized = false;
+    int attn_impl = 1;          // 1 = MFMA flash kernel for full attention (bf16), 0 = VALU kernel
+
+    std::map<std::string, HostTensor> host_w;
+    std::vector<void*> allocs;
+
+    // derived dims
+    int N = 0, g = 0, Kp = 0, Kp_pad = 0;
+
+    // packed weights
+    void* conv_w = nullptr;
+    float *cls = nullptr, *pos = nullptr, *lnpre_g = nullptr, *lnpre_b = nullptr, *lnpost_g = nullptr, *lnpost_b = nullptr;
+    std::vector<VitLayerW> vit;
+    std::vector<float*> temb;
+    void* vp_w = nullptr;
+    float *vp_b = nullptr, *vp_lng = nullptr, *vp_lnb = nullptr;
+    float *words_f = nullptr, *positions_f = nullptr, *emb_lng = nullptr, *emb_lnb = nullptr;
+    std::vector<DecLayerW> dec;
+    void* out_w = nullptr;
+    float* out_b = nullptr;
+    double dec_weight_bytes = 0;
+
+    // ViT workspaces (one frame of max_batch images at a time)
+    void *patches = nullptr, *v_h = nullptr, *v_qkv = nullptr, *v_ctx = nullptr, *v_u = nullptr;
+    float *patch_out = nullptr, *v_x = nullptr;
+    // visual features [B, F*N, vfs]
+    void* feats = nullptr;
+    // prefill workspaces
+    float *p_y = nullptr, *p_hf = nullptr;
+    void *p_ht = nullptr, *p_ctx = nullptr, *p_u = nullptr;
+    std::vector<void*> img_kv;      // per layer [B*N_img, 3d]
+    // decode workspaces
+    float *d_y = nullptr, *d_hf = nullptr, *logits = nullptr;
+    void *d_ht = nullptr, *d_qkv = nullptr, *d_ctx = nullptr, *d_u = nullptr;
+    std::vector<void*> txt_k, txt_v;   // per layer [R_max, T_max, d]
+    int ldl = 0;
+    // search
+    SearchState ss{};
+    int ss_cur = 0, ss_len = 0, ss_M = 0;
+    bool ss_first = true;
+    long long* start_dev = nullptr;
+    const float* const* frames_dummy = nullptr;
+
+    // state of the current batch
+    int cur_B = 0, cur_F = 0, cur_Nimg = 0;
+    bool have_feats = false, have_prefill = false;
+
+    // profiling
+    bool profiling = false;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+    size_t event_next = 0;
+    double last_decode_step_bytes = 0;
+    bool use_graph = true;
+
+    // hipGraph cache for gitmi_generate
+    struct GraphKey {
+        int B, F, P, kind, k, pn, T; double lp;
+        bool operator==(const GraphKey& o) const {
+            return B == o.B && F == o.F && P == o.P && kind == o.kind && k == o.k && pn == o.pn && T == o.T && lp == o.lp;
+        }
+    };
+    bool graph_valid = false;
+    GraphKey graph_key{};
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<float*> frame_stage;   // engine-owned copies of the input frames (graph inputs)
+    long long* prefix_stage = nullptr;
+    long long* out_tokens = nullptr;   // graph outputs, copied to the caller's buffers after the launch
+    float* out_lp = nullptr;
+    int* out_info = nullptr;
+    hipStream_t own_stream = nullptr;  // used when the caller passes the (uncapturable) null stream
+    hipEvent_t fence_in = nullptr, fence_out = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------
+static int dev_alloc(gitmi_engine* e, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    HIPCK(hipMalloc(p, bytes));
+    e->allocs.push_back(*p);
+    return 0;
+}
+template <typename T> static int dev_alloc_t(gitmi_engine* e, T** p, size_t count) {
+    return dev_alloc(e, reinterpret_cast<void**>(p), count * sizeof(T));
+}
+
+static hipEvent_t get_event(gitmi_engine* e) {
+    if (e->event_next == e->event_pool.size()) {
+        hipEvent_t ev;
+        hipEventCreate(&ev);
+        e->event_pool.push_back(ev);
+    }
+    return e->event_pool[e->event_next++];
+}
+struct SpanGuard {
+    gitmi_engine* e; hipStream_t s; size_t idx; bool on;
+    SpanGuard(gitmi_engine* e_, hipStream_t s_, int tag, double flops) : e(e_), s(s_), idx(0), on(e_->profiling) {
+        if (!on) return;
+        TimedSpan sp{get_event(e), get_event(e), tag, flops};
+        hipEventRecord(sp.a, s);
+        idx = e->spans.size();
+        e->spans.push_back(sp);
+    }
+    ~SpanGuard() { if (on) hipEventRecord(e->spans[idx].b, s); }
+};
+
+// GEMM wrapper: C = act(A W^T + bias) (+ res)
+static int gemm(gitmi_engine* e, hipStream_t s, const void* A, int lda, const void* W, const float* bias,
+                const float* res, int ldr, void* C, int ldc, bool out_f32, int M, int N, int K, int act, int tag) {
+    GemmArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.res = res; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldr; g.act = act;
+    SpanGuard sp(e, s, tag, 2.0 * (double)M * (double)N * (double)K);
+    HIPCK(launch_gemm(g, e->f32, out_f32, s));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+extern "C" int gitmi_abi_version(void) { return GITMI_ABI_VERSION; }
+extern "C" const char* gitmi_last_error(void) { return g_err; }
+
+extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** out) {
+    if (!cfg || !out) return fail("gitmi_create: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail("gitmi_create: no HIP device available (this engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail("gitmi_create: device %d out of range (%d devices)", device, ndev);
+    HIPCK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("gitmi_create: device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                    prop.gcnArchName);
+    const gitmi_config& c = *cfg;
+    if (c.vit_width % c.vit_heads || c.vit_width / c.vit_heads != 64) return fail("ViT head_dim must be 64");
+    if (c.dec_hidden % c.dec_heads || c.dec_hidden / c.dec_heads != 64) return fail("decoder head_dim must be 64");
+    if (c.image_size % c.patch) return fail("image_size must be a multiple of patch");
+    if (c.vit_width > 1024 || c.dec_hidden > 1024) return fail("hidden sizes above 1024 are not supported");
+    if (c.vit_width % 64 || c.dec_hidden % 64 || c.dec_ffn % 64) return fail("hidden sizes must be multiples of 64");
+    if (c.max_batch < 1 || c.max_beams < 1 || c.max_beams > 8 || c.max_frames < 1 || c.max_text_len < 2)
+        return fail("bad capacity (max_batch>=1, 1<=max_beams<=8, max_frames>=1, max_text_len>=2)");
+    if (c.max_text_len > c.max_pos) return fail("max_text_len exceeds max_pos");
+    if (c.precision != GITMI_PREC_BF16 && c.precision != GITMI_PREC_F32) return fail("bad precision");
+
+    gitmi_engine* e = new gitmi_engine();
+    e->cfg = c;
+    e->device = device;
+    e->f32 = c.precision == GITMI_PREC_F32;
+    e->esz = e->f32 ? 4 : 2;
+    e->attn_impl = e->f32 ? 0 : 1;
+    e->g = c.image_size / c.patch;
+    e->N = e->g * e->g + 1;
+    e->Kp = 3 * c.patch * c.patch;
+    e->Kp_pad = round_up(e->Kp, 64);
+    if (const char* env = getenv("GITMI_ATTN_IMPL")) e->attn_impl = e->f32 ? 0 : atoi(env);
+    if (const char* env = getenv("GITMI_GRAPH")) e->use_graph = atoi(env) != 0;
+    if (attn_decode_configure() != hipSuccess) { delete e; return fail("hipFuncSetAttribute failed"); }
+    *out = e;
+    return 0;
+}
+
+static void destroy_graph(gitmi_engine* e) {
+    if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
+    if (e->graph) hipGraphDestroy(e->graph);
+    e->graph_exec = nullptr;
+    e->graph = nullptr;
+    e->graph_valid = false;
+}
+
+extern "C" void gitmi_destroy(gitmi_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipDeviceSynchronize();
+    destroy_graph(e);
+    if (e->own_stream) hipStreamDestroy(e->own_stream);
+    if (e->fence_in) hipEventDestroy(e->fence_in);
+    if (e->fence_out) hipEventDestroy(e->fence_out);
+    for (auto ev : e->event_pool) hipEventDestroy(ev);
+    for (void* p : e->allocs) hipFree(p);
+    delete e;
+}
+
+// ---------------------------------------------------------------------------------------
+static float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000) << 16;
+    uint32_t exp = (h >> 10) & 0x1f, man = h & 0x3ff, out;
+    if (exp == 0) {
+        if (man == 0) out = sign;
+        else {
+            exp = 127 - 15 + 1;
+            while (!(man & 0x400)) { man <<= 1; --exp; }
+            man &= 0x3ff;
+            out = sign | (exp << 23) | (man << 13);
+        }
+    } else if (exp == 31) out = sign | 0x7f800000u | (man << 13);
+    else out = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &out, 4);
+    return f;
+}
+
+extern "C" int gitmi_load_tensor(gitmi_engine* e, const char* key, const void* data_host, const int64_t* shape,
+                                 int ndim, int dtype) {
+    if (!e || !key || !data_host || (ndim > 0 && !shape)) return fail("gitmi_load_tensor: null argument");
+    if (e->finalized) return fail("gitmi_load_tensor: weights already finalized");
+    std::string k(key);
+    if (k.rfind("module.", 0) == 0) k = k.substr(7);          // torch_common.py:95-99 strips DataParallel prefixes
+    if (k == "image_encoder.proj") return 0;                   // unused with output_grid=True
+    const bool known = k.rfind("image_encoder.", 0) == 0 || k.rfind("textual.", 0) == 0 ||
+                       k.rfind("img_temperal_embedding.", 0) == 0;
+    if (!known) return fail("gitmi_load_tensor: unknown key '%s'", key);
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    const size_t n = t.numel();
+    t.data.resize(n);
+    if (dtype == GITMI_DTYPE_F32) memcpy(t.data.data(), data_host, n * 4);
+    else if (dtype == GITMI_DTYPE_BF16) {
+        const uint16_t* p = (const uint16_t*)data_host;
+        for (size_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)p[i] << 16; memcpy(&t.data[i], &u, 4); }
+    } else if (dtype == GITMI_DTYPE_F16) {
+        const uint16_t* p = (const uint16_t*)data_host;
+        for (size_t i = 0; i < n; ++i) t.data[i] = half_to_float(p[i]);
+    } else return fail("gitmi_load_tensor: bad dtype %d", dtype);
+    e->host_w[k] = std::move(t);
+    return 0;
+}
+
+static int get_w(gitmi_engine* e, const std::string& key, std::initializer_list<int64_t> shape, const HostTensor** out) {
+    auto it = e->host_w.find(key);
+    if (it == e->host_w.end()) return fail("missing weight '%s'", key.c_str());
+    size_t want = 1;
+    for (auto s : shape) want *= (size_t)s;
+    if (it->second.numel() != want) return fail("weight '%s' has %zu elements, expected %zu", key.c_str(), it->second.numel(), want);
+    *out = &it->second;
+    return 0;
+}
+// fp32 vector / table on device
+static int up_f32(gitmi_engine* e, const std::string& key, std::initializer_list<int64_t> shape, float** dst) {
+    const HostTensor* t;
+    RCK(get_w(e, key, shape, &t));
+    RCK(dev_alloc_t(e, dst, t->numel()));
+    HIPCK(hipMemcpy(*dst, t->data.data(), t->numel() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+// matrix [rows, K] -> compute dtype [rows, Kpad] written at dst + row_off rows
+static int up_mat_into(gitmi_engine* e, const std::string& key, int64_t rows, int K, int Kpad, void* dst, size_t row_off) {
+    const HostTensor* t;
+    RCK(get_w(e, key, {rows, (int64_t)K}, &t));
+    float* tmp = nullptr;
+    HIPCK(hipMalloc((void**)&tmp, t->numel() * 4));
+    hipError_t err = hipMemcpy(tmp, t->data.data(), t->numel() * 4, hipMemcpyHostToDevice);
+    if (err == hipSuccess)
+        err = launch_convert_pad(tmp, (char*)dst + row_off * (size_t)Kpad * e->esz, e->f32, (size_t)rows, K, Kpad, 0);
+    if (err == hipSuccess) err = hipDeviceSynchronize();
+    hipFree(tmp);
+    HIPCK(err);
+    return 0;
+}
+static int up_mat(gitmi_engine* e, const std::string& key, int64_t rows, int K, int Kpad, void** dst) {
+    RCK(dev_alloc(e, dst, (size_t)rows * Kpad * e->esz));
+    return up_mat_into(e, key, rows, K, Kpad, *dst, 0);
+}
+static int up_f32_into(gitmi_engine* e, const std::string& key, int64_t n, float* dst, size_t off) {
+    const HostTensor* t;
+    RCK(get_w(e, key, {n}, &t));
+    HIPCK(hipMemcpy(dst + off, t->data.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int alloc_workspaces(gitmi_engine* e) {
+    const gitmi_config& c = e->cfg;
+    const size_t esz = e->esz;
+    const int D = c.vit_width, d = c.dec_hidden;
+    const size_t Mv = (size_t)c.max_batch * e->N;                 // ViT rows per frame
+    const size_t Mp = (size_t)c.max_batch * c.max_frames * e->N;  // prefill rows
+    const size_t R = (size_t)c.max_batch * c.max_beams;
+    const int T = c.max_text_len;
+    RCK(dev_alloc(e, &e->patches, (size_t)c.max_batch * e->g * e->g * e->Kp_pad * esz));
+    RCK(dev_alloc_t(e, &e->patch_out, (size_t)c.max_batch * e->g * e->g * D));
+    RCK(dev_alloc_t(e, &e->v_x, Mv * D));
+    RCK(dev_alloc(e, &e->v_h, Mv * D * esz));
+    RCK(dev_alloc(e, &e->v_qkv, Mv * 3 * D * esz));
+    RCK(dev_alloc(e, &e->v_ctx, Mv * D * esz));
+    RCK(dev_alloc(e, &e->v_u, Mv * 4 * D * esz));
+    RCK(dev_alloc(e, &e->feats, Mp * D * esz));
+    RCK(dev_alloc_t(e, &e->p_y, Mp * d));
+    RCK(dev_alloc_t(e, &e->p_hf, Mp * d));
+    RCK(dev_alloc(e, &e->p_ht, Mp * d * esz));
+    RCK(dev_alloc(e, &e->p_ctx, Mp * d * esz));
+    RCK(dev_alloc(e, &e->p_u, Mp * c.dec_ffn * esz));
+    e->img_kv.resize(c.dec_layers);
+    e->txt_k.resize(c.dec_layers);
+    e->txt_v.resize(c.dec_layers);
+    for (int l = 0; l < c.dec_layers; ++l) {
+        RCK(dev_alloc(e, &e->img_kv[l], Mp * 3 * d * esz));
+        RCK(dev_alloc(e, &e->txt_k[l], R * T * d * esz));
+        RCK(dev_alloc(e, &e->txt_v[l], R * T * d * esz));
+    }
+    RCK(dev_alloc_t(e, &e->d_y, R * d));
+    RCK(dev_alloc_t(e, &e->d_hf, R * d));
+    RCK(dev_alloc(e, &e->d_ht, R * d * esz));
+    RCK(dev_alloc(e, &e->d_qkv, R * 3 * d * esz));
+    RCK(dev_alloc(e, &e->d_ctx, R * d * esz));
+    RCK(dev_alloc(e, &e->d_u, R * c.dec_ffn * esz));
+    e->ldl = round_up(c.vocab, 8);
+    RCK(dev_alloc_t(e, &e->logits, R * e->ldl));
+    // search state
+    SearchState& s = e->ss;
+    for (int i = 0; i < 2; ++i) {
+        RCK(dev_alloc_t(e, &s.ids[i], R * T));
+        RCK(dev_alloc_t(e, &s.kv_src[i], R * T));
+        RCK(dev_alloc_t(e, &s.score[i], R));
+    }
+    RCK(dev_alloc_t(e, &s.cand_val, R * 16));
+    RCK(dev_alloc_t(e, &s.cand_idx, R * 16));
+    RCK(dev_alloc_t(e, &s.done, (size_t)c.max_batch));
+    RCK(dev_alloc_t(e, &s.hyp_n, (size_t)c.max_batch));
+    RCK(dev_alloc_t(e, &s.hyp_score, (size_t)c.max_batch));
+    RCK(dev_alloc_t(e, &s.hyp_len, (size_t)c.max_batch));
+    RCK(dev_alloc_t(e, &s.hyp_tok, (size_t)c.max_batch * T));
+    RCK(dev_alloc_t(e, &s.info, 4));
+    RCK(dev_alloc_t(e, &e->start_dev, (size_t)c.max_batch * T));
+    RCK(dev_alloc_t(e, &e->prefix_stage, (size_t)T));
+    RCK(dev_alloc_t(e, &e->out_tokens, (size_t)c.max_batch * T));
+    RCK(dev_alloc_t(e, &e->out_lp, (size_t)c.max_batch));
+    RCK(dev_alloc_t(e, &e->out_info, 4));
+    HIPCK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&e->fence_in, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&e->fence_out, hipEventDisableTiming));
+    e->frame_stage.resize(c.max_frames);
+    for (int f = 0; f < c.max_frames; ++f)
+        RCK(dev_alloc_t(e, &e->frame_stage[f], (size_t)c.max_batch * 3 * c.image_size * c.image_size));
+    return 0;
+}
+
+extern "C" int gitmi_finalize_weights(gitmi_engine* e) {
+    if (!e) return fail("null engine");
+    if (e->finalized) return 0;
+    HIPCK(hipSetDevice(e->device));
+    const gitmi_config& c = e->cfg;
+    const int D = c.vit_width, F4 = 4 * D, d = c.dec_hidden, f = c.dec_ffn, V = c.vocab;
+    const int64_t p = c.patch;
+    // ---- image encoder -----------------------------------------------------------------
+    {
+        const HostTensor* t;
+        RCK(get_w(e, "image_encoder.conv1.weight", {D, 3, p, p}, &t));
+        e->host_w["image_encoder.conv1.weight"].shape = {D, (int64_t)e->Kp};
+        RCK(up_mat(e, "image_encoder.conv1.weight", D, e->Kp, e->Kp_pad, &e->conv_w));
+    }
+    RCK(up_f32(e, "image_encoder.class_embedding", {D}, &e->cls));
+    RCK(up_f32(e, "image_encoder.positional_embedding", {e->N, D}, &e->pos));
+    RCK(up_f32(e, "image_encoder.ln_pre.weight", {D}, &e->lnpre_g));
+    RCK(up_f32(e, "image_encoder.ln_pre.bias", {D}, &e->lnpre_b));
+    RCK(up_f32(e, "image_encoder.ln_post.weight", {D}, &e->lnpost_g));
+    RCK(up_f32(e, "image_encoder.ln_post.bias", {D}, &e->lnpost_b));
+    e->vit.resize(c.vit_layers);
+    for (int i = 0; i < c.vit_layers; ++i) {
+        const std::string pre = "image_encoder.transformer.resblocks." + std::to_string(i) + ".";
+        VitLayerW& L = e->vit[i];
+        RCK(up_mat(e, pre + "attn.in_proj_weight", 3 * D, D, D, &L.wqkv));
+        RCK(up_f32(e, pre + "attn.in_proj_bias", {3 * D}, &L.bqkv));
+        RCK(up_mat(e, pre + "attn.out_proj.weight", D, D, D, &L.wo));
+        RCK(up_f32(e, pre + "attn.out_proj.bias", {D}, &L.bo));
+        RCK(up_f32(e, pre + "ln_1.weight", {D}, &L.ln1g));
+        RCK(up_f32(e, pre + "ln_1.bias", {D}, &L.ln1b));
+        RCK(up_mat(e, pre + "mlp.c_fc.weight", F4, D, D, &L.w1));
+        RCK(up_f32(e, pre + "mlp.c_fc.bias", {F4}, &L.b1));
+        RCK(up_mat(e, pre + "mlp.c_proj.weight", D, F4, F4, &L.w2));
+        RCK(up_f32(e, pre + "mlp.c_proj.bias", {D}, &L.b2));
+        RCK(up_f32(e, pre + "ln_2.weight", {D}, &L.ln2g));
+        RCK(up_f32(e, pre + "ln_2.bias", {D}, &L.ln2b));
+    }
+    e->temb.resize(c.num_frames);
+    for (int i = 0; i < c.num_frames; ++i)
+        RCK(up_f32(e, "img_temperal_embedding." + std::to_string(i), {1, 1, D}, &e->temb[i]));
+    // ---- text decoder ------------------------------------------------------------------
+    RCK(up_mat(e, "textual.visual_projection.0.weight", d, D, D, &e->vp_w));
+    RCK(up_f32(e, "textual.visual_projection.0.bias", {d}, &e->vp_b));
+    RCK(up_f32(e, "textual.visual_projection.1.weight", {d}, &e->vp_lng));
+    RCK(up_f32(e, "textual.visual_projection.1.bias", {d}, &e->vp_lnb));
+    RCK(up_f32(e, "textual.embedding.words.weight", {V, d}, &e->words_f));
+    RCK(up_f32(e, "textual.embedding.positions.weight", {c.max_pos, d}, &e->positions_f));
+    RCK(up_f32(e, "textual.embedding.layer_norm.weight", {d}, &e->emb_lng));
+    RCK(up_f32(e, "textual.embedding.layer_norm.bias", {d}, &e->emb_lnb));
+    e->dec.resize(c.dec_layers);
+    double wbytes = 0;
+    for (int i = 0; i < c.dec_layers; ++i) {
+        const std::string pre = "textual.transformer.encoder.layer." + std::to_string(i) + ".";
+        DecLayerW& L = e->dec[i];
+        // fused [Wq; Wk; Wv] so that one GEMM produces the packed q|k|v rows the attention kernels read
+        RCK(dev_alloc(e, &L.wqkv, (size_t)3 * d * d * e->esz));
+        RCK(dev_alloc_t(e, &L.bqkv, (size_t)3 * d));
+        const char* names[3] = {"query", "key", "value"};
+        for (int j = 0; j < 3; ++j) {
+            RCK(up_mat_into(e, pre + "attention.self." + names[j] + ".weight", d, d, d, L.wqkv, (size_t)j * d));
+            RCK(up_f32_into(e, pre + "attention.self." + names[j] + ".bias", d, L.bqkv, (size_t)j * d));
+        }
+        RCK(up_mat(e, pre + "attention.output.dense.weight", d, d, d, &L.wo));
+        RCK(up_f32(e, pre + "attention.output.dense.bias", {d}, &L.bo));
+        RCK(up_f32(e, pre + "attention.output.LayerNorm.weight", {d}, &L.lnag));
+        RCK(up_f32(e, pre + "attention.output.LayerNorm.bias", {d}, &L.lnab));
+        RCK(up_mat(e, pre + "intermediate.dense.weight", f, d, d, &L.w1));
+        RCK(up_f32(e, pre + "intermediate.dense.bias", {f}, &L.b1));
+        RCK(up_mat(e, pre + "output.dense.weight", d, f, f, &L.w2));
+        RCK(up_f32(e, pre + "output.dense.bias", {d}, &L.b2));
+        RCK(up_f32(e, pre + "output.LayerNorm.weight", {d}, &L.lnog));
+        RCK(up_f32(e, pre + "output.LayerNorm.bias", {d}, &L.lnob));
+        wbytes += ((double)4 * d * d + (double)2 * d * f) * e->esz;
+    }
+    if (e->host_w.find("textual.output.weight") == e->host_w.end())   // tied (decoder.py:503-505)
+        e->host_w["textual.output.weight"] = e->host_w["textual.embedding.words.weight"];
+    RCK(up_mat(e, "textual.output.weight", V, d, d, &e->out_w));
+    RCK(up_f32(e, "textual.output.bias", {V}, &e->out_b));
+    wbytes += (double)V * d * e->esz;
+    e->dec_weight_bytes = wbytes;
+    e->host_w.clear();
+    RCK(alloc_workspaces(e));
+    HIPCK(hipDeviceSynchronize());
+    e->finalized = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+static int encode_frames_impl(gitmi_engine* e, const float* const* frames, int F, int B, float* feats_out,
+                              hipStream_t s) {
+    const gitmi_config& c = e->cfg;
+    const int D = c.vit_width, N = e->N, M = B * N;
+    const int F_eff = c.num_frames > 0 ? std::min(F, c.num_frames) : F;   // zip() truncation, decoder.py:849
+    const int Nimg = F_eff * N;
+    SpanGuard phase(e, s, TAG_VIT, 0);
+    for (int fr = 0; fr < F_eff; ++fr) {
+        HIPCK(launch_im2col(frames[fr], e->patches, e->f32, B, c.image_size, c.patch, e->Kp, e->Kp_pad, s));
+        RCK(gemm(e, s, e->patches, e->Kp_pad, e->conv_w, nullptr, nullptr, 0, e->patch_out, D, true, B * e->g * e->g,
+                 D, e->Kp_pad, 0, TAG_GEMM_VIT));
+        HIPCK(launch_vit_assemble_ln(e->patch_out, e->cls, e->pos, e->lnpre_g, e->lnpre_b, 1e-5f, e->v_x, B, N, D, s));
+        for (int l = 0; l < c.vit_layers; ++l) {
+            const VitLayerW& L = e->vit[l];
+            HIPCK(launch_layernorm(e->v_x, D, L.ln1g, L.ln1b, 1e-5f, nullptr, e->v_h, D, e->f32, nullptr, 0, M, D, 0, 0, 0, s));
+            RCK(gemm(e, s, e->v_h, D, L.wqkv, L.bqkv, nullptr, 0, e->v_qkv, 3 * D, e->f32, M, 3 * D, D, 0, TAG_GEMM_VIT));
+            AttnFullArgs a{};
+            a.q = e->v_qkv;
+            a.k = (char*)e->v_qkv + (size_t)D * e->esz;
+            a.v = (char*)e->v_qkv + (size_t)2 * D * e->esz;
+            a.out = e->v_ctx;
+            a.ldq = a.ldk = a.ldv = 3 * D;
+            a.ldo = D;
+            a.N = N; a.H = c.vit_heads; a.scale = 0.125f;
+            HIPCK(launch_attn_full(a, B, e->f32, e->attn_impl, s));
+            RCK(gemm(e, s, e->v_ctx, D, L.wo, L.bo, e->v_x, D, e->v_x, D, true, M, D, D, 0, TAG_GEMM_VIT));
+            HIPCK(launch_layernorm(e->v_x, D, L.ln2g, L.ln2b, 1e-5f, nullptr, e->v_h, D, e->f32, nullptr, 0, M, D, 0, 0, 0, s));
+            RCK(gemm(e, s, e->v_h, D, L.w1, L.b1, nullptr, 0, e->v_u, 4 * D, e->f32, M, 4 * D, D, 1, TAG_GEMM_VIT));
+            RCK(gemm(e, s, e->v_u, 4 * D, L.w2, L.b2, e->v_x, D, e->v_x, D, true, M, D, 4 * D, 0, TAG_GEMM_VIT));
+        }
+        const float* te = c.num_frames > 0 ? e->temb[fr] : nullptr;
+        HIPCK(launch_layernorm(e->v_x, D, e->lnpost_g, e->lnpost_b, 1e-5f, te, e->feats, D, e->f32, feats_out, D, M, D,
+                               N, Nimg, fr * N, s));
+    }
+    e->cur_B = B; e->cur_F = F_eff; e->cur_Nimg = Nimg;
+    e->have_feats = true;
+    e->have_prefill = false;
+    return 0;
+}
+
+static int prefill_impl(gitmi_engine* e, hipStream_t s) {
+    const gitmi_config& c = e->cfg;
+    const int d = c.dec_hidden, ffn = c.dec_ffn, D = c.vit_width;
+    const int B = e->cur_B, Nimg = e->cur_Nimg, M = B * Nimg;
+    SpanGuard phase(e, s, TAG_PREFILL, 0);
+    RCK(gemm(e, s, e->feats, D, e->vp_w, e->vp_b, nullptr, 0, e->p_y, d, true, M, d, D, 0, TAG_GEMM_OTHER));
+    HIPCK(launch_layernorm(e->p_y, d, e->vp_lng, e->vp_lnb, 1e-5f, nullptr, e->p_ht, d, e->f32, e->p_hf, d, M, d, 0, 0, 0, s));
+    for (int l = 0; l < c.dec_layers; ++l) {
+        const DecLayerW& L = e->dec[l];
+        const bool last = l + 1 == c.dec_layers;
+        if (!last) {
+            RCK(gemm(e, s, e->p_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->img_kv[l], 3 * d, e->f32, M, 3 * d, d, 0, TAG_GEMM_OTHER));
+        } else {
+            // the last layer's image-row outputs are never consumed: only its K and V are needed
+            RCK(gemm(e, s, e->p_ht, d, (char*)L.wqkv + (size_t)d * d * e->esz, L.bqkv + d, nullptr, 0,
+                     (char*)e->img_kv[l] + (size_t)d * e->esz, 3 * d, e->f32, M, 2 * d, d, 0, TAG_GEMM_OTHER));
+            break;
+        }
+        AttnFullArgs a{};
+        a.q = e->img_kv[l];
+        a.k = (char*)e->img_kv[l] + (size_t)d * e->esz;
+        a.v = (char*)e->img_kv[l] + (size_t)2 * d * e->esz;
+        a.out = e->p_ctx;
+        a.ldq = a.ldk = a.ldv = 3 * d;
+        a.ldo = d;
+        a.N = Nimg; a.H = c.dec_heads; a.scale = 0.125f;
+        HIPCK(launch_attn_full(a, B, e->f32, e->attn_impl, s));
+        RCK(gemm(e, s, e->p_ctx, d, L.wo, L.bo, e->p_hf, d, e->p_y, d, true, M, d, d, 0, TAG_GEMM_OTHER));
+        HIPCK(launch_layernorm(e->p_y, d, L.lnag, L.lnab, 1e-12f, nullptr, e->p_ht, d, e->f32, e->p_hf, d, M, d, 0, 0, 0, s));
+        RCK(gemm(e, s, e->p_ht, d, L.w1, L.b1, nullptr, 0, e->p_u, ffn, e->f32, M, ffn, d, 2, TAG_GEMM_OTHER));
+        RCK(gemm(e, s, e->p_u, ffn, L.w2, L.b2, e->p_hf, d, e->p_y, d, true, M, d, ffn, 0, TAG_GEMM_OTHER));
+        HIPCK(launch_layernorm(e->p_y, d, L.lnog, L.lnob, 1e-12f, nullptr, e->p_ht, d, e->f32, e->p_hf, d, M, d, 0, 0, 0, s));
+    }
+    e->have_prefill = true;
+    return 0;
+}
+
+// one text position for every row of the beam batch
+static int decode_step_impl(gitmi_engine* e, const int* ids, const int* kv_src, int ld_ids, int pos, int R,
+                            int beams, bool want_logits, hipStream_t s) {
+    const gitmi_config& c = e->cfg;
+    const int d = c.dec_hidden, ffn = c.dec_ffn;
+    const int B = R / beams;
+    SpanGuard step(e, s, TAG_STEP, 0);
+    HIPCK(launch_embed_ln(ids, ld_ids, pos, e->words_f, e->positions_f, e->emb_lng, e->emb_lnb, 1e-8f, e->d_hf,
+                          e->d_ht, e->f32, R, d, c.vocab, s));
+    for (int l = 0; l < c.dec_layers; ++l) {
+        const DecLayerW& L = e->dec[l];
+        RCK(gemm(e, s, e->d_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->d_qkv, 3 * d, e->f32, R, 3 * d, d, 0, TAG_GEMM_OTHER));
+        AttnDecodeArgs a{};
+        a.qkv = e->d_qkv; a.img_kv = e->img_kv[l]; a.txt_k = e->txt_k[l]; a.txt_v = e->txt_v[l]; a.out = e->d_ctx;
+        a.kv_src = kv_src; a.ld_src = ld_ids; a.d = d; a.N_img = e->cur_Nimg; a.T_max = c.max_text_len;
+        a.pos = pos; a.beams = beams; a.scale = 0.125f;
+        HIPCK(launch_attn_decode(a, B, c.dec_heads, e->f32, s));
+        RCK(gemm(e, s, e->d_ctx, d, L.wo, L.bo, e->d_hf, d, e->d_y, d, true, R, d, d, 0, TAG_GEMM_OTHER));
+        HIPCK(launch_layernorm(e->d_y, d, L.lnag, L.lnab, 1e-12f, nullptr, e->d_ht, d, e->f32, e->d_hf, d, R, d, 0, 0, 0, s));
+        RCK(gemm(e, s, e->d_ht, d, L.w1, L.b1, nullptr, 0, e->d_u, ffn, e->f32, R, ffn, d, 2, TAG_GEMM_OTHER));
+        RCK(gemm(e, s, e->d_u, ffn, L.w2, L.b2, e->d_hf, d, e->d_y, d, true, R, d, ffn, 0, TAG_GEMM_OTHER));
+        HIPCK(launch_layernorm(e->d_y, d, L.lnog, L.lnob, 1e-12f, nullptr, e->d_ht, d, e->f32, e->d_hf, d, R, d, 0, 0, 0, s));
+    }
+    if (want_logits)
+        RCK(gemm(e, s, e->d_ht, d, e->out_w, e->out_b, nullptr, 0, e->logits, e->ldl, true, R, c.vocab, d, 0, TAG_GEMM_OTHER));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+static int check_ready(gitmi_engine* e) {
+    if (!e) return fail("null engine");
+    if (!e->finalized) return fail("weights not finalized (call gitmi_finalize_weights)");
+    HIPCK(hipSetDevice(e->device));
+    return 0;
+}
+
+extern "C" int gitmi_encode_frames(gitmi_engine* e, const float* const* frames, int F, int B, float* feats_out,
+                                   void* stream) {
+    RCK(check_ready(e));
+    if (!frames || F < 1 || F > e->cfg.max_frames) return fail("encode_frames: F=%d outside [1,%d]", F, e->cfg.max_frames);
+    if (B < 1 || B > e->cfg.max_batch) return fail("encode_frames: B=%d outside [1,%d]", B, e->cfg.max_batch);
+    return encode_frames_impl(e, frames, F, B, feats_out, (hipStream_t)stream);
+}
+
+extern "C" int gitmi_prefill(gitmi_engine* e, void* stream) {
+    RCK(check_ready(e));
+    if (!e->have_feats) return fail("prefill: no encoded frames");
+    return prefill_impl(e, (hipStream_t)stream);
+}
+
+extern "C" int gitmi_step_logits(gitmi_engine* e, const int64_t* tokens, int R, int t, float* logits_out, void* stream) {
+    RCK(check_ready(e));
+    if (!e->have_feats) return fail("step_logits: no encoded frames");
+    hipStream_t s = (hipStream_t)stream;
+    if (!e->have_prefill) RCK(prefill_impl(e, s));
+    const int B = e->cur_B;
+    if (R < B || R % B) return fail("step_logits: R=%d is not a multiple of the encoded batch %d", R, B);
+    const int beams = R / B;
+    if (beams > e->cfg.max_beams) return fail("step_logits: %d beams exceed max_beams", beams);
+    if (t < 1 || t > e->cfg.max_text_len) return fail("step_logits: t=%d outside [1,%d]", t, e->cfg.max_text_len);
+    const int T = e->cfg.max_text_len;
+    HIPCK(launch_load_ids((const long long*)tokens, R, t, e->ss.ids[0], e->ss.kv_src[0], T, s));
+    // note: load_ids writes rows of length ld = T_max
+    for (int pos = 0; pos < t; ++pos)
+        RCK(decode_step_impl(e, e->ss.ids[0], e->ss.kv_src[0], T, pos, R, beams, pos == t - 1, s));
+    HIPCK(launch_copy_f32(e->logits, e->ldl, logits_out, e->cfg.vocab, R, e->cfg.vocab, s));
+    return 0;
+}
+
+// ---- search seam -----------------------------------------------------------------------
+static int search_begin_impl(gitmi_engine* e, const gitmi_search* sp, int B, const long long* start_dev, int P, int V,
+                             hipStream_t s) {
+    const gitmi_config& c = e->cfg;
+    if (!sp) return fail("search: null config");
+    if (sp->kind != GITMI_SEARCH_AUTOREGRESSIVE && sp->kind != GITMI_SEARCH_GENERATOR) return fail("search: bad kind");
+    if (B < 1 || B > c.max_batch) return fail("search: B=%d outside [1,%d]", B, c.max_batch);
+    if (sp->beam_size < 1 || sp->beam_size > c.max_beams) return fail("search: beam_size %d outside [1,%d]", sp->beam_size, c.max_beams);
+    if (sp->per_node_beam_size < 1) return fail("search: per_node_beam_size must be >= 1");
+    if (sp->kind == GITMI_SEARCH_GENERATOR && sp->per_node_beam_size < 2)
+        return fail("search: GeneratorWithBeamSearch requires per_node_beam_size > 1 (decoder.py:1078)");
+    if (sp->beam_size * sp->per_node_beam_size > 16) return fail("search: beam_size*per_node_beam_size > 16 unsupported");
+    if (sp->max_steps > c.max_text_len) return fail("search: max_steps %d exceeds max_text_len %d", sp->max_steps, c.max_text_len);
+    if (P < 1 || P > sp->max_steps) return fail("search: prefix length %d outside [1,max_steps]", P);
+    if (sp->kind == GITMI_SEARCH_GENERATOR && !(sp->length_penalty > 0)) return fail("search: length_penalty must be > 0");
+    SearchState& st = e->ss;
+    st.B = B; st.k = sp->beam_size; st.pn = sp->per_node_beam_size; st.P = P;
+    st.T = sp->max_steps;           // max_length of the search AND the row stride of ids/kv_src/hyp_tok
+    st.V = V; st.eos = c.eos; st.kind = sp->kind; st.length_penalty = sp->length_penalty;
+    e->ss_cur = 0; e->ss_len = P; e->ss_first = true;
+    e->ss_M = 0;
+    HIPCK(launch_search_init(st, start_dev, s));
+    return 0;
+}
+
+static int search_advance_impl(gitmi_engine* e, const float* logits, int ldl, hipStream_t s) {
+    const SearchState& st = e->ss;
+    const int R = st.B * st.k;
+    const int cur_len = e->ss_len;
+    if (cur_len >= st.T) return fail("search_advance: sequence already at max_steps");
+    if (st.kind == GITMI_SEARCH_AUTOREGRESSIVE) {
+        const int first = e->ss_first ? 1 : 0;
+        const int M = first ? st.k : st.pn;
+        HIPCK(launch_row_topm(logits, ldl, st.V, st.ids[e->ss_cur], st.T, cur_len, st.eos, first ? 0 : 1, first ? 0 : 1, M,
+                              R, st.cand_val, st.cand_idx, s));
+        HIPCK(launch_s1_advance(st, e->ss_cur, cur_len, first, M, s));
+    } else {
+        const int M = st.pn * st.k;
+        HIPCK(launch_row_topm(logits, ldl, st.V, st.ids[e->ss_cur], st.T, cur_len, st.eos, 0, 0, M, R, st.cand_val,
+                              st.cand_idx, s));
+        HIPCK(launch_s2_advance(st, e->ss_cur, cur_len, M, s));
+    }
+    e->ss_cur ^= 1;
+    e->ss_len = cur_len + 1;
+    e->ss_first = false;
+    return 0;
+}
+
+extern "C" int gitmi_search_begin(gitmi_engine* e, const gitmi_search* sp, int B, const int64_t* start_host, int P,
+                                  int vocab, void* stream) {
+    RCK(check_ready(e));
+    if (!start_host) return fail("search_begin: null start");
+    if (B < 1 || B > e->cfg.max_batch || P < 1 || P > e->cfg.max_text_len) return fail("search_begin: bad B/P");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCK(hipMemcpyAsync(e->start_dev, start_host, (size_t)B * P * sizeof(long long), hipMemcpyHostToDevice, s));
+    HIPCK(hipStreamSynchronize(s));
+    if (vocab < 2) return fail("search_begin: bad vocab");
+    return search_begin_impl(e, sp, B, e->start_dev, P, vocab, s);
+}
+
+extern "C" int gitmi_search_rows(gitmi_engine* e, int64_t* tokens_out, int* R, int* t, void* stream) {
+    RCK(check_ready(e));
+    const SearchState& st = e->ss;
+    if (R) *R = st.B * st.k;
+    if (t) *t = e->ss_len;
+    if (tokens_out) HIPCK(launch_search_rows(st, e->ss_cur, e->ss_len, (long long*)tokens_out, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int gitmi_search_advance(gitmi_engine* e, const float* logits, void* stream) {
+    RCK(check_ready(e));
+    if (!logits) return fail("search_advance: null logits");
+    return search_advance_impl(e, logits, e->ss.V, (hipStream_t)stream);
+}
+
+extern "C" int gitmi_search_finish(gitmi_engine* e, int64_t* tokens_out, float* logprob_out, int32_t* info_out,
+                                   void* stream) {
+    RCK(check_ready(e));
+    const SearchState& st = e->ss;
+    HIPCK(launch_search_finish(st, e->ss_cur, e->ss_len, (long long*)tokens_out, logprob_out, info_out,
+                               (hipStream_t)stream));
+    return 0;
+}
+
+// ---- the whole hot path ------------------------------------------------------------------
+static int generate_body(gitmi_engine* e, const float* const* frames, int F, int B, const long long* start_dev, int P,
+                         const gitmi_search* sp, long long* tokens_out, float* logprob_out, int32_t* info_out,
+                         hipStream_t s, bool allow_poll) {
+    SpanGuard total(e, s, 99, 0);
+    RCK(encode_frames_impl(e, frames, F, B, nullptr, s));
+    RCK(prefill_impl(e, s));
+    RCK(search_begin_impl(e, sp, B, start_dev, P, e->cfg.vocab, s));
+    const int T = sp->max_steps;
+    const SearchState& st = e->ss;
+    const int R = B * sp->beam_size;
+    {
+        SpanGuard phase(e, s, TAG_DECODE, 0);
+        // teacher-forced prefix positions (VQA question tokens): no logits needed
+        for (int pos = 0; pos + 1 < P; ++pos)
+            RCK(decode_step_impl(e, st.ids[0], st.kv_src[0], T, pos, R, sp->beam_size, false, s));
+        while (e->ss_len < T) {
+            RCK(decode_step_impl(e, st.ids[e->ss_cur], st.kv_src[e->ss_cur], T, e->ss_len - 1, R, sp->beam_size, true, s));
+            RCK(search_advance_impl(e, e->logits, e->ldl, s));
+            // long step budgets (the shipped default is max_steps=1024, model.py:37): every 8 steps read
+            // the device-side "every sentence finished" flag so the loop ends like decoder.py:319 / :1251.
+            // Extra steps past that point are idempotent, so polling sparsely is exact.
+            if (allow_poll && (e->ss_len - P) % 8 == 0 && e->ss_len < T) {
+                int h[4];
+                HIPCK(hipMemcpyAsync(h, st.info, sizeof(h), hipMemcpyDeviceToHost, s));
+                HIPCK(hipStreamSynchronize(s));
+                if (sp->kind == GITMI_SEARCH_AUTOREGRESSIVE ? h[0] != 0 : h[3] != 0) break;
+            }
+        }
+    }
+    HIPCK(launch_search_finish(st, e->ss_cur, e->ss_len, tokens_out, logprob_out, info_out, s));
+    // algorithmic bytes of one decode step: all decoder weights once +
+    // per image the K/V of every layer (image part shared by beams, text part per beam)
+    const double kv = (double)B * e->cfg.dec_layers * 2.0 * ((double)e->cur_Nimg + sp->beam_size * 0.5 * (P + T)) *
+                      e->cfg.dec_hidden * e->esz;
+    e->last_decode_step_bytes = e->dec_weight_bytes + kv;
+    return 0;
+}
+
+extern "C" int gitmi_generate(gitmi_engine* e, const float* const* frames, int F, int B, const int64_t* prefix, int P,
+                              const gitmi_search* sp, int64_t* tokens_out, float* logprob_out, int32_t* info_out,
+                              void* stream) {
+    RCK(check_ready(e));
+    const gitmi_config& c = e->cfg;
+    if (!frames || !sp || !tokens_out || !logprob_out || !info_out) return fail("generate: null argument");
+    if (F < 1 || F > c.max_frames) return fail("generate: F=%d outside [1,%d]", F, c.max_frames);
+    if (B < 1 || B > c.max_batch) return fail("generate: B=%d outside [1,%d]", B, c.max_batch);
+    if (!prefix) P = 1;
+    if (P < 1 || P > c.max_text_len) return fail("generate: prefix length %d outside [1,%d]", P, c.max_text_len);
+    if (sp->max_steps < P || sp->max_steps > c.max_text_len) return fail("generate: max_steps %d outside [P,%d]", sp->max_steps, c.max_text_len);
+    hipStream_t s = (hipStream_t)stream;
+
+    // start tokens [B, P] on device (shared prefix, or [CLS])
+    std::vector<long long> start((size_t)B * P);
+    if (prefix) {
+        std::vector<long long> pf(P);
+        HIPCK(hipMemcpyAsync(pf.data(), prefix, (size_t)P * sizeof(long long), hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+        for (int b = 0; b < B; ++b) std::copy(pf.begin(), pf.end(), start.begin() + (size_t)b * P);
+    } else {
+        std::fill(start.begin(), start.end(), (long long)c.sos);
+    }
+    HIPCK(hipMemcpyAsync(e->start_dev, start.data(), start.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+    HIPCK(hipStreamSynchronize(s));   // `start` is a stack-lifetime host buffer
+
+    const bool long_budget = sp->max_steps - P > 32;
+    const bool graph = e->use_graph && !e->profiling && !long_budget;
+    if (!graph)
+        return generate_body(e, frames, F, B, e->start_dev, P, sp, (long long*)tokens_out, logprob_out, info_out, s,
+                             long_budget && !e->profiling);
+
+    // ---- hipGraph path: the launch sequence only depends on (B,F,P,search); inputs and outputs are
+    // staged through engine-owned buffers so the captured pointers stay valid across calls.
+    // The legacy null stream cannot be captured: run on the engine's own stream, fenced by events.
+    hipStream_t x = s ? s : e->own_stream;
+    if (x != s) {
+        HIPCK(hipEventRecord(e->fence_in, s));
+        HIPCK(hipStreamWaitEvent(x, e->fence_in, 0));
+    }
+    const size_t frame_bytes = (size_t)B * 3 * c.image_size * c.image_size * sizeof(float);
+    const int F_eff = c.num_frames > 0 ? std::min(F, c.num_frames) : F;
+    for (int f = 0; f < F_eff; ++f)
+        HIPCK(hipMemcpyAsync(e->frame_stage[f], frames[f], frame_bytes, hipMemcpyDeviceToDevice, x));
+    gitmi_engine::GraphKey key{};
+    key.B = B; key.F = F_eff; key.P = P; key.kind = sp->kind; key.k = sp->beam_size; key.pn = sp->per_node_beam_size;
+    key.T = sp->max_steps; key.lp = sp->length_penalty;
+    if (!e->graph_valid || !(key == e->graph_key)) {
+        destroy_graph(e);
+        std::vector<const float*> fp(F_eff);
+        for (int f = 0; f < F_eff; ++f) fp[f] = e->frame_stage[f];
+        HIPCK(hipStreamBeginCapture(x, hipStreamCaptureModeThreadLocal));
+        int rc = generate_body(e, fp.data(), F_eff, B, e->start_dev, P, sp, e->out_tokens, e->out_lp, e->out_info, x, false);
+        hipGraph_t gr = nullptr;
+        hipError_t ce = hipStreamEndCapture(x, &gr);
+        if (rc != 0) { if (gr) hipGraphDestroy(gr); return rc; }
+        HIPCK(ce);
+        e->graph = gr;
+        HIPCK(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+        e->graph_key = key;
+        e->graph_valid = true;
+    } else {
+        // host-side mirror of the state generate_body leaves behind
+        e->cur_B = B; e->cur_F = F_eff; e->cur_Nimg = F_eff * e->N;
+        e->have_feats = e->have_prefill = true;
+    }
+    HIPCK(hipGraphLaunch(e->graph_exec, x));
+    HIPCK(hipMemcpyAsync(tokens_out, e->out_tokens, (size_t)B * sp->max_steps * sizeof(long long), hipMemcpyDeviceToDevice, x));
+    HIPCK(hipMemcpyAsync(logprob_out, e->out_lp, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, x));
+    HIPCK(hipMemcpyAsync(info_out, e->out_info, 4 * sizeof(int), hipMemcpyDeviceToDevice, x));
+    if (x != s) {
+        HIPCK(hipEventRecord(e->fence_out, x));
+        HIPCK(hipStreamWaitEvent(s, e->fence_out, 0));
+    }
+    return 0;
+}
+
+// ---- profiling --------------------------------------------------------------------------
+extern "C" int gitmi_profile_enable(gitmi_engine* e, int on) {
+    if (!e) return fail("null engine");
+    e->profiling = on != 0;
+    e->spans.clear();
+    e->event_next = 0;
+    return 0;
+}
+extern "C" int gitmi_set_graph(gitmi_engine* e, int on) {
+    if (!e) return fail("null engine");
+    e->use_graph = on != 0;
+    return 0;
+}
+extern "C" int gitmi_profile_read(gitmi_engine* e, gitmi_profile* out) {
+    if (!e || !out) return fail("null argument");
+    HIPCK(hipSetDevice(e->device));
+    HIPCK(hipDeviceSynchronize());
+    memset(out, 0, sizeof(*out));
+    double step_ms = 0;
+    for (const TimedSpan& sp : e->spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
+        switch (sp.tag) {
+            case TAG_VIT: out->vit_ms += ms; break;
+            case TAG_PREFILL: out->prefill_ms += ms; break;
+            case TAG_DECODE: out->decode_ms += ms; break;
+            case 99: out->total_ms += ms; break;
+            case TAG_STEP: step_ms += ms; out->decode_steps += 1; break;
+            case TAG_GEMM_VIT:
+                out->vit_gemm_ms += ms; out->vit_gemm_launches += 1; out->vit_gemm_flops += sp.flops;
+                // fallthrough
+            case TAG_GEMM_OTHER:
+                out->gemm_ms += ms; out->gemm_launches += 1; out->gemm_flops += sp.flops;
+                break;
+            default: break;
+        }
+    }
+    out->decode_step_ms = out->decode_steps ? (float)(step_ms / out->decode_steps) : 0.f;
+    out->decode_step_bytes = e->last_decode_step_bytes;
+    e->spans.clear();
+    e->event_next = 0;
+    return 0;
+}
+
+// ---- single-kernel entry points ------------------------------------------------------------
+extern "C" int gitmi_op_gemm(const void* A, const void* W, const float* bias, const float* residual, void* C, int M,
+                             int N, int K, int lda, int ldc, int in_dtype, int out_dtype, int act, void* stream) {
+    GemmArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.res = residual; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldc; g.act = act;
+    const bool in_f32 = in_dtype == GITMI_DTYPE_F32;
+    if ((in_f32 && K % 16) || (!in_f32 && K % 64)) return fail("op_gemm: K must be a multiple of %d", in_f32 ? 16 : 64);
+    HIPCK(launch_gemm(g, in_f32, out_dtype == GITMI_DTYPE_F32, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int gitmi_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, void* y_t,
+                                  float* y_f32, int rows, int D, int out_dtype, void* stream) {
+    HIPCK(launch_layernorm(x, D, gamma, beta, eps, nullptr, y_t, D, out_dtype == GITMI_DTYPE_F32, y_f32, D, rows, D, 0, 0,
+                           0, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int gitmi_op_attention(const void* qkv, void* out, int B, int N, int H, int dtype, int impl, void* stream) {
+    const size_t esz = dtype == GITMI_DTYPE_F32 ? 4 : 2;
+    const int D = H * 64;
+    AttnFullArgs a{};
+    a.q = qkv;
+    a.k = (const char*)qkv + (size_t)D * esz;
+    a.v = (const char*)qkv + (size_t)2 * D * esz;
+    a.out = out;
+    a.ldq = a.ldk = a.ldv = 3 * D;
+    a.ldo = D;
+    a.N = N; a.H = H; a.scale = 0.125f;
+    if (attn_decode_configure() != hipSuccess) return fail("configure failed");
+    HIPCK(launch_attn_full(a, B, dtype == GITMI_DTYPE_F32, impl, (hipStream_t)stream));
+    return 0;
+}

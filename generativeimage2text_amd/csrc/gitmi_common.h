@@ -1,0 +1,83 @@
+// Device-side helpers shared by all gfx950 kernels of the GIT engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;   // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+#define GITMI_WAVE 64
+
+// ---- bf16 <-> f32 (round-to-nearest-even; NaN kept quiet) --------------------------
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ---- typed element access: T is float (exact path) or bf16_t (fast path) ----------
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// load 8 consecutive elements as floats (16-byte aligned for bf16, 32 for float)
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+    u32x4_t r = *reinterpret_cast<const u32x4_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(r[i] << 16);
+        v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+    f32x4_t a = *reinterpret_cast<const f32x4_t*>(p);
+    f32x4_t b = *reinterpret_cast<const f32x4_t*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+    u32x4_t r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+    *reinterpret_cast<u32x4_t*>(p) = r;
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+    f32x4_t a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    *reinterpret_cast<f32x4_t*>(p) = a;
+    *reinterpret_cast<f32x4_t*>(p + 4) = b;
+}
+
+// ---- 64-lane wave reductions -------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// activation codes shared with the host
+#define GITMI_ACT_NONE 0
+#define GITMI_ACT_QUICKGELU 1   // x * sigmoid(1.702 x)            CLIP/model.py:171-173
+#define GITMI_ACT_GELU_ERF 2    // 0.5 x (1 + erf(x / sqrt 2))     bert/activations.py:15-22
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    if (act == GITMI_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
+    if (act == GITMI_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    return x;
+}

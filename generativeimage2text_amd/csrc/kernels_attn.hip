@@ -1,0 +1,438 @@
+// Attention kernels of the GIT engine (head_dim is 64 everywhere: ViT-B/16, ViT-L/14, decoder).
+//
+//  attn_full_valu   : unmasked multi-head attention, fp32 math on the vector ALUs, any dtype.
+//                     Reference / exact-precision path and the checker for the MFMA kernel.
+//  attn_full_mfma   : same contract, bf16 MFMA flash kernel (swapped QK^T so that softmax
+//                     statistics are lane-local, online softmax over 64-key tiles).
+//  attn_decode      : one new text position per row against [shared image K/V | per-beam text K/V]
+//                     with beam indirection (no KV copies when beams are re-ordered).
+//
+// Replaces nn.MultiheadAttention in CLIP/model.py:189-197 and BertSelfAttention/qk2attn in
+// modeling_bert.py:41-47,122-159.  The additive block mask of decoder.py:111-149
+// (image->image 0, image->text -inf, text->image 0, text->text causal) is never materialised:
+// image rows run the unmasked kernel over image keys only, text rows see all image keys plus
+// text keys <= their own position.
+#include "gitmi_common.h"
+#include "launchers.h"
+
+namespace gitmi {
+
+constexpr int HD = 64;
+
+// ---------------------------------------------------------------------------------------
+// VALU kernel: block = 4 waves, each wave owns 4 query rows; K/V tiles of 64 keys in LDS (fp32).
+// grid = (ceil(N/16), H, B)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_full_valu_kernel(AttnFullArgs a) {
+    __shared__ float Ks[64][HD + 1];
+    __shared__ float Vs[64][HD + 1];
+    __shared__ float qs[16][HD];
+    __shared__ float ps[16][64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 16;
+    const T* Q = reinterpret_cast<const T*>(a.q);
+    const T* K = reinterpret_cast<const T*>(a.k);
+    const T* V = reinterpret_cast<const T*>(a.v);
+    T* O = reinterpret_cast<T*>(a.out);
+    const size_t base_row = (size_t)b * a.N;
+
+    for (int i = tid; i < 16 * HD; i += 256) {
+        const int qi = i / HD, d = i % HD;
+        const int qr = q0 + qi;
+        qs[qi][d] = qr < a.N ? ld<T>(Q + (base_row + qr) * a.ldq + h * HD + d) * a.scale : 0.f;
+    }
+
+    float m_run[4], l_run[4], o_acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { m_run[j] = -INFINITY; l_run[j] = 0.f; o_acc[j] = 0.f; }
+
+    for (int kt = 0; kt < a.N; kt += 64) {
+        __syncthreads();   // previous tile fully consumed (also orders the qs fill on the first pass)
+        for (int i = tid; i < 64 * HD; i += 256) {
+            const int key = i / HD, d = i % HD;
+            const int kr = kt + key;
+            float kv = 0.f, vv = 0.f;
+            if (kr < a.N) {
+                kv = ld<T>(K + (base_row + kr) * a.ldk + h * HD + d);
+                vv = ld<T>(V + (base_row + kr) * a.ldv + h * HD + d);
+            }
+            Ks[key][d] = kv;
+            Vs[key][d] = vv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int qi = wave * 4 + j;
+            // lane = key
+            float s = 0.f;
+#pragma unroll 16
+            for (int d = 0; d < HD; ++d) s += qs[qi][d] * Ks[lane][d];
+            if (kt + lane >= a.N) s = -INFINITY;
+            const float m_new = fmaxf(m_run[j], wave_max(s));
+            const float p = __expf(s - m_new);             // exp(-inf) = 0 for masked keys
+            const float alpha = __expf(m_run[j] - m_new);  // first tile: exp(-inf) = 0
+            l_run[j] = l_run[j] * alpha + wave_sum(p);
+            m_run[j] = m_new;
+            ps[qi][lane] = p;
+            // wave-private row of ps: written and read by this wave only, LDS ops are in order
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // lane = dim
+            float o = o_acc[j] * alpha;
+#pragma unroll 16
+            for (int key = 0; key < 64; ++key) o += ps[qi][key] * Vs[key][lane];
+            o_acc[j] = o;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int qr = q0 + wave * 4 + j;
+        if (qr < a.N) st<T>(O + (base_row + qr) * a.ldo + h * HD + lane, o_acc[j] / l_run[j]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// MFMA flash kernel (bf16).  Block = 4 waves, 64 query rows (16 per wave), key tiles of 64.
+//   S^T[key][query] = K_tile . Q^T      (MFMA A = K rows from LDS, B = Q rows from registers)
+//   O^T[dim][query] += V^T_tile . P^T   (MFMA A = V^T rows from LDS, B = P^T from registers)
+// In both products the lane's column is its query (lane & 15), so row max / row sum / the
+// rescale factor never leave the lane group {l, l^16, l^32, l^48}.
+// The 32-deep contraction of the second product enumerates keys in the order the first
+// product's accumulators already hold them: slot j<4 -> key 4g+j, slot j>=4 -> key 16+4g+(j-4)
+// (g = lane>>4) inside each 32-key half tile; V^T is read with the same permutation.
+// grid = (ceil(N/64), H, B)
+// ---------------------------------------------------------------------------------------
+constexpr int FA_LDK = HD + 8;    // K tile row stride (bf16): 144 B, conflict-free b128 reads
+constexpr int FA_LDV = 64 + 8;    // V^T tile row stride (keys)
+
+__global__ __launch_bounds__(256) void attn_full_mfma_kernel(AttnFullArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * FA_LDK];   // [key][dim]
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[HD * FA_LDV];   // [dim][key]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q);
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k);
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v);
+    bf16_t* O = reinterpret_cast<bf16_t*>(a.out);
+    const size_t base_row = (size_t)b * a.N;
+
+    // Q^T operand (B of the first product): lane = query l15, dims lg*8 + 32*s .. +8
+    bf16x8_t qf[2];
+    {
+        int qr = q0 + l15;
+        qr = qr < a.N ? qr : a.N - 1;
+        const bf16_t* qp = Q + (base_row + qr) * a.ldq + h * HD + lg * 8;
+        qf[0] = *reinterpret_cast<const bf16x8_t*>(qp);
+        qf[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+    }
+
+    f32x4_t o_acc[4];   // O^T[dim = dt*16 + lg*4 + r][query = l15]
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o_acc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // cooperative tile load mapping: 64 rows x 8 chunks(16 B) = 512 chunks, 2 per thread
+    const int ld_row = tid >> 3;          // 0..31 (+32)
+    const int ld_c = (tid & 7) * 8;       // dim offset of the chunk
+
+    for (int kt = 0; kt < a.N; kt += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int key = ld_row + it * 32;
+            int kr = kt + key;
+            kr = kr < a.N ? kr : a.N - 1;          // clamped rows are masked below
+            const u32x4_t kc = *reinterpret_cast<const u32x4_t*>(K + (base_row + kr) * a.ldk + h * HD + ld_c);
+            const u32x4_t vc = *reinterpret_cast<const u32x4_t*>(V + (base_row + kr) * a.ldv + h * HD + ld_c);
+            *reinterpret_cast<u32x4_t*>(Ks + key * FA_LDK + ld_c) = kc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {          // transpose V into [dim][key]
+                Vt[(ld_c + 2 * e) * FA_LDV + key] = (bf16_t)(vc[e] & 0xffffu);
+                Vt[(ld_c + 2 * e + 1) * FA_LDV + key] = (bf16_t)(vc[e] >> 16);
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T tile: 4 key sub-tiles of 16 -------------------------------------------
+        f32x4_t s_acc[4];
+#pragma unroll
+        for (int st_ = 0; st_ < 4; ++st_) {
+            s_acc[st_] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (st_ * 16 + l15) * FA_LDK + ks * 32 + lg * 8);
+                s_acc[st_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s_acc[st_], 0, 0, 0);
+            }
+        }
+        // lane holds keys kt + st*16 + lg*4 + r for its query
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int st_ = 0; st_ < 4; ++st_)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + st_ * 16 + lg * 4 + r;
+                const float sv = key < a.N ? s_acc[st_][r] * a.scale : -INFINITY;
+                s_acc[st_][r] = sv;
+                tmax = fmaxf(tmax, sv);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int st_ = 0; st_ < 4; ++st_)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s_acc[st_][r] - m_new);
+                s_acc[st_][r] = p;
+                psum += p;
+            }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o_acc[dt][r] *= alpha;
+
+        // ---- O^T += V^T . P^T, two 32-key halves ----------------------------------------
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            // P^T operand: slots 0-3 <- sub-tile 2*hf, slots 4-7 <- sub-tile 2*hf+1
+            bf16x8_t pf;
+            {
+                union { bf16x8_t v; uint32_t u[4]; } pk;
+                pk.u[0] = pack2bf(s_acc[2 * hf][0], s_acc[2 * hf][1]);
+                pk.u[1] = pack2bf(s_acc[2 * hf][2], s_acc[2 * hf][3]);
+                pk.u[2] = pack2bf(s_acc[2 * hf + 1][0], s_acc[2 * hf + 1][1]);
+                pk.u[3] = pack2bf(s_acc[2 * hf + 1][2], s_acc[2 * hf + 1][3]);
+                pf = pk.v;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                // V^T operand: row = dim dt*16 + l15, keys hf*32 + {4lg..4lg+3, 16+4lg..16+4lg+3}
+                union { bf16x8_t v; uint2 h2[2]; } vf;
+                const bf16_t* vp = Vt + (dt * 16 + l15) * FA_LDV + hf * 32 + lg * 4;
+                vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
+                vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 16);
+                o_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf, o_acc[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    const int qr = q0 + l15;
+    if (qr < a.N) {
+        const float inv = 1.0f / l_run;
+        bf16_t* op = O + (base_row + qr) * a.ldo + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 t;
+            t.x = pack2bf(o_acc[dt][0] * inv, o_acc[dt][1] * inv);
+            t.y = pack2bf(o_acc[dt][2] * inv, o_acc[dt][3] * inv);
+            *reinterpret_cast<uint2*>(op + dt * 16 + lg * 4) = t;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Decode attention.  grid = (H, B); block = 256 threads.  The k beams of image b share one
+// pass over the image keys/values (read once per block), text keys/values are fetched through
+// kv_src[row][pos] -> cache row, so re-ordering beams never moves KV data.
+//   qkv      : [R, 3d] this step's projections (q | k | v) for position `pos`
+//   img_kv   : [B*N_img, 3d] layer cache written by the prefill (k at +d, v at +2d)
+//   txt_k/v  : [R, T_max, d] text cache (this kernel appends position `pos`)
+//   out      : [R, d]
+// dynamic LDS: scores[k][Nk] + q[k][64] + red[32][k][64]   (Nk = N_img + pos + 1)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int k = a.beams;
+    const int Nk = a.N_img + a.pos + 1;
+    float* sc = dsm;                        // [k][Nk]
+    float* qs = sc + (size_t)k * Nk;        // [k][64]
+    float* red = qs + k * HD;               // [32][k][64]
+
+    const T* QKV = reinterpret_cast<const T*>(a.qkv);
+    const T* IMG = reinterpret_cast<const T*>(a.img_kv);
+    T* TK = reinterpret_cast<T*>(a.txt_k);
+    T* TV = reinterpret_cast<T*>(a.txt_v);
+    T* O = reinterpret_cast<T*>(a.out);
+    const int ld3 = 3 * a.d;
+    const int row0 = b * k;
+
+    // stage q (scaled) and append this position's K/V of every beam to the text cache
+    for (int i = tid; i < k * HD; i += 256) {
+        const int j = i / HD, dd = i % HD;
+        const T* src = QKV + (size_t)(row0 + j) * ld3 + h * HD + dd;
+        qs[i] = ld<T>(src) * a.scale;
+        const size_t dst = ((size_t)(row0 + j) * a.T_max + a.pos) * a.d + h * HD + dd;
+        TK[dst] = src[a.d];
+        TV[dst] = src[2 * a.d];
+    }
+    __syncthreads();
+
+    const int grp = tid >> 3, sub = tid & 7;    // 32 groups of 8 lanes; a group reads one 64-dim row
+
+    // ---- scores over image keys: every beam uses the same key row ----------------------
+    for (int n = grp; n < a.N_img; n += 32) {
+        float kv[8];
+        ld8(IMG + ((size_t)b * a.N_img + n) * ld3 + a.d + h * HD + sub * 8, kv);
+        for (int j = 0; j < k; ++j) {
+            float p = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) p += qs[j * HD + sub * 8 + e] * kv[e];
+            p += __shfl_xor(p, 1, 64);
+            p += __shfl_xor(p, 2, 64);
+            p += __shfl_xor(p, 4, 64);
+            if (sub == 0) sc[(size_t)j * Nk + n] = p;
+        }
+    }
+    // ---- scores over text keys (per beam, through the indirection) ---------------------
+    const int nt = a.pos + 1;
+    for (int it = grp; it < k * nt; it += 32) {
+        const int j = it / nt, s = it % nt;
+        float kv[8];
+        if (s == a.pos) {
+            ld8(QKV + (size_t)(row0 + j) * ld3 + a.d + h * HD + sub * 8, kv);
+        } else {
+            const int srow = a.kv_src[(size_t)(row0 + j) * a.ld_src + s];
+            ld8(TK + ((size_t)srow * a.T_max + s) * a.d + h * HD + sub * 8, kv);
+        }
+        float p = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p += qs[j * HD + sub * 8 + e] * kv[e];
+        p += __shfl_xor(p, 1, 64);
+        p += __shfl_xor(p, 2, 64);
+        p += __shfl_xor(p, 4, 64);
+        if (sub == 0) sc[(size_t)j * Nk + a.N_img + s] = p;
+    }
+    __syncthreads();
+
+    // ---- softmax per beam (one wave per beam, looping if k > 4) -------------------------
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int j = wave; j < k; j += 4) {
+        float* row = sc + (size_t)j * Nk;
+        float mx = -INFINITY;
+        for (int n = lane; n < Nk; n += 64) mx = fmaxf(mx, row[n]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int n = lane; n < Nk; n += 64) {
+            const float p = __expf(row[n] - mx);
+            row[n] = p;
+            sum += p;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int n = lane; n < Nk; n += 64) row[n] *= inv;
+    }
+    __syncthreads();
+
+    // ---- out = P . V : group g accumulates its keys for dims sub*8..+8, all beams -------
+    constexpr int KMAX = 8;
+    float acc[KMAX][8];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+
+    for (int n = grp; n < a.N_img; n += 32) {
+        float vv[8];
+        ld8(IMG + ((size_t)b * a.N_img + n) * ld3 + 2 * a.d + h * HD + sub * 8, vv);
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            if (j < k) {
+                const float p = sc[(size_t)j * Nk + n];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[j][e] += p * vv[e];
+            }
+        }
+    }
+    for (int it = grp; it < k * nt; it += 32) {
+        const int j = it / nt, s = it % nt;
+        float vv[8];
+        if (s == a.pos) {
+            ld8(QKV + (size_t)(row0 + j) * ld3 + 2 * a.d + h * HD + sub * 8, vv);
+        } else {
+            const int srow = a.kv_src[(size_t)(row0 + j) * a.ld_src + s];
+            ld8(TV + ((size_t)srow * a.T_max + s) * a.d + h * HD + sub * 8, vv);
+        }
+        const float p = sc[(size_t)j * Nk + a.N_img + s];
+        // beam index is data dependent here: accumulate through LDS-free select
+#pragma unroll
+        for (int jj = 0; jj < KMAX; ++jj) {
+            if (jj == j) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[jj][e] += p * vv[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        if (j < k) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[((size_t)grp * k + j) * HD + sub * 8 + e] = acc[j][e];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < k * HD; i += 256) {
+        const int j = i / HD, dd = i % HD;
+        float s = 0.f;
+#pragma unroll 8
+        for (int g = 0; g < 32; ++g) s += red[((size_t)g * k + j) * HD + dd];
+        st<T>(O + (size_t)(row0 + j) * a.d + h * HD + dd, s);
+    }
+}
+
+// ---- host launchers ------------------------------------------------------------------
+hipError_t launch_attn_full(const AttnFullArgs& a, int B, bool is_f32, int impl, hipStream_t s) {
+    if (B <= 0 || a.N <= 0) return hipSuccess;
+    if (impl == 1) {
+        if (is_f32) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(attn_full_mfma_kernel, dim3((a.N + 63) / 64, a.H, B), dim3(256), 0, s, a);
+    } else if (is_f32) {
+        hipLaunchKernelGGL(attn_full_valu_kernel<float>, dim3((a.N + 15) / 16, a.H, B), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(attn_full_valu_kernel<bf16_t>, dim3((a.N + 15) / 16, a.H, B), dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+size_t attn_decode_lds_bytes(int beams, int N_img, int pos) {
+    const size_t Nk = (size_t)N_img + pos + 1;
+    return sizeof(float) * ((size_t)beams * Nk + (size_t)beams * HD + (size_t)32 * beams * HD);
+}
+
+hipError_t attn_decode_configure() {
+    // allow the full 160 KiB of LDS as dynamic shared memory (k = 8 beams or long video contexts)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<float>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<bf16_t>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_attn_decode(const AttnDecodeArgs& a, int B, int H, bool is_f32, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (a.beams > 8) return hipErrorInvalidValue;
+    const size_t lds = attn_decode_lds_bytes(a.beams, a.N_img, a.pos);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (is_f32)
+        hipLaunchKernelGGL(attn_decode_kernel<float>, dim3(H, B), dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL(attn_decode_kernel<bf16_t>, dim3(H, B), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace gitmi

@@ -1,0 +1,266 @@
+// Row-wise / elementwise kernels of the GIT engine (HBM-bound, one wave per row):
+//   LayerNorm                      CLIP/model.py:161-168, decoder.py:35,60, modeling_bert.py:168,241
+//   patch extraction (im2col)      CLIP/model.py:242  (conv k=s=p, no bias == per-patch dot product)
+//   class token + positional add + ln_pre        CLIP/model.py:252-257
+//   word + position embedding + LayerNorm(1e-8)  decoder.py:65-78
+//   f32 -> compute-dtype weight repack
+#include "gitmi_common.h"
+#include "launchers.h"
+
+namespace gitmi {
+
+// Output-row remap: out_row = (row / n_in) * n_out + off + row % n_in.
+// Used to scatter per-frame encoder outputs into the concatenated [B, F*N, D] visual
+// feature tensor (decoder.py:847-851) without a separate torch.cat pass.
+struct RowMap {
+    int n_in, n_out, off;
+};
+__device__ __forceinline__ size_t map_row(const RowMap& m, int row) {
+    return (size_t)(row / m.n_in) * m.n_out + m.off + row % m.n_in;
+}
+
+constexpr int LN_MAXV = 16;   // supports D <= 1024 with one wave per row
+
+// y = (x - mean) * rsqrt(var + eps) * gamma + beta (+ add_after[D]);  statistics in fp32,
+// biased variance from centred values (matches at::native layer_norm numerics class).
+template <typename TOut>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        const float* __restrict__ add_after,
+                                                        TOut* __restrict__ y_t, int ld_t,
+                                                        float* __restrict__ y_f, int ld_f, int rows, int D,
+                                                        RowMap map) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < D ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < D ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    const size_t orow = map_row(map, row);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) {
+            float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+            if (add_after) o += add_after[c];
+            if (y_t) st<TOut>(y_t + orow * ld_t + c, o);
+            if (y_f) y_f[orow * ld_f + c] = o;
+        }
+    }
+}
+
+// patches[(b*g*g + gy*g + gx), c*p*p + ky*p + kx] = img[b, c, gy*p + ky, gx*p + kx]; zero pad to Kpad
+template <typename TOut>
+__global__ void im2col_kernel(const float* __restrict__ img, TOut* __restrict__ out, int B, int C, int HW,
+                              int p, int g, int K, int Kpad) {
+    const size_t total = (size_t)B * g * g * Kpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad);
+        const size_t prow = i / Kpad;
+        float val = 0.f;
+        if (k < K) {
+            const int kx = k % p, ky = (k / p) % p, c = k / (p * p);
+            const int gx = (int)(prow % g), gy = (int)((prow / g) % g), b = (int)(prow / ((size_t)g * g));
+            val = img[(((size_t)b * C + c) * HW + gy * p + ky) * HW + gx * p + kx];
+        }
+        st<TOut>(out + i, val);
+    }
+}
+
+// token row (b, n): n == 0 ? class_embedding : patch_out[b*g2 + n - 1];  + positional[n];  ln_pre.
+// Output: fp32 residual stream X[B*N, D].
+__global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __restrict__ patch_out,
+                                                              const float* __restrict__ cls,
+                                                              const float* __restrict__ pos,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps,
+                                                              float* __restrict__ X, int B, int N, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * N) return;
+    const int b = row / N, n = row % N;
+    const float* src = n == 0 ? cls : patch_out + ((size_t)b * (N - 1) + (n - 1)) * D;
+    const float* pr = pos + (size_t)n * D;
+    float v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < D ? src[c] + pr[c] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < D ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) X[(size_t)row * D + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+// x = words[ids[r, pos]] + positions[pos];  LayerNorm(eps);  -> fp32 hidden + compute-dtype hidden
+template <typename TOut>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, int ld_ids, int pos,
+                                                       const float* __restrict__ words,
+                                                       const float* __restrict__ positions,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps,
+                                                       float* __restrict__ h_f, TOut* __restrict__ h_t, int R,
+                                                       int D, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    int tok = ids[(size_t)row * ld_ids + pos];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    const float* wr = words + (size_t)tok * D;
+    const float* pr = positions + (size_t)pos * D;
+    float v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < D ? wr[c] + pr[c] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < D ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) {
+            const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+            h_f[(size_t)row * D + c] = o;
+            st<TOut>(h_t + (size_t)row * D + c, o);
+        }
+    }
+}
+
+// dst[r, 0..Kpad) = convert(src[r, 0..K)), zero padded
+template <typename TOut>
+__global__ void convert_pad_kernel(const float* __restrict__ src, TOut* __restrict__ dst, size_t rows, int K,
+                                   int Kpad) {
+    const size_t total = rows * (size_t)Kpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad);
+        const size_t r = i / Kpad;
+        st<TOut>(dst + i, k < K ? src[r * K + k] : 0.f);
+    }
+}
+
+__global__ void copy_f32_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
+                                int rows, int cols) {
+    const size_t total = (size_t)rows * cols;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / cols, c = i % cols;
+        dst[r * ldd + c] = src[r * lds + c];
+    }
+}
+
+// ---- host launchers ------------------------------------------------------------------
+static inline int grid_for(size_t total, int block) {
+    size_t g = (total + block - 1) / block;
+    return (int)(g > 8192 ? 8192 : (g == 0 ? 1 : g));
+}
+
+hipError_t launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                            const float* add_after, void* y_t, int ld_t, bool t_is_f32, float* y_f, int ld_f,
+                            int rows, int D, int map_n_in, int map_n_out, int map_off, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (D > 64 * LN_MAXV) return hipErrorInvalidValue;
+    RowMap m{map_n_in > 0 ? map_n_in : rows, map_n_in > 0 ? map_n_out : rows, map_off};
+    dim3 grid((rows + 3) / 4), block(256);
+    if (t_is_f32)
+        hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, s, x, ldx, gamma, beta, eps, add_after,
+                           (float*)y_t, ld_t, y_f, ld_f, rows, D, m);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, s, x, ldx, gamma, beta, eps, add_after,
+                           (bf16_t*)y_t, ld_t, y_f, ld_f, rows, D, m);
+    return hipGetLastError();
+}
+
+hipError_t launch_im2col(const float* img, void* out, bool out_f32, int B, int HW, int p, int K, int Kpad,
+                         hipStream_t s) {
+    const int g = HW / p;
+    const size_t total = (size_t)B * g * g * Kpad;
+    if (out_f32)
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, img, (float*)out, B,
+                           3, HW, p, g, K, Kpad);
+    else
+        hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, img, (bf16_t*)out,
+                           B, 3, HW, p, g, K, Kpad);
+    return hipGetLastError();
+}
+
+hipError_t launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* gamma,
+                                  const float* beta, float eps, float* X, int B, int N, int D, hipStream_t s) {
+    if (D > 64 * LN_MAXV) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(vit_assemble_ln_kernel, dim3((B * N + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, gamma,
+                       beta, eps, X, B, N, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_embed_ln(const int* ids, int ld_ids, int pos, const float* words, const float* positions,
+                           const float* gamma, const float* beta, float eps, float* h_f, void* h_t, bool t_is_f32,
+                           int R, int D, int vocab, hipStream_t s) {
+    if (D > 64 * LN_MAXV) return hipErrorInvalidValue;
+    dim3 grid((R + 3) / 4), block(256);
+    if (t_is_f32)
+        hipLaunchKernelGGL(embed_ln_kernel<float>, grid, block, 0, s, ids, ld_ids, pos, words, positions, gamma,
+                           beta, eps, h_f, (float*)h_t, R, D, vocab);
+    else
+        hipLaunchKernelGGL(embed_ln_kernel<bf16_t>, grid, block, 0, s, ids, ld_ids, pos, words, positions, gamma,
+                           beta, eps, h_f, (bf16_t*)h_t, R, D, vocab);
+    return hipGetLastError();
+}
+
+hipError_t launch_convert_pad(const float* src, void* dst, bool dst_f32, size_t rows, int K, int Kpad,
+                              hipStream_t s) {
+    const size_t total = rows * (size_t)Kpad;
+    if (total == 0) return hipSuccess;
+    if (dst_f32)
+        hipLaunchKernelGGL(convert_pad_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, src, (float*)dst,
+                           rows, K, Kpad);
+    else
+        hipLaunchKernelGGL(convert_pad_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, src,
+                           (bf16_t*)dst, rows, K, Kpad);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_f32(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s) {
+    const size_t total = (size_t)rows * cols;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_f32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
+    return hipGetLastError();
+}
+
+}  // namespace gitmi

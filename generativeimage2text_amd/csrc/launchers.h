@@ -1,0 +1,77 @@
+// Host-side declarations of the kernel launchers (definitions live next to the kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace gitmi {
+
+struct GemmArgs {
+    const void* A; const void* W; const float* bias; const float* res; void* C;
+    int M, N, K;
+    int lda, ldc, ldr;
+    int act;
+    int tiles_n, nwg;
+};
+hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t s);
+
+hipError_t launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                            const float* add_after, void* y_t, int ld_t, bool t_is_f32, float* y_f, int ld_f,
+                            int rows, int D, int map_n_in, int map_n_out, int map_off, hipStream_t s);
+hipError_t launch_im2col(const float* img, void* out, bool out_f32, int B, int HW, int p, int K, int Kpad,
+                         hipStream_t s);
+hipError_t launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* gamma,
+                                  const float* beta, float eps, float* X, int B, int N, int D, hipStream_t s);
+hipError_t launch_embed_ln(const int* ids, int ld_ids, int pos, const float* words, const float* positions,
+                           const float* gamma, const float* beta, float eps, float* h_f, void* h_t, bool t_is_f32,
+                           int R, int D, int vocab, hipStream_t s);
+hipError_t launch_convert_pad(const float* src, void* dst, bool dst_f32, size_t rows, int K, int Kpad,
+                              hipStream_t s);
+hipError_t launch_copy_f32(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s);
+
+struct AttnFullArgs {
+    const void* q; const void* k; const void* v; void* out;
+    int ldq, ldk, ldv, ldo;
+    int N, H;
+    float scale;
+};
+hipError_t launch_attn_full(const AttnFullArgs& a, int B, bool is_f32, int impl, hipStream_t s);
+
+struct AttnDecodeArgs {
+    const void* qkv; const void* img_kv; void* txt_k; void* txt_v; void* out;
+    const int* kv_src;
+    int ld_src;
+    int d;
+    int N_img, T_max, pos, beams;
+    float scale;
+};
+size_t attn_decode_lds_bytes(int beams, int N_img, int pos);
+hipError_t launch_attn_decode(const AttnDecodeArgs& a, int B, int H, bool is_f32, hipStream_t s);
+hipError_t attn_decode_configure();
+
+struct SearchState {
+    int B, k, pn, P, T, V, eos, kind;
+    double length_penalty;
+    int* ids[2];
+    int* kv_src[2];
+    float* score[2];
+    float* cand_val;
+    int* cand_idx;
+    int* done;
+    int* hyp_n;
+    double* hyp_score;
+    int* hyp_len;
+    int* hyp_tok;
+    int* info;
+};
+hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, int ld_ids, int cur_len, int eos,
+                           int suppress_last, int force_eos, int M, int R, float* cand_val, int* cand_idx,
+                           hipStream_t s);
+hipError_t launch_s1_advance(const SearchState& st, int src, int cur_len, int first, int M, hipStream_t s);
+hipError_t launch_s2_advance(const SearchState& st, int src, int cur_len, int M, hipStream_t s);
+hipError_t launch_search_init(const SearchState& st, const long long* start_dev, hipStream_t s);
+hipError_t launch_search_finish(const SearchState& st, int cur, int cur_len, long long* tokens_out,
+                                float* logprob_out, int* info_out, hipStream_t s);
+hipError_t launch_search_rows(const SearchState& st, int cur, int cur_len, long long* out, hipStream_t s);
+hipError_t launch_load_ids(const long long* tokens, int R, int t, int* ids, int* kv_src, int ld, hipStream_t s);
+
+}  // namespace gitmi

@@ -1,0 +1,302 @@
+"""ctypes binding of libgitmi.so (include/gitmi.h) -- the only way Python reaches the HIP kernels.
+
+PyTorch is used for device memory, streams and host<->device copies only; every FLOP of the
+hot path runs inside the shared library.  There is no CPU fallback: if the library is missing
+or no gfx950 device is present this module raises, it never silently computes on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Mapping, Optional, Sequence, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgitmi.so")
+
+PREC_BF16, PREC_F32 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+SEARCH_AUTOREGRESSIVE, SEARCH_GENERATOR = 0, 1
+ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
+
+EXPORTED_SYMBOLS = [
+    "gitmi_abi_version", "gitmi_last_error", "gitmi_create", "gitmi_destroy", "gitmi_load_tensor",
+    "gitmi_finalize_weights", "gitmi_encode_frames", "gitmi_prefill", "gitmi_step_logits",
+    "gitmi_generate", "gitmi_search_begin", "gitmi_search_rows", "gitmi_search_advance",
+    "gitmi_search_finish", "gitmi_profile_enable", "gitmi_profile_read", "gitmi_set_graph",
+    "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention",
+]
+
+
+class GitmiConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "image_size", "patch", "vit_width", "vit_layers", "vit_heads", "dec_hidden", "dec_layers",
+        "dec_heads", "dec_ffn", "vocab", "max_pos", "num_frames", "sos", "eos", "precision",
+        "max_batch", "max_beams", "max_frames", "max_text_len")]
+
+
+class GitmiSearch(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("beam_size", C.c_int32), ("per_node_beam_size", C.c_int32),
+                ("max_steps", C.c_int32), ("length_penalty", C.c_double)]
+
+
+class GitmiProfile(C.Structure):
+    _fields_ = [("vit_ms", C.c_float), ("prefill_ms", C.c_float), ("decode_ms", C.c_float),
+                ("total_ms", C.c_float), ("gemm_ms", C.c_float), ("gemm_launches", C.c_int32),
+                ("gemm_flops", C.c_double), ("vit_gemm_ms", C.c_float), ("vit_gemm_launches", C.c_int32),
+                ("vit_gemm_flops", C.c_double), ("decode_step_ms", C.c_float), ("decode_steps", C.c_int32),
+                ("decode_step_bytes", C.c_double)]
+
+    def as_dict(self) -> Dict[str, float]:
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class GitmiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libgitmi.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GitmiError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C generativeimage2text_amd/csrc`.  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64p, fp = C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p
+    lib.gitmi_abi_version.restype = C.c_int
+    lib.gitmi_last_error.restype = C.c_char_p
+    lib.gitmi_create.argtypes = [C.POINTER(GitmiConfig), i32, C.POINTER(vp)]
+    lib.gitmi_destroy.argtypes = [vp]
+    lib.gitmi_destroy.restype = None
+    lib.gitmi_load_tensor.argtypes = [vp, C.c_char_p, vp, i64p, i32, i32]
+    lib.gitmi_finalize_weights.argtypes = [vp]
+    lib.gitmi_encode_frames.argtypes = [vp, C.POINTER(vp), i32, i32, vp, vp]
+    lib.gitmi_prefill.argtypes = [vp, vp]
+    lib.gitmi_step_logits.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.gitmi_generate.argtypes = [vp, C.POINTER(vp), i32, i32, vp, i32, C.POINTER(GitmiSearch), vp, vp, vp, vp]
+    lib.gitmi_search_begin.argtypes = [vp, C.POINTER(GitmiSearch), i32, vp, i32, i32, vp]
+    lib.gitmi_search_rows.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
+    lib.gitmi_search_advance.argtypes = [vp, vp, vp]
+    lib.gitmi_search_finish.argtypes = [vp, vp, vp, vp, vp]
+    lib.gitmi_profile_enable.argtypes = [vp, i32]
+    lib.gitmi_profile_read.argtypes = [vp, C.POINTER(GitmiProfile)]
+    lib.gitmi_set_graph.argtypes = [vp, i32]
+    lib.gitmi_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.gitmi_op_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp]
+    lib.gitmi_op_attention.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    for name in EXPORTED_SYMBOLS:
+        if name not in ("gitmi_last_error", "gitmi_destroy"):
+            getattr(lib, name).restype = C.c_int
+    if lib.gitmi_abi_version() != 1:
+        raise GitmiError("libgitmi.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _ck(rc: int) -> None:
+    if rc != 0:
+        raise GitmiError(load_library().gitmi_last_error().decode("utf-8", "replace"))
+
+
+def _stream() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else int(t.data_ptr())
+
+
+def _torch_dtype_code(t: torch.Tensor) -> int:
+    return {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16, torch.float16: DTYPE_F16}[t.dtype]
+
+
+class Engine:
+    """One GIT engine on one GPU.  Mirrors what `get_git_model(...).cuda()` holds in the reference."""
+
+    def __init__(self, model_cfg, precision: str = "bf16", max_batch: int = 64, max_beams: int = 4,
+                 max_frames: int = 1, max_text_len: int = 40, device: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise GitmiError("no GPU visible: the GIT engine runs on MI355X (gfx950) only, there is no CPU fallback")
+        self.lib = load_library()
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.cfg = model_cfg
+        self.precision = precision
+        c = GitmiConfig()
+        for name in ("image_size", "patch", "vit_width", "vit_layers", "vit_heads", "dec_hidden", "dec_layers",
+                     "dec_heads", "dec_ffn", "vocab", "max_pos", "num_frames", "sos", "eos"):
+            setattr(c, name, int(getattr(model_cfg, name)))
+        c.precision = {"bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32}[precision]
+        c.max_batch, c.max_beams = int(max_batch), int(max_beams)
+        c.max_frames, c.max_text_len = int(max_frames), int(max_text_len)
+        self.c = c
+        self.n_tok = (c.image_size // c.patch) ** 2 + 1
+        self._h = C.c_void_p()
+        _ck(self.lib.gitmi_create(C.byref(c), self.device, C.byref(self._h)))
+        self._finalized = False
+        self._cur_B = 0
+        self._cur_F = 0
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.gitmi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights -------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict: Mapping[str, torch.Tensor]) -> None:
+        """Reference keys; tensors may be fp32/bf16/fp16, any device."""
+        for key, t in state_dict.items():
+            if key == "image_encoder.proj" or key.endswith("attn_mask"):
+                continue
+            t = t.detach().to("cpu").contiguous()
+            if t.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+                t = t.float()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            _ck(self.lib.gitmi_load_tensor(self._h, key.encode(), t.data_ptr(), shape, t.dim(), _torch_dtype_code(t)))
+        _ck(self.lib.gitmi_finalize_weights(self._h))
+        self._finalized = True
+
+    # -- phases --------------------------------------------------------------------------------
+    def _frames_arg(self, frames: Sequence[torch.Tensor]) -> Tuple[C.Array, List[torch.Tensor], int]:
+        keep = [f.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous() for f in frames]
+        B = keep[0].shape[0]
+        for f in keep:
+            assert f.shape == (B, 3, self.c.image_size, self.c.image_size), f"frame shape {tuple(f.shape)}"
+        arr = (C.c_void_p * len(keep))(*[f.data_ptr() for f in keep])
+        return arr, keep, B
+
+    def encode(self, frames: Sequence[torch.Tensor], return_features: bool = True) -> Optional[torch.Tensor]:
+        arr, keep, B = self._frames_arg(frames)
+        F = len(keep)
+        F_eff = min(F, self.c.num_frames) if self.c.num_frames > 0 else F
+        out = None
+        if return_features:
+            out = torch.empty(B, F_eff * self.n_tok, self.c.vit_width, device=keep[0].device, dtype=torch.float32)
+        _ck(self.lib.gitmi_encode_frames(self._h, arr, F, B, _ptr(out), _stream()))
+        self._cur_B, self._cur_F = B, F_eff
+        return out
+
+    def prefill(self) -> None:
+        _ck(self.lib.gitmi_prefill(self._h, _stream()))
+
+    def step_logits(self, tokens: torch.Tensor) -> torch.Tensor:
+        tokens = tokens.to(device=f"cuda:{self.device}", dtype=torch.int64).contiguous()
+        R, t = tokens.shape
+        out = torch.empty(R, self.c.vocab, device=tokens.device, dtype=torch.float32)
+        _ck(self.lib.gitmi_step_logits(self._h, tokens.data_ptr(), R, t, out.data_ptr(), _stream()))
+        return out
+
+    @staticmethod
+    def make_search(kind: str, max_steps: int, beam_size: int, per_node_beam_size: int,
+                    length_penalty: float = 1.0) -> GitmiSearch:
+        s = GitmiSearch()
+        s.kind = SEARCH_AUTOREGRESSIVE if kind in ("greedy", "autoregressive") else SEARCH_GENERATOR
+        s.beam_size, s.per_node_beam_size, s.max_steps = int(beam_size), int(per_node_beam_size), int(max_steps)
+        s.length_penalty = float(length_penalty)
+        return s
+
+    def generate(self, frames: Sequence[torch.Tensor], search: GitmiSearch,
+                 prefix: Optional[torch.Tensor] = None, sync: bool = True):
+        """-> (tokens int64 [B, max_steps] incl. start tokens / EOS padded, logprobs fp32 [B], info int32 [4])"""
+        arr, keep, B = self._frames_arg(frames)
+        dev = keep[0].device
+        tokens = torch.empty(B, search.max_steps, device=dev, dtype=torch.int64)
+        logprobs = torch.empty(B, device=dev, dtype=torch.float32)
+        info = torch.empty(4, device=dev, dtype=torch.int32)
+        P, pfx = 1, None
+        if prefix is not None:
+            pfx = prefix.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
+            P = int(pfx.numel())
+        _ck(self.lib.gitmi_generate(self._h, arr, len(keep), B, _ptr(pfx), P, C.byref(search), tokens.data_ptr(),
+                                    logprobs.data_ptr(), info.data_ptr(), _stream()))
+        self._cur_B = B
+        if sync:
+            torch.cuda.current_stream().synchronize()
+        return tokens, logprobs, info
+
+    # -- search seam ---------------------------------------------------------------------------
+    def search_begin(self, search: GitmiSearch, start: torch.Tensor, vocab: int) -> None:
+        start = start.to("cpu", torch.int64).contiguous()
+        B, P = start.shape
+        _ck(self.lib.gitmi_search_begin(self._h, C.byref(search), B, start.data_ptr(), P, vocab, _stream()))
+        self._search_k = search.beam_size
+        self._search_B = B
+        self._search_T = search.max_steps
+
+    def search_rows(self) -> torch.Tensor:
+        R, t = C.c_int(), C.c_int()
+        _ck(self.lib.gitmi_search_rows(self._h, None, C.byref(R), C.byref(t), _stream()))
+        out = torch.empty(R.value, t.value, device=f"cuda:{self.device}", dtype=torch.int64)
+        _ck(self.lib.gitmi_search_rows(self._h, out.data_ptr(), C.byref(R), C.byref(t), _stream()))
+        return out
+
+    def search_advance(self, logits: torch.Tensor) -> None:
+        logits = logits.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
+        self._keep_logits = logits
+        _ck(self.lib.gitmi_search_advance(self._h, logits.data_ptr(), _stream()))
+
+    def search_finish(self):
+        dev = f"cuda:{self.device}"
+        tokens = torch.empty(self._search_B, self._search_T, device=dev, dtype=torch.int64)
+        logprobs = torch.empty(self._search_B, device=dev, dtype=torch.float32)
+        info = torch.empty(4, device=dev, dtype=torch.int32)
+        _ck(self.lib.gitmi_search_finish(self._h, tokens.data_ptr(), logprobs.data_ptr(), info.data_ptr(), _stream()))
+        torch.cuda.current_stream().synchronize()
+        return tokens, logprobs, info
+
+    # -- profiling -----------------------------------------------------------------------------
+    def profile_enable(self, on: bool) -> None:
+        _ck(self.lib.gitmi_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self) -> Dict[str, float]:
+        p = GitmiProfile()
+        _ck(self.lib.gitmi_profile_read(self._h, C.byref(p)))
+        return p.as_dict()
+
+    def set_graph(self, on: bool) -> None:
+        _ck(self.lib.gitmi_set_graph(self._h, 1 if on else 0))
+
+
+# ---- single-kernel entry points (unit parity tests) -----------------------------------------------
+def op_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
+            residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+            out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    lib = load_library()
+    assert A.is_cuda and W.is_cuda and A.dtype == W.dtype and A.is_contiguous() and W.is_contiguous()
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty(M, N, device=A.device, dtype=out_dtype)
+    _ck(lib.gitmi_op_gemm(A.data_ptr(), W.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, K, N,
+                          _torch_dtype_code(A), _torch_dtype_code(out), act, _stream()))
+    return out
+
+
+def op_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                 out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    lib = load_library()
+    rows, D = x.shape
+    out = torch.empty(rows, D, device=x.device, dtype=out_dtype)
+    _ck(lib.gitmi_op_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, out.data_ptr(), None, rows, D,
+                               _torch_dtype_code(out), _stream()))
+    return out
+
+
+def op_attention(qkv: torch.Tensor, B: int, N: int, H: int, impl: int) -> torch.Tensor:
+    lib = load_library()
+    assert qkv.is_cuda and qkv.is_contiguous() and qkv.shape == (B * N, 3 * H * 64)
+    out = torch.empty(B * N, H * 64, device=qkv.device, dtype=qkv.dtype)
+    _ck(lib.gitmi_op_attention(qkv.data_ptr(), out.data_ptr(), B, N, H, _torch_dtype_code(qkv), impl, _stream()))
+    return out

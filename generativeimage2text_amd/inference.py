@@ -1,0 +1,231 @@
+"""The two inference tasks of the reference, same names and positional signatures
+(generativeimage2text/inference.py:67-109 and :134-225), running on the HIP engine.
+
+Differences forced by the environment, not by design:
+  * torchvision / azfuse are not imported: the image transform is restated on PIL (torchvision's
+    Resize/CenterCrop on PIL images call PIL themselves), checkpoints are read with torch.load.
+  * the WordPiece vocabulary is looked up offline (HF cache, $GIT_VOCAB or aux_data/vocab.txt);
+    without one the tasks still run and report token ids instead of text.
+  * images are batched (the reference runs batch 1, one host sync per image) and ranks return
+    their results through one RCCL gather instead of the shared-filesystem poll of
+    inference.py:214-225; shard files `{out}.{rank}.{world}.tsv` are still written.
+"""
+from __future__ import annotations
+
+import base64
+import io
+import json
+import logging
+import os
+import os.path as op
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .configs import MODEL_PARAMS, config_for_model
+from .model import GeneratorWithBeamSearch, CaptioningModel
+from .tsv_io import TSVFile, tsv_writer, concat_tsv_files
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)      # inference.py:126-129
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+# ---- rank helpers (common.py:106-119) ---------------------------------------------------------
+def get_mpi_rank() -> int:
+    return int(os.environ.get("RANK", os.environ.get("OMPI_COMM_WORLD_RANK", "0")))
+
+
+def get_mpi_local_rank() -> int:
+    return int(os.environ.get("LOCAL_RANK", os.environ.get("OMPI_COMM_WORLD_LOCAL_RANK", "0")))
+
+
+def get_mpi_size() -> int:
+    return int(os.environ.get("WORLD_SIZE", os.environ.get("OMPI_COMM_WORLD_SIZE", "1")))
+
+
+def shard_range(num_rows: int, rank: int, world: int):
+    """Contiguous rows of this rank, inference.py:165-169."""
+    per = (num_rows + world - 1) // world
+    start = per * rank
+    return start, min(start + per, num_rows)
+
+
+# ---- tokenizer --------------------------------------------------------------------------------
+class IdTokenizer:
+    """Stand-in when no WordPiece vocabulary is available offline: ids in, ids out."""
+    cls_token_id, sep_token_id = 101, 102
+
+    def __call__(self, text, **kw):
+        ids = [int(x) for x in text.split()] if text.strip() else []
+        return {"input_ids": ids}
+
+    def decode(self, ids, skip_special_tokens=True):
+        if skip_special_tokens:
+            ids = [i for i in ids if i not in (0, 100, 101, 102, 103)]
+        return " ".join(str(i) for i in ids)
+
+
+def get_tokenizer():
+    """BertTokenizer.from_pretrained('bert-base-uncased', do_lower_case=True) (inference.py:72), offline."""
+    vocab = os.environ.get("GIT_VOCAB", "aux_data/vocab.txt")
+    try:
+        from transformers import BertTokenizer
+        if op.isfile(vocab):
+            return BertTokenizer(vocab, do_lower_case=True)
+        os.environ.setdefault("HF_HUB_OFFLINE", "1")
+        return BertTokenizer.from_pretrained("bert-base-uncased", do_lower_case=True)
+    except Exception as exc:   # no vocabulary on this machine
+        logging.warning("no bert-base-uncased vocabulary available (%s); reporting token ids", type(exc).__name__)
+        return IdTokenizer()
+
+
+# ---- image transform (inference.py:111-132) ------------------------------------------------------
+def load_image_by_pil(path_or_bytes):
+    from PIL import Image
+    if isinstance(path_or_bytes, (bytes, bytearray)):
+        return Image.open(io.BytesIO(path_or_bytes)).convert("RGB")
+    return Image.open(path_or_bytes).convert("RGB")
+
+
+def image_transform(img, crop_size: int = 224) -> torch.Tensor:
+    """Resize(crop, BICUBIC) -> CenterCrop(crop) -> RGB -> ToTensor -> Normalize(CLIP mean/std)."""
+    from PIL import Image
+    w, h = img.size
+    if w <= h:
+        nw, nh = crop_size, int(crop_size * h / w)
+    else:
+        nw, nh = int(crop_size * w / h), crop_size
+    if (w, h) != (nw, nh):
+        img = img.resize((nw, nh), Image.BICUBIC)
+    left, top = int(round((nw - crop_size) / 2.0)), int(round((nh - crop_size) / 2.0))
+    img = img.crop((left, top, left + crop_size, top + crop_size)).convert("RGB")
+    x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+    mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
+    std = torch.tensor(CLIP_STD).view(3, 1, 1)
+    return (x - mean) / std
+
+
+def get_image_transform(param: dict):
+    if "test_respect_ratio_max" in param:
+        raise NotImplementedError(
+            "aspect-preserving resize (MinMaxResizeForTest, inference.py:29-64) needs the variable-resolution "
+            "ViT path, which is a 'next' row (SURVEY.md 8f-3)")
+    crop = param.get("test_crop_size", 224)
+    return lambda im: image_transform(im, crop)
+
+
+# ---- model construction -----------------------------------------------------------------------
+def load_checkpoint(model_name: str, checkpoint: Optional[str] = None):
+    path = checkpoint or f"output/{model_name}/snapshot/model.pt"       # inference.py:84
+    if not op.isfile(path):
+        raise FileNotFoundError(
+            f"checkpoint {path} not found (the reference downloads it through azfuse; this build is offline). "
+            f"Place the file there or pass checkpoint=...")
+    ckpt = torch.load(path, map_location="cpu")
+    return ckpt["model"] if "model" in ckpt else ckpt
+
+
+def build_model(model_name: str, tokenizer, checkpoint=None, max_batch: int = 64, precision: str = "bf16",
+                decoder=None) -> CaptioningModel:
+    cfg = config_for_model(model_name)
+    if decoder is None:
+        decoder = GeneratorWithBeamSearch(eos_index=tokenizer.sep_token_id, max_steps=1024, beam_size=4,
+                                          length_penalty=0.6)               # model.py:34-40
+    model = CaptioningModel(cfg, decoder, precision=precision, max_batch=max_batch)
+    state = checkpoint if isinstance(checkpoint, dict) else load_checkpoint(model_name, checkpoint)
+    model.load_state_dict(state)
+    return model
+
+
+def _prefix_ids(tokenizer, prefix: str, max_text_len: int = 40) -> List[int]:
+    """inference.py:92-101."""
+    enc = tokenizer(prefix, padding="do_not_pad", truncation=True, add_special_tokens=False, max_length=max_text_len)
+    payload = enc["input_ids"]
+    if len(payload) > max_text_len - 2:
+        payload = payload[-(max_text_len - 2):]
+    return [tokenizer.cls_token_id] + payload
+
+
+# ---- tasks --------------------------------------------------------------------------------------
+def test_git_inference_single_image(image_path, model_name, prefix, *, checkpoint=None, precision="bf16"):
+    """inference.py:67-109.  image_path: str or list of str (video frames); logs 'output: <caption>'."""
+    param = MODEL_PARAMS.get(model_name, {})
+    tokenizer = get_tokenizer()
+    if isinstance(image_path, str):
+        image_path = [image_path]
+    transforms = get_image_transform(param)
+    img = [transforms(load_image_by_pil(p)) for p in image_path]
+    model = build_model(model_name, tokenizer, checkpoint, max_batch=1, precision=precision)
+    model.cuda()
+    model.eval()
+    img = [i.unsqueeze(0).cuda() for i in img]
+    input_ids = _prefix_ids(tokenizer, prefix)
+    with torch.no_grad():
+        result = model({"image": img, "prefix": torch.tensor(input_ids).unsqueeze(0).cuda()})
+    cap = tokenizer.decode(result["predictions"][0].tolist(), skip_special_tokens=True)
+    logging.info("output: {}".format(cap))
+    test_git_inference_single_image.last_output = cap
+
+
+def _gather_rows(rows: List[list]) -> Optional[List[list]]:
+    """Result gather over RCCL (replaces the file poll of inference.py:214-225). Rank 0 gets all rows."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rows
+    out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+    dist.gather_object(rows, out, dst=0)
+    if dist.get_rank() != 0:
+        return None
+    return [r for part in out for r in part]
+
+
+def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, *, checkpoint=None,
+                                  batch_size=64, precision="bf16"):
+    """inference.py:134-225.  image_tsv rows: key \\t base64(jpeg).  question_tsv (optional) rows:
+    key \\t json list of {'question', 'question_id'}.  Writes out_tsv rows
+    key \\t [{"caption": ...}]   or   key \\t {"answer": ..., "question_id": ...}."""
+    param = MODEL_PARAMS.get(model_name, {})
+    tokenizer = get_tokenizer()
+    torch.cuda.set_device(get_mpi_local_rank())                             # inference.py:152
+    is_vqa = question_tsv is not None
+    model = build_model(model_name, tokenizer, checkpoint, max_batch=1 if is_vqa else batch_size, precision=precision)
+    transforms = get_image_transform(param)
+    rank, world = get_mpi_rank(), get_mpi_size()
+    tsv = TSVFile(image_tsv)
+    start, end = shard_range(len(tsv), rank, world)
+    shard_file = out_tsv if world == 1 else f"{out_tsv}.{rank}.{world}.tsv"    # inference.py:159-164
+    questions = TSVFile(question_tsv) if is_vqa else None
+    rows: List[list] = []
+
+    def run_batch(keys: Sequence[str], imgs: Sequence[torch.Tensor]):
+        with torch.no_grad():
+            res = model({"image": torch.stack(list(imgs)).cuda()})
+        for key, pred in zip(keys, res["predictions"].tolist()):
+            rows.append([key, json.dumps([{"caption": tokenizer.decode(pred, skip_special_tokens=True)}])])
+
+    keys, imgs = [], []
+    for i in range(start, end):
+        key, b64 = tsv[i][0], tsv[i][1]
+        img = transforms(load_image_by_pil(base64.b64decode(b64)))
+        if not is_vqa:
+            keys.append(key)
+            imgs.append(img)
+            if len(keys) == batch_size:
+                run_batch(keys, imgs)
+                keys, imgs = [], []
+            continue
+        qkey, qjson = questions[i][0], questions[i][1]
+        assert qkey == key
+        for q in json.loads(qjson):                                          # inference.py:172-199
+            ids = _prefix_ids(tokenizer, q["question"])
+            with torch.no_grad():
+                res = model({"image": img.unsqueeze(0).cuda(), "prefix": torch.tensor(ids).unsqueeze(0).cuda()})
+            ans = tokenizer.decode(res["predictions"][0].tolist(), skip_special_tokens=True)
+            rows.append([key, json.dumps({"answer": ans, "question_id": q["question_id"]})])
+    if keys:
+        run_batch(keys, imgs)
+    tsv_writer(rows, shard_file)
+    all_rows = _gather_rows(rows)
+    if world > 1 and rank == 0:
+        tsv_writer(all_rows, out_tsv)

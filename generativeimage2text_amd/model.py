@@ -1,0 +1,186 @@
+"""Host-side mirror of the reference's model interface for the hot path.
+
+Same names, argument meaning and return conventions as
+  generativeimage2text/model.py:9-61              get_git_model
+  generativeimage2text/layers/decoder.py:774-1054 CaptioningModel (forward / infer)
+  generativeimage2text/layers/decoder.py:208-222  AutoRegressiveBeamSearch  (constructor arguments)
+  generativeimage2text/layers/decoder.py:1056-1081 GeneratorWithBeamSearch (constructor arguments)
+but all arithmetic happens in libgitmi.so (HIP, gfx950).  The two search classes are plain
+configuration holders here: the search itself runs on the device (csrc/kernels_search.hip).
+"""
+from __future__ import annotations
+
+import logging
+from typing import Dict, Mapping, Optional, Sequence, Union
+
+import torch
+
+from .configs import GitModelConfig, config_from_param
+from .engine import Engine
+
+
+class AutoRegressiveBeamSearch:
+    """Constructor-compatible with the reference class (decoder.py:209-222)."""
+
+    def __init__(self, eos_index: int, max_steps: int = 50, beam_size: int = 5,
+                 per_node_beam_size: int = 2, fix_missing_prefix: bool = False) -> None:
+        assert fix_missing_prefix, "should always true"          # decoder.py:222
+        self._eos_index = eos_index
+        self.max_steps = max_steps
+        self.beam_size = beam_size
+        self.per_node_beam_size = per_node_beam_size or beam_size
+        self.kind = "autoregressive"
+        self.length_penalty = 1.0
+
+
+class GeneratorWithBeamSearch:
+    """Constructor-compatible with the reference class (decoder.py:1057-1081)."""
+
+    def __init__(self, eos_index: int, max_steps: int, beam_size: int, per_node_beam_size: int = 2,
+                 length_penalty: float = 1, repetition_penalty: float = 1, temperature: float = 1) -> None:
+        self._eos_index = eos_index
+        self.max_steps = max_steps
+        self.beam_size = beam_size
+        self.per_node_beam_size = per_node_beam_size or beam_size
+        self.length_penalty = length_penalty
+        assert self.per_node_beam_size > 1
+        assert self.length_penalty > 0, "`length_penalty` should be strictely positive."
+        if repetition_penalty != 1 or temperature != 1:
+            raise NotImplementedError("repetition_penalty / temperature (sampling branches) are out of scope")
+        self.kind = "generator"
+
+
+def load_state_dict_by_suffix(model_keys: Sequence[str], loaded: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Key alignment of torch_common.py:93-145: strip 'module.' prefixes, then give every model key the
+    loaded key that is its LONGEST suffix."""
+    stripped = {}
+    for k, v in loaded.items():
+        stripped[k[len("module."):] if k.startswith("module.") else k] = v
+    out: Dict[str, torch.Tensor] = {}
+    for key in model_keys:
+        best = None
+        for cand in stripped:
+            if key.endswith(cand) and (best is None or len(cand) > len(best)):
+                best = cand
+        if best is not None:
+            out[key] = stripped[best]
+    return out
+
+
+def expected_state_dict_keys(cfg: GitModelConfig, tied_output: bool = False) -> Sequence[str]:
+    """Keys the engine ingests."""
+    keys = ["image_encoder.class_embedding", "image_encoder.positional_embedding", "image_encoder.conv1.weight",
+            "image_encoder.ln_pre.weight", "image_encoder.ln_pre.bias", "image_encoder.ln_post.weight",
+            "image_encoder.ln_post.bias"]
+    for i in range(cfg.vit_layers):
+        p = f"image_encoder.transformer.resblocks.{i}."
+        keys += [p + s for s in ("attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
+                                 "attn.out_proj.bias", "ln_1.weight", "ln_1.bias", "mlp.c_fc.weight",
+                                 "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias", "ln_2.weight", "ln_2.bias")]
+    keys += ["textual.visual_projection.0.weight", "textual.visual_projection.0.bias",
+             "textual.visual_projection.1.weight", "textual.visual_projection.1.bias",
+             "textual.embedding.words.weight", "textual.embedding.positions.weight",
+             "textual.embedding.layer_norm.weight", "textual.embedding.layer_norm.bias"]
+    for i in range(cfg.dec_layers):
+        p = f"textual.transformer.encoder.layer.{i}."
+        for nm in ("query", "key", "value"):
+            keys += [p + f"attention.self.{nm}.weight", p + f"attention.self.{nm}.bias"]
+        keys += [p + s for s in ("attention.output.dense.weight", "attention.output.dense.bias",
+                                 "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias",
+                                 "intermediate.dense.weight", "intermediate.dense.bias", "output.dense.weight",
+                                 "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias")]
+    if not tied_output:
+        keys.append("textual.output.weight")
+    keys.append("textual.output.bias")
+    keys += [f"img_temperal_embedding.{i}" for i in range(cfg.num_frames)]
+    return keys
+
+
+class CaptioningModel:
+    """Callable like the reference model: ``model(batch) -> {'predictions', 'logprobs'}``.
+
+    batch['image']  : FloatTensor [B,3,H,W] or a list of such (video frames)   (decoder.py:845-857)
+    batch['prefix'] : LongTensor [1,P] starting with [CLS] (VQA question)       (decoder.py:984-989)
+    """
+
+    def __init__(self, cfg: GitModelConfig, decoder, precision: str = "bf16", max_batch: int = 64,
+                 max_frames: Optional[int] = None, max_text_len: Optional[int] = None,
+                 device: Optional[int] = None):
+        self.cfg = cfg
+        self.decoder = decoder
+        self.sos_index = cfg.sos
+        self.eos_index = cfg.eos
+        if max_frames is None:
+            max_frames = max(1, cfg.num_frames)
+        if max_text_len is None:
+            max_text_len = min(cfg.max_pos, max(int(decoder.max_steps), 2))
+        self.engine = Engine(cfg, precision=precision, max_batch=max_batch,
+                             max_beams=max(1, int(decoder.beam_size)), max_frames=max_frames,
+                             max_text_len=max_text_len, device=device)
+        self._loaded = False
+
+    # nn.Module look-alikes so that reference call sites (`model.cuda(); model.eval()`) keep working
+    def cuda(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def load_state_dict(self, state_dict: Mapping[str, torch.Tensor], strict: bool = False):
+        tied = "textual.output.weight" not in state_dict
+        keys = expected_state_dict_keys(self.cfg, tied_output=tied)
+        aligned = load_state_dict_by_suffix(keys, state_dict)
+        missing = [k for k in keys if k not in aligned]
+        if missing:
+            raise KeyError(f"checkpoint is missing {len(missing)} tensors, e.g. {missing[:4]}")
+        self.engine.load_state_dict(aligned)
+        self._loaded = True
+        return self
+
+    def _search_struct(self):
+        d = self.decoder
+        return Engine.make_search(d.kind, d.max_steps, d.beam_size, d.per_node_beam_size, d.length_penalty)
+
+    def forward(self, batch: Mapping[str, Union[torch.Tensor, Sequence[torch.Tensor]]]) -> Dict[str, torch.Tensor]:
+        if not self._loaded:
+            raise RuntimeError("weights not loaded (call load_state_dict first)")
+        image = batch["image"]
+        frames = list(image) if isinstance(image, (list, tuple)) else [image]
+        prefix = batch.get("prefix")
+        if prefix is not None:
+            assert len(prefix) == 1, "not supported"                       # decoder.py:988
+        search = self._search_struct()
+        tokens, logprobs, info = self.engine.generate(frames, search, prefix=prefix)
+        seq_len, early, _, _ = info.tolist()
+        P = 1 if prefix is None else int(prefix.numel())
+        if self.decoder.kind == "autoregressive":
+            if early:                                                       # decoder.py:279-291
+                predictions = tokens[:, P:P + 1]
+                logprobs = logprobs[:, None]
+            else:
+                predictions = tokens[:, :seq_len]
+        else:
+            predictions = tokens
+            logprobs = logprobs[:, None]                                    # [B, num_keep_best=1]
+        if prefix is not None:
+            predictions = predictions[:, P:]                                # decoder.py:1004-1006
+        return {"predictions": predictions, "logprobs": logprobs}
+
+    __call__ = forward
+
+
+def get_git_model(tokenizer, param: Optional[dict], precision: str = "bf16", max_batch: int = 64,
+                  decoder=None, device: Optional[int] = None) -> CaptioningModel:
+    """Same role as the reference's get_git_model (model.py:9-61): GIT decoder hyper-parameters are
+    fixed, the encoder follows param['image_encoder_type'].  The default search is the shipped one:
+    GeneratorWithBeamSearch(beam_size=4, length_penalty=0.6, max_steps=1024) (model.py:34-40)."""
+    cfg = config_from_param(param)
+    sos = getattr(tokenizer, "cls_token_id", None)
+    eos = getattr(tokenizer, "sep_token_id", None)
+    if sos is not None and eos is not None and (sos != cfg.sos or eos != cfg.eos):
+        import dataclasses
+        cfg = dataclasses.replace(cfg, sos=int(sos), eos=int(eos))
+    if decoder is None:
+        decoder = GeneratorWithBeamSearch(eos_index=cfg.eos, max_steps=1024, beam_size=4, length_penalty=0.6)
+    logging.info("building GIT engine: %s, search %s", cfg, type(decoder).__name__)
+    return CaptioningModel(cfg, decoder, precision=precision, max_batch=max_batch, device=device)

@@ -1,0 +1,183 @@
+/*
+ * gitmi.h -- C ABI of the MI355X-native GIT captioning / VQA inference engine.
+ *
+ * The reference (microsoft/GenerativeImage2Text) has no FFI / operator layer: its
+ * extension seams are Python duck-typed.  This header is the drop-in
+ * boundary a maintainer binds instead of those seams; every entry point names the
+ * reference interface it replaces (paths relative to
+ * /root/reference/generativeimage2text/).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain C, no torch types.  All tensor pointers are DEVICE pointers unless the
+ *     parameter name ends in _host.  Caller owns inputs/outputs; the engine owns
+ *     repacked weights, KV caches and workspaces sized at gitmi_create().
+ *   - every call returns 0 on success, non-zero on error; gitmi_last_error() returns
+ *     a thread-local message.  Nothing throws across the ABI.
+ *   - one engine per device per process; calls on one engine are serialised by the
+ *     caller and are asynchronous w.r.t. the host on the hipStream_t passed as
+ *     `stream` (a void* so that this header needs no HIP include).
+ *   - no CPU fallback exists: without a gfx950 device gitmi_create() fails.
+ */
+#ifndef GITMI_H_
+#define GITMI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GITMI_ABI_VERSION 1
+
+/* compute precision of GEMM/attention operands (accumulation, LayerNorm statistics,
+ * softmax, residual stream and logits are fp32 in both modes) */
+#define GITMI_PREC_BF16 0   /* bf16 MFMA -- the production / benchmarked path        */
+#define GITMI_PREC_F32  1   /* f32-input MFMA, exact fp32 -- parity-debug path        */
+
+/* tensor dtypes accepted by gitmi_load_tensor */
+#define GITMI_DTYPE_F32  0
+#define GITMI_DTYPE_BF16 1
+#define GITMI_DTYPE_F16  2
+
+/* search strategies (layers/decoder.py) */
+#define GITMI_SEARCH_AUTOREGRESSIVE 0  /* AutoRegressiveBeamSearch   decoder.py:208-440  */
+#define GITMI_SEARCH_GENERATOR      1  /* GeneratorWithBeamSearch    decoder.py:1056-1290 */
+
+typedef struct gitmi_engine gitmi_engine;
+
+/* Model + capacity description.  Replaces the hyper-parameters hard-coded in
+ * model.py:9-61 (decoder) / CLIP build_model (encoder) / aux_data/models/<m>/parameter.yaml. */
+typedef struct gitmi_config {
+    int32_t image_size;     /* test_crop_size, 224                                    */
+    int32_t patch;          /* 16 (ViT-B/16) | 14 (ViT-L/14)                          */
+    int32_t vit_width;      /* 768 | 1024  (== visual_feature_size)                   */
+    int32_t vit_layers;     /* 12 | 24                                                */
+    int32_t vit_heads;      /* 12 | 16   (head_dim must be 64)                        */
+    int32_t dec_hidden;     /* 768                                                    */
+    int32_t dec_layers;     /* 6                                                      */
+    int32_t dec_heads;      /* 12  (head_dim must be 64)                              */
+    int32_t dec_ffn;        /* 3072                                                   */
+    int32_t vocab;          /* 30522                                                  */
+    int32_t max_pos;        /* 1024 (max_caption_length, model.py:21)                 */
+    int32_t num_frames;     /* num_image_with_embedding: temporal embeddings, 0=none  */
+    int32_t sos;            /* tokenizer.cls_token_id = 101                           */
+    int32_t eos;            /* tokenizer.sep_token_id = 102                           */
+    int32_t precision;      /* GITMI_PREC_*                                           */
+    int32_t max_batch;      /* capacity: images per call                              */
+    int32_t max_beams;      /* capacity: beam_size                                    */
+    int32_t max_frames;     /* capacity: frames per sample (>=1)                      */
+    int32_t max_text_len;   /* capacity: prefix + generated tokens (KV-cache length)  */
+} gitmi_config;
+
+/* Replaces the constructor arguments of the two search classes
+ * (decoder.py:209-222, 1057-1081). */
+typedef struct gitmi_search {
+    int32_t kind;                 /* GITMI_SEARCH_*                                   */
+    int32_t beam_size;
+    int32_t per_node_beam_size;
+    int32_t max_steps;            /* TOTAL length incl. [CLS]/prefix (decoder.py:313, 1111) */
+    double  length_penalty;       /* GENERATOR only (double: the reference does this math in Python floats) */
+} gitmi_search;
+
+/* per-phase device timings (ms) of the last profiled gitmi_generate(), see gitmi_profile_enable */
+typedef struct gitmi_profile {
+    float    vit_ms, prefill_ms, decode_ms, total_ms;
+    float    gemm_ms;             /* sum over every GEMM launch of the call            */
+    int32_t  gemm_launches;
+    double   gemm_flops;          /* algorithmic 2*M*N*K summed over those launches    */
+    float    vit_gemm_ms;         /* GEMM launches of the image encoder only           */
+    int32_t  vit_gemm_launches;
+    double   vit_gemm_flops;
+    float    decode_step_ms;      /* average over executed decode steps                */
+    int32_t  decode_steps;
+    double   decode_step_bytes;   /* algorithmic bytes per step: weights + KV read     */
+} gitmi_profile;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+int  gitmi_abi_version(void);
+const char* gitmi_last_error(void);
+/* replaces get_git_model(tokenizer, param) + model.cuda()  (model.py:9-61, inference.py:83-87) */
+int  gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** out);
+void gitmi_destroy(gitmi_engine* e);
+
+/* ---- checkpoint ingest:  replaces load_state_dict(model, ckpt) (torch_common.py:93-145).
+ * `key` is the reference state-dict key, e.g.
+ * "image_encoder.transformer.resblocks.3.attn.in_proj_weight".  `data_host` is a HOST
+ * pointer to a dense row-major tensor. Unknown keys return an error; "image_encoder.proj"
+ * is accepted and ignored (unused when output_grid=True, CLIP/model.py:263-268). */
+int  gitmi_load_tensor(gitmi_engine* e, const char* key, const void* data_host,
+                       const int64_t* shape, int ndim, int dtype);
+/* repack for the device: fused QKV, K padding, compute-dtype copies; ties
+ * textual.output.weight to embedding.words.weight if it was not loaded (decoder.py:503-505) */
+int  gitmi_finalize_weights(gitmi_engine* e);
+
+/* ---- image encoder: replaces model.image_encoder(x) + the multi-frame branch of
+ * CaptioningModel.forward_one (CLIP/model.py:240-274, decoder.py:845-857).
+ * frames: F device pointers to fp32 [B,3,H,W] (H=W=image_size).  The visual features
+ * [B, F*N, vit_width] stay resident in the engine; feats_out (optional, fp32) receives a copy. */
+int  gitmi_encode_frames(gitmi_engine* e, const float* const* frames, int F, int B,
+                         float* feats_out, void* stream);
+
+/* ---- decoder prefill over image tokens (visual_projection + image rows of all layers);
+ * builds the per-image K/V cache.  Mathematically the image part of
+ * TransformerDecoderTextualHead.forward (decoder.py:521-600), computed once per image. */
+int  gitmi_prefill(gitmi_engine* e, void* stream);
+
+/* ---- teacher-forced step == the reference's `step` callable
+ * (CaptioningModel.decoding_step, decoder.py:1013-1054): tokens int64 [R,t], R = B*beams with
+ * rows of one image contiguous; writes fp32 next-token logits [R, vocab]. */
+int  gitmi_step_logits(gitmi_engine* e, const int64_t* tokens, int R, int t,
+                       float* logits_out, void* stream);
+
+/* ---- whole hot path: replaces model({'image':..., 'prefix':...})
+ * (CaptioningModel.forward/infer, decoder.py:838-877, 977-1011) incl. the search loop.
+ *   prefix       : int64 [P] starting with [CLS], or NULL for captioning (P ignored);
+ *                  the reference requires B==1 with a prefix (decoder.py:988) -- here a
+ *                  single prefix is shared by all B images.
+ *   tokens_out   : int64 [B, max_steps]; sequences INCLUDE the start tokens, EOS-padded.
+ *   logprob_out  : fp32 [B]  (AUTOREGRESSIVE: sum/num_valid, decoder.py:429-438;
+ *                              GENERATOR: length-normalised score, decoder.py:1310-1320)
+ *   info_out     : int32 [4] = { seq_len, early_all_eos, steps_run, 0 }
+ *                  seq_len = length of the tensor the reference returns (AUTOREGRESSIVE stops
+ *                  when every beam ended, decoder.py:319; GENERATOR always max_steps);
+ *                  early_all_eos=1 is the first-step early return of decoder.py:279-291. */
+int  gitmi_generate(gitmi_engine* e, const float* const* frames, int F, int B,
+                    const int64_t* prefix, int P, const gitmi_search* search,
+                    int64_t* tokens_out, float* logprob_out, int32_t* info_out, void* stream);
+
+/* ---- search with caller-supplied logits: the seam decoder.search(start, step)
+ * (decoder.py:224-231, 1083-1092) for scripted-step parity tests of the device search.
+ * begin -> [ next_input -> (caller computes logits) -> advance ]* -> finish. */
+int  gitmi_search_begin(gitmi_engine* e, const gitmi_search* search, int B,
+                        const int64_t* start_host, int P, int vocab, void* stream);
+/* current rows the `step` callable would receive: int64 [R, cur_len]; returns cur_len via *t */
+int  gitmi_search_rows(gitmi_engine* e, int64_t* tokens_out, int* R, int* t, void* stream);
+int  gitmi_search_advance(gitmi_engine* e, const float* logits, void* stream);
+int  gitmi_search_finish(gitmi_engine* e, int64_t* tokens_out, float* logprob_out,
+                         int32_t* info_out, void* stream);
+
+/* ---- profiling ---------------------------------------------------------------------- */
+int  gitmi_profile_enable(gitmi_engine* e, int on);   /* on: HIP events around phases and GEMMs */
+int  gitmi_profile_read(gitmi_engine* e, gitmi_profile* out);   /* synchronises */
+/* use hipGraph replay for gitmi_generate (default 1 unless profiling) */
+int  gitmi_set_graph(gitmi_engine* e, int on);
+
+/* ---- single-kernel entry points (unit parity tests through the C ABI).
+ * dtype arguments are GITMI_DTYPE_F32 / GITMI_DTYPE_BF16. ------------------------------- */
+/* C[M,N] = act(A[M,K] * W[N,K]^T + bias) (+ residual);  act: 0 none, 1 QuickGELU, 2 erf-GELU.
+ * A, W in `in_dtype`; bias/residual fp32 (may be NULL); C in `out_dtype`. K % 64 == 0. */
+int  gitmi_op_gemm(const void* A, const void* W, const float* bias, const float* residual,
+                   void* C, int M, int N, int K, int lda, int ldc, int in_dtype, int out_dtype,
+                   int act, void* stream);
+/* y = LayerNorm(x) (biased variance, eps), x fp32 [rows, D]; y_t (in out_dtype) and/or y_f32 */
+int  gitmi_op_layernorm(const float* x, const float* gamma, const float* beta, float eps,
+                        void* y_t, float* y_f32, int rows, int D, int out_dtype, void* stream);
+/* full (unmasked) multi-head attention over packed qkv [B*N, 3*D] (q|k|v, head h = cols h*64..);
+ * out [B*N, D].  impl: 0 = reference VALU kernel, 1 = MFMA flash kernel (bf16 only). */
+int  gitmi_op_attention(const void* qkv, void* out, int B, int N, int H, int dtype, int impl,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GITMI_H_ */

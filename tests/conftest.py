@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def golden_case(name):
+    """Rebuild (cfg, weights, frames, search, prefix) of a golden case from its recorded seeds."""
+    from oracle import git_oracle as O
+    g = load_golden(name)
+    cfg = O.CONFIGS[str(g["config"])]
+    wkw = eval(str(g["weights_kw"]), {"__builtins__": {}}, {"dict": dict})
+    kind, max_steps, k, pn, lp = eval(str(g["search"]), {"__builtins__": {}}, {})
+    search = O.SearchConfig(kind, max_steps, k, pn, lp)
+    w = O.make_weights(cfg, **wkw)
+    frames = O.make_images(cfg, int(g["batch"]), int(g["frames"]), seed=int(g["image_seed"]))
+    prefix = torch.tensor(g["prefix"], dtype=torch.long)[None] if g["prefix"].size else None
+    return g, cfg, w, frames, search, prefix

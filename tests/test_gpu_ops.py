@@ -1,0 +1,111 @@
+"""GPU: every HIP kernel that has a single-op C-ABI entry point against a plain PyTorch fp32/fp64
+reference of the same op (asymmetric random data, ragged sizes)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _act(x, act):
+    if act == 1:
+        return x * torch.sigmoid(1.702 * x)
+    if act == 2:
+        return x * 0.5 * (1.0 + torch.erf(x / 2 ** 0.5))
+    return x
+
+
+GEMM_SHAPES = [(1000, 768, 768), (197, 2304, 768), (64, 768, 3072), (300, 1002, 128), (1, 128, 64),
+               (130, 70, 640), (12608, 768, 768)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_bf16(M, N, K, act):
+    from generativeimage2text_amd import engine as E
+    A = _rand(M, K, seed=1).bfloat16()
+    W = _rand(N, K, seed=2, scale=K ** -0.5).bfloat16()
+    bias = _rand(N, seed=3)
+    res = _rand(M, N, seed=4)
+    ref = _act(A.double() @ W.double().t() + bias.double(), act) + res.double()
+    out = E.op_gemm(A.cuda(), W.cuda(), bias.cuda(), res.cuda(), act, torch.float32).cpu().double()
+    # fp32 accumulation of exact bf16 products: only summation-order error
+    assert (out - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+    out_b = E.op_gemm(A.cuda(), W.cuda(), bias.cuda(), None, act, torch.bfloat16).cpu().double()
+    ref_b = _act(A.double() @ W.double().t() + bias.double(), act)
+    assert (out_b - ref_b).abs().max().item() < 1e-2 * max(1.0, ref_b.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (64, 768, 3072), (300, 1002, 128), (1, 128, 64), (130, 70, 592)])
+def test_gemm_f32_exact_class(M, N, K):
+    from generativeimage2text_amd import engine as E
+    A = _rand(M, K, seed=5)
+    W = _rand(N, K, seed=6, scale=K ** -0.5)
+    bias = _rand(N, seed=7)
+    ref = (A.double() @ W.double().t() + bias.double())
+    out = E.op_gemm(A.cuda(), W.cuda(), bias.cuda(), None, 0, torch.float32).cpu().double()
+    assert (out - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_detects_transpose():
+    # A = I with asymmetric W: a row/col swap in the accumulator write would transpose the output
+    from generativeimage2text_amd import engine as E
+    K = 128
+    A = torch.eye(K).bfloat16()
+    W = (torch.arange(96 * K).reshape(96, K).float() % 251 - 125).bfloat16()
+    out = E.op_gemm(A.cuda(), W.cuda(), None, None, 0, torch.float32).cpu()
+    assert torch.equal(out, W.float().t())
+
+
+@pytest.mark.parametrize("rows,D", [(5, 768), (1000, 1024), (33, 128), (7, 192)])
+@pytest.mark.parametrize("eps", [1e-5, 1e-12])
+def test_layernorm(rows, D, eps):
+    from generativeimage2text_amd import engine as E
+    x = _rand(rows, D, seed=8, scale=3.0) + 0.5
+    g, b = 1 + _rand(D, seed=9, scale=0.1), _rand(D, seed=10, scale=0.1)
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), g.double(), b.double(), eps)
+    out = E.op_layernorm(x.cuda(), g.cuda(), b.cuda(), eps, torch.float32).cpu().double()
+    assert (out - ref).abs().max().item() < 2e-5
+    out_b = E.op_layernorm(x.cuda(), g.cuda(), b.cuda(), eps, torch.bfloat16).cpu().double()
+    assert (out_b - ref).abs().max().item() < 3e-2
+
+
+def _attn_ref(qkv, B, N, H):
+    D = H * 64
+    q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    return (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * N, D)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 17, 2), (3, 197, 12), (1, 257, 16), (2, 300, 3), (1, 1182, 2), (1, 64, 1)])
+def test_attention_full(B, N, H):
+    from generativeimage2text_amd import engine as E
+    qkv = _rand(B * N, 3 * H * 64, seed=11, scale=1.5)
+    ref = _attn_ref(qkv, B, N, H)
+    out = E.op_attention(qkv.cuda(), B, N, H, impl=0).cpu().double()
+    assert (out - ref).abs().max().item() < 2e-5
+    qb = qkv.bfloat16()
+    ref_b = _attn_ref(qb.float(), B, N, H)
+    for impl in (0, 1):
+        out_b = E.op_attention(qb.cuda(), B, N, H, impl=impl).cpu().double()
+        err = (out_b - ref_b).abs().max().item()
+        assert err < 3e-2, (impl, err)
+
+
+def test_attention_softmax_rescale_branch():
+    # a spiked key in a LATER tile forces the online-softmax running max to jump (rescale path)
+    from generativeimage2text_amd import engine as E
+    B, N, H = 1, 200, 1
+    qkv = _rand(N, 192, seed=12, scale=0.5)
+    qkv[150, 64:128] = qkv[3, 0:64] * 40.0
+    ref = _attn_ref(qkv, B, N, H)
+    out = E.op_attention(qkv.cuda(), B, N, H, impl=0).cpu().double()
+    assert (out - ref).abs().max().item() < 5e-5
+    qb = qkv.bfloat16()
+    ref_b = _attn_ref(qb.float(), B, N, H)
+    out_b = E.op_attention(qb.cuda(), B, N, H, impl=1).cpu().double()
+    assert (out_b - ref_b).abs().max().item() < 5e-2

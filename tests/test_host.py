@@ -1,0 +1,119 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gitmi.h declares; host-side logic."""
+import base64
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from generativeimage2text_amd import configs, engine, inference, model, tsv_io
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "gitmi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gitmi_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = engine.load_library()
+    declared = _declared_functions()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(engine.EXPORTED_SYMBOLS) == declared
+    assert lib.gitmi_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert engine.C.sizeof(engine.GitmiConfig) == 19 * 4
+    assert engine.C.sizeof(engine.GitmiSearch) == 24          # 4 x int32 + double
+    assert engine.GitmiSearch.length_penalty.offset == 16
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")
+def test_engine_fails_loudly_without_gpu():
+    with pytest.raises(engine.GitmiError):
+        engine.Engine(configs.config_for_model("GIT_BASE"))
+
+
+def test_model_param_table():
+    c = configs.config_for_model("GIT_LARGE_COCO")
+    assert (c.patch, c.vit_width, c.vit_layers, c.vit_heads, c.n_tok) == (14, 1024, 24, 16, 257)
+    c = configs.config_for_model("GIT_BASE_VATEX")
+    assert c.num_frames == 6 and c.n_tok == 197
+    c = configs.config_for_model("GIT_BASE_VQAv2")
+    assert c.image_size == 480 and c.test_respect_ratio_max == 640
+    with pytest.raises(KeyError):
+        configs.config_for_model("nope")
+
+
+def test_state_dict_suffix_alignment():
+    cfg = configs.config_for_model("GIT_BASE")
+    keys = model.expected_state_dict_keys(cfg)
+    assert len(keys) == len(set(keys))
+    loaded = {"module." + k: torch.zeros(1) for k in keys}
+    loaded["module.image_encoder.proj"] = torch.zeros(1)
+    out = model.load_state_dict_by_suffix(keys, loaded)
+    assert set(out) == set(keys)
+    # longest suffix wins
+    got = model.load_state_dict_by_suffix(["a.b.weight"], {"weight": torch.ones(1), "b.weight": torch.zeros(1)})
+    assert got["a.b.weight"].item() == 0
+
+
+def test_search_config_holders():
+    d = model.GeneratorWithBeamSearch(eos_index=102, max_steps=1024, beam_size=4, length_penalty=0.6)
+    assert (d.per_node_beam_size, d.kind) == (2, "generator")
+    a = model.AutoRegressiveBeamSearch(eos_index=102, max_steps=20, beam_size=1, per_node_beam_size=1,
+                                       fix_missing_prefix=True)
+    assert a.kind == "autoregressive"
+    with pytest.raises(AssertionError):
+        model.AutoRegressiveBeamSearch(eos_index=102)
+
+
+def test_shard_range_matches_reference_rule():
+    # inference.py:165-169: ceil(N/W) rows per rank, contiguous
+    for n, w in [(10, 3), (8, 8), (5, 8), (1000, 7)]:
+        covered = []
+        for r in range(w):
+            s, e = inference.shard_range(n, r, w)
+            covered += list(range(s, max(s, e)))
+        assert covered == list(range(n))
+
+
+def test_tsv_roundtrip_and_concat(tmp_path):
+    a, b, out = str(tmp_path / "a.tsv"), str(tmp_path / "b.tsv"), str(tmp_path / "all.tsv")
+    tsv_io.tsv_writer([["k%d" % i, "v%d" % i] for i in range(5)], a)
+    tsv_io.tsv_writer([["q%d" % i, "wé%d" % i] for i in range(3)], b)
+    assert os.path.getsize(str(tmp_path / "a.lineidx.8b")) == 5 * 8
+    t = tsv_io.TSVFile(a)
+    assert len(t) == 5 and t[3] == ["k3", "v3"]
+    tsv_io.concat_tsv_files([a, b], out)
+    t = tsv_io.TSVFile(out)
+    assert len(t) == 8 and t[6] == ["q1", "wé1"] and t[0] == ["k0", "v0"]
+    assert list(tsv_io.tsv_reader(out))[7] == ["q2", "wé2"]
+
+
+def test_image_transform_shape_and_normalisation():
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    img = Image.fromarray(rng.randint(0, 255, (300, 400, 3), dtype=np.uint8))
+    x = inference.image_transform(img, 224)
+    assert x.shape == (3, 224, 224) and x.dtype == torch.float32
+    assert -2.5 < x.mean().item() < 2.5
+    buf = io.BytesIO()
+    img.save(buf, format="JPEG")
+    im2 = inference.load_image_by_pil(base64.b64decode(base64.b64encode(buf.getvalue())))
+    assert im2.size == (400, 300)
+
+
+def test_prefix_ids_and_id_tokenizer():
+    tok = inference.IdTokenizer()
+    assert inference._prefix_ids(tok, "2054 2003") == [101, 2054, 2003]
+    long = " ".join(str(i) for i in range(1000, 1100))
+    ids = inference._prefix_ids(tok, long)
+    assert len(ids) == 39 and ids[0] == 101 and ids[-1] == 1099          # keeps the LAST 38 (inference.py:99-100)
+    assert tok.decode([101, 7, 8, 102, 102]) == "7 8"
