@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--contexts", type=int, default=4,
+                    help="engine contexts (shared weights) kept in flight on separate HIP streams")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,6 +116,14 @@ def main():
     eng.load_state_dict(random_state_dict(cfg, seed=1234))
     if args.no_graph:
         eng.set_graph(False)
+    # several batches in flight: context i%C runs on its own stream, so the latency-bound decode steps of
+    # one batch overlap the MFMA-bound encoder of the next (weights are shared, workspaces are not)
+    ctxs = [eng] + [eng.clone() for _ in range(max(1, args.contexts) - 1)]
+    for c in ctxs[1:]:
+        if args.no_graph:
+            c.set_graph(False)
+    streams = [torch.cuda.Stream() for _ in ctxs]
+    counter = [0]
     frames = random_frames(cfg, args.batch, args.frames, seed=rank)     # resident in HBM before timing
     if args.search == "greedy":
         search = Engine.make_search("greedy", args.max_steps, 1, 1)
@@ -121,9 +131,12 @@ def main():
         search = Engine.make_search("beam", args.max_steps, 4, 2, 0.6)
 
     def step():
-        tokens, logprobs, info = eng.generate(frames, search, sync=False)
-        if world > 1:
-            gather_results(tokens, logprobs)
+        i = counter[0] % len(ctxs)
+        counter[0] += 1
+        with torch.cuda.stream(streams[i]):
+            tokens, logprobs, info = ctxs[i].generate(frames, search, sync=False)
+            if world > 1:
+                gather_results(tokens, logprobs)
         return tokens, info
 
     def fence():
@@ -161,7 +174,7 @@ def main():
                                    f"max_len={args.max_steps} frames={args.frames}",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "decode_steps_per_caption": steps_run, "seq_len_returned": info_h[0],
-                       "hip_graph": not args.no_graph},
+                       "hip_graph": not args.no_graph, "contexts_in_flight": len(ctxs)},
         }
 
     # ---- roofline pass (rank 0 of N=1 only): HIP events around phases and every GEMM launch ----

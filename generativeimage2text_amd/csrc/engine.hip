@@ -70,6 +70,7 @@ struct gitmi_engine {
     bool f32 = false;
     size_t esz = 2;
     bool finalized = false;
+    gitmi_engine* parent = nullptr;   // clone: packed weights are borrowed from this engine
     int attn_impl = 1;          // 1 = MFMA flash kernel for full attention (bf16), 0 = VALU kernel
 
     std::map<std::string, HostTensor> host_w;
@@ -105,6 +106,8 @@ struct gitmi_engine {
     void *d_ht = nullptr, *d_qkv = nullptr, *d_ctx = nullptr, *d_u = nullptr;
     std::vector<void*> txt_k, txt_v;   // per layer [R_max, T_max, d]
     int ldl = 0;
+    float* d_part = nullptr;            // split-K partial slabs [S_MAX][R_max][d]
+    bool skinny = true;                 // bf16 decode GEMMs through the weight-streaming kernel
     // search
     SearchState ss{};
     int ss_cur = 0, ss_len = 0, ss_M = 0;
@@ -225,6 +228,8 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     e->Kp_pad = round_up(e->Kp, 64);
     if (const char* env = getenv("GITMI_ATTN_IMPL")) e->attn_impl = e->f32 ? 0 : atoi(env);
     if (const char* env = getenv("GITMI_GRAPH")) e->use_graph = atoi(env) != 0;
+    if (const char* env = getenv("GITMI_SKINNY")) e->skinny = atoi(env) != 0;
+    if (const char* env = getenv("GITMI_GEMM_IMPL")) set_gemm_impl(atoi(env));
     if (attn_decode_configure() != hipSuccess) { delete e; return fail("hipFuncSetAttribute failed"); }
     *out = e;
     return 0;
@@ -373,6 +378,7 @@ static int alloc_workspaces(gitmi_engine* e) {
     RCK(dev_alloc(e, &e->d_qkv, R * 3 * d * esz));
     RCK(dev_alloc(e, &e->d_ctx, R * d * esz));
     RCK(dev_alloc(e, &e->d_u, R * c.dec_ffn * esz));
+    RCK(dev_alloc_t(e, &e->d_part, (size_t)8 * R * d));
     e->ldl = round_up(c.vocab, 8);
     RCK(dev_alloc_t(e, &e->logits, R * e->ldl));
     // search state
@@ -491,6 +497,33 @@ extern "C" int gitmi_finalize_weights(gitmi_engine* e) {
     return 0;
 }
 
+// A second execution context on the same device that BORROWS the packed weights of `src` (its own
+// workspaces, KV caches, search state, streams and graph).  Lets a server keep several batches in
+// flight on different HIP streams: the latency-bound decode steps of one batch overlap the
+// MFMA-bound encoder of the next.  `src` must outlive the clone.
+extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
+    if (!src || !out) return fail("gitmi_clone: null argument");
+    if (!src->finalized) return fail("gitmi_clone: source weights not finalized");
+    HIPCK(hipSetDevice(src->device));
+    gitmi_engine* e = new gitmi_engine();
+    e->cfg = src->cfg; e->device = src->device; e->f32 = src->f32; e->esz = src->esz;
+    e->attn_impl = src->attn_impl; e->N = src->N; e->g = src->g; e->Kp = src->Kp; e->Kp_pad = src->Kp_pad;
+    e->use_graph = src->use_graph; e->skinny = src->skinny;
+    e->parent = src->parent ? src->parent : src;
+    e->conv_w = src->conv_w; e->cls = src->cls; e->pos = src->pos;
+    e->lnpre_g = src->lnpre_g; e->lnpre_b = src->lnpre_b; e->lnpost_g = src->lnpost_g; e->lnpost_b = src->lnpost_b;
+    e->vit = src->vit; e->temb = src->temb;
+    e->vp_w = src->vp_w; e->vp_b = src->vp_b; e->vp_lng = src->vp_lng; e->vp_lnb = src->vp_lnb;
+    e->words_f = src->words_f; e->positions_f = src->positions_f; e->emb_lng = src->emb_lng; e->emb_lnb = src->emb_lnb;
+    e->dec = src->dec; e->out_w = src->out_w; e->out_b = src->out_b; e->dec_weight_bytes = src->dec_weight_bytes;
+    int rc = alloc_workspaces(e);
+    if (rc != 0) { gitmi_destroy(e); return rc; }
+    HIPCK(hipDeviceSynchronize());
+    e->finalized = true;
+    *out = e;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 static int encode_frames_impl(gitmi_engine* e, const float* const* frames, int F, int B, float* feats_out,
                               hipStream_t s) {
@@ -569,6 +602,39 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
     return 0;
 }
 
+// ---- decode-step GEMMs (bf16): weight-streaming kernel, optional split-K + fused LayerNorm -------
+static int pick_splitk(int K, int n_blocks) {
+    // enough workgroups to cover the chip while every wave keeps >= 2 k-steps of 32
+    const int ksteps = K / 32;
+    int S = 1;
+    while (S < 8 && n_blocks * S < 160 && ksteps / (4 * (S + 1)) >= 2) ++S;
+    return S;
+}
+static int skinny(gitmi_engine* e, hipStream_t s, const void* A, int lda, const void* W, const float* bias,
+                  const float* res, int ldr, void* C, int ldc, bool out_f32, int M, int N, int K, int act, int NT) {
+    SkinnyArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.res = res; g.C = C; g.partial = nullptr;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldr; g.act = act; g.S = 1;
+    SpanGuard sp(e, s, TAG_GEMM_OTHER, 2.0 * (double)M * (double)N * (double)K);
+    HIPCK(launch_skinny_gemm(g, out_f32, NT, s));
+    return 0;
+}
+// y = LayerNorm(A W^T + bias + res) -> (y_f fp32, y_t bf16)
+static int skinny_ln(gitmi_engine* e, hipStream_t s, const void* A, int lda, const void* W, const float* bias,
+                     const float* res, const float* gamma, const float* beta, float eps, float* y_f, void* y_t,
+                     int M, int N, int K) {
+    SkinnyArgs g{};
+    g.A = A; g.W = W; g.partial = e->d_part;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = N; g.ldr = N; g.act = 0;
+    g.S = std::max(2, pick_splitk(K, ((N + 15) / 16) * ((M + 63) / 64)));
+    {
+        SpanGuard sp(e, s, TAG_GEMM_OTHER, 2.0 * (double)M * (double)N * (double)K);
+        HIPCK(launch_skinny_gemm(g, true, 1, s));
+    }
+    HIPCK(launch_splitk_ln(e->d_part, g.S, bias, res, gamma, beta, eps, y_f, y_t, M, N, s));
+    return 0;
+}
+
 // one text position for every row of the beam batch
 static int decode_step_impl(gitmi_engine* e, const int* ids, const int* kv_src, int ld_ids, int pos, int R,
                             int beams, bool want_logits, hipStream_t s) {
@@ -578,22 +644,32 @@ static int decode_step_impl(gitmi_engine* e, const int* ids, const int* kv_src, 
     SpanGuard step(e, s, TAG_STEP, 0);
     HIPCK(launch_embed_ln(ids, ld_ids, pos, e->words_f, e->positions_f, e->emb_lng, e->emb_lnb, 1e-8f, e->d_hf,
                           e->d_ht, e->f32, R, d, c.vocab, s));
+    const bool sk = e->skinny && !e->f32;
     for (int l = 0; l < c.dec_layers; ++l) {
         const DecLayerW& L = e->dec[l];
-        RCK(gemm(e, s, e->d_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->d_qkv, 3 * d, e->f32, R, 3 * d, d, 0, TAG_GEMM_OTHER));
+        if (sk) RCK(skinny(e, s, e->d_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->d_qkv, 3 * d, false, R, 3 * d, d, 0, 1));
+        else RCK(gemm(e, s, e->d_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->d_qkv, 3 * d, e->f32, R, 3 * d, d, 0, TAG_GEMM_OTHER));
         AttnDecodeArgs a{};
         a.qkv = e->d_qkv; a.img_kv = e->img_kv[l]; a.txt_k = e->txt_k[l]; a.txt_v = e->txt_v[l]; a.out = e->d_ctx;
         a.kv_src = kv_src; a.ld_src = ld_ids; a.d = d; a.N_img = e->cur_Nimg; a.T_max = c.max_text_len;
         a.pos = pos; a.beams = beams; a.scale = 0.125f;
         HIPCK(launch_attn_decode(a, B, c.dec_heads, e->f32, s));
-        RCK(gemm(e, s, e->d_ctx, d, L.wo, L.bo, e->d_hf, d, e->d_y, d, true, R, d, d, 0, TAG_GEMM_OTHER));
-        HIPCK(launch_layernorm(e->d_y, d, L.lnag, L.lnab, 1e-12f, nullptr, e->d_ht, d, e->f32, e->d_hf, d, R, d, 0, 0, 0, s));
-        RCK(gemm(e, s, e->d_ht, d, L.w1, L.b1, nullptr, 0, e->d_u, ffn, e->f32, R, ffn, d, 2, TAG_GEMM_OTHER));
-        RCK(gemm(e, s, e->d_u, ffn, L.w2, L.b2, e->d_hf, d, e->d_y, d, true, R, d, ffn, 0, TAG_GEMM_OTHER));
-        HIPCK(launch_layernorm(e->d_y, d, L.lnog, L.lnob, 1e-12f, nullptr, e->d_ht, d, e->f32, e->d_hf, d, R, d, 0, 0, 0, s));
+        if (sk) {
+            RCK(skinny_ln(e, s, e->d_ctx, d, L.wo, L.bo, e->d_hf, L.lnag, L.lnab, 1e-12f, e->d_hf, e->d_ht, R, d, d));
+            RCK(skinny(e, s, e->d_ht, d, L.w1, L.b1, nullptr, 0, e->d_u, ffn, false, R, ffn, d, 2, 1));
+            RCK(skinny_ln(e, s, e->d_u, ffn, L.w2, L.b2, e->d_hf, L.lnog, L.lnob, 1e-12f, e->d_hf, e->d_ht, R, d, ffn));
+        } else {
+            RCK(gemm(e, s, e->d_ctx, d, L.wo, L.bo, e->d_hf, d, e->d_y, d, true, R, d, d, 0, TAG_GEMM_OTHER));
+            HIPCK(launch_layernorm(e->d_y, d, L.lnag, L.lnab, 1e-12f, nullptr, e->d_ht, d, e->f32, e->d_hf, d, R, d, 0, 0, 0, s));
+            RCK(gemm(e, s, e->d_ht, d, L.w1, L.b1, nullptr, 0, e->d_u, ffn, e->f32, R, ffn, d, 2, TAG_GEMM_OTHER));
+            RCK(gemm(e, s, e->d_u, ffn, L.w2, L.b2, e->d_hf, d, e->d_y, d, true, R, d, ffn, 0, TAG_GEMM_OTHER));
+            HIPCK(launch_layernorm(e->d_y, d, L.lnog, L.lnob, 1e-12f, nullptr, e->d_ht, d, e->f32, e->d_hf, d, R, d, 0, 0, 0, s));
+        }
     }
-    if (want_logits)
-        RCK(gemm(e, s, e->d_ht, d, e->out_w, e->out_b, nullptr, 0, e->logits, e->ldl, true, R, c.vocab, d, 0, TAG_GEMM_OTHER));
+    if (want_logits) {
+        if (sk) RCK(skinny(e, s, e->d_ht, d, e->out_w, e->out_b, nullptr, 0, e->logits, e->ldl, true, R, c.vocab, d, 0, 2));
+        else RCK(gemm(e, s, e->d_ht, d, e->out_w, e->out_b, nullptr, 0, e->logits, e->ldl, true, R, c.vocab, d, 0, TAG_GEMM_OTHER));
+    }
     return 0;
 }
 
@@ -912,5 +988,31 @@ extern "C" int gitmi_op_attention(const void* qkv, void* out, int B, int N, int 
     a.N = N; a.H = H; a.scale = 0.125f;
     if (attn_decode_configure() != hipSuccess) return fail("configure failed");
     HIPCK(launch_attn_full(a, B, dtype == GITMI_DTYPE_F32, impl, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int gitmi_op_gemm_skinny(const void* A, const void* W, const float* bias, const float* residual, void* C,
+                                    int M, int N, int K, int out_dtype, int act, int NT, void* stream) {
+    SkinnyArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.res = residual; g.C = C; g.partial = nullptr;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N; g.act = act; g.S = 1;
+    if (K % 32) return fail("op_gemm_skinny: K must be a multiple of 32");
+    HIPCK(launch_skinny_gemm(g, out_dtype == GITMI_DTYPE_F32, NT, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int gitmi_op_gemm_splitk_ln(const void* A, const void* W, const float* bias, const float* residual,
+                                       const float* gamma, const float* beta, float eps, float* partial_ws, int S,
+                                       float* y_f32, void* y_bf16, int M, int N, int K, void* stream) {
+    SkinnyArgs g{};
+    g.A = A; g.W = W; g.partial = partial_ws;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N; g.act = 0; g.S = S;
+    if (K % 32 || S < 2 || N > 1024) return fail("op_gemm_splitk_ln: need K%%32==0, S>=2, N<=1024");
+    HIPCK(launch_skinny_gemm(g, true, 1, (hipStream_t)stream));
+    HIPCK(launch_splitk_ln(partial_ws, S, bias, residual, gamma, beta, eps, y_f32, y_bf16, M, N, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int gitmi_debug_set_gemm_impl(int impl) {
+    set_gemm_impl(impl);
     return 0;
 }

@@ -253,6 +253,33 @@ __global__ __launch_bounds__(256) void attn_full_mfma_kernel(AttnFullArgs a) {
 //   out      : [R, d]
 // dynamic LDS: scores[k][Nk] + q[k][64] + red[32][k][64]   (Nk = N_img + pos + 1)
 // ---------------------------------------------------------------------------------------
+// 16 bytes-or-32 of one key/value row slice kept raw in registers until it is consumed
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    u32x4_t r;
+    __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const u32x4_t*>(p); }
+    __device__ __forceinline__ void zero() { r = u32x4_t{0u, 0u, 0u, 0u}; }
+    __device__ __forceinline__ void get(float (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(r[i] << 16);
+            v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+        }
+    }
+};
+template <> struct Raw8<float> {
+    f32x4_t a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const f32x4_t*>(p);
+        b = *reinterpret_cast<const f32x4_t*>(p + 4);
+    }
+    __device__ __forceinline__ void zero() { a = f32x4_t{0.f, 0.f, 0.f, 0.f}; b = a; }
+    __device__ __forceinline__ void get(float (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
@@ -271,6 +298,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     T* O = reinterpret_cast<T*>(a.out);
     const int ld3 = 3 * a.d;
     const int row0 = b * k;
+    const int grp = tid >> 3, sub = tid & 7;    // 32 groups of 8 lanes; a group reads one 64-dim row
+    constexpr int PF = 8;                       // image keys per group kept in flight (covers N_img <= 256)
+
+    // image K rows of the first chunk: issued before anything else so HBM latency overlaps the q staging
+    const T* kbase = IMG + (size_t)b * a.N_img * ld3 + a.d + h * HD + sub * 8;
+    const T* vbase = kbase + a.d;
+    Raw8<T> kr[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int n = grp + 32 * u;
+        if (n < a.N_img) kr[u].load(kbase + (size_t)n * ld3);
+        else kr[u].zero();
+    }
 
     // stage q (scaled) and append this position's K/V of every beam to the text cache
     for (int i = tid; i < k * HD; i += 256) {
@@ -283,21 +323,39 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     }
     __syncthreads();
 
-    const int grp = tid >> 3, sub = tid & 7;    // 32 groups of 8 lanes; a group reads one 64-dim row
-
     // ---- scores over image keys: every beam uses the same key row ----------------------
-    for (int n = grp; n < a.N_img; n += 32) {
-        float kv[8];
-        ld8(IMG + ((size_t)b * a.N_img + n) * ld3 + a.d + h * HD + sub * 8, kv);
-        for (int j = 0; j < k; ++j) {
-            float p = 0.f;
+    for (int base = 0; base < a.N_img; base += 32 * PF) {
+        if (base > 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) p += qs[j * HD + sub * 8 + e] * kv[e];
-            p += __shfl_xor(p, 1, 64);
-            p += __shfl_xor(p, 2, 64);
-            p += __shfl_xor(p, 4, 64);
-            if (sub == 0) sc[(size_t)j * Nk + n] = p;
+            for (int u = 0; u < PF; ++u) {
+                const int n = base + grp + 32 * u;
+                if (n < a.N_img) kr[u].load(kbase + (size_t)n * ld3);
+                else kr[u].zero();
+            }
         }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int n = base + grp + 32 * u;
+            float kv[8];
+            kr[u].get(kv);
+            for (int j = 0; j < k; ++j) {
+                float p = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) p += qs[j * HD + sub * 8 + e] * kv[e];
+                p += __shfl_xor(p, 1, 64);
+                p += __shfl_xor(p, 2, 64);
+                p += __shfl_xor(p, 4, 64);
+                if (sub == 0 && n < a.N_img) sc[(size_t)j * Nk + n] = p;
+            }
+        }
+    }
+    // image V rows of the first chunk: in flight across the softmax
+    Raw8<T> vr[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int n = grp + 32 * u;
+        if (n < a.N_img) vr[u].load(vbase + (size_t)n * ld3);
+        else vr[u].zero();
     }
     // ---- scores over text keys (per beam, through the indirection) ---------------------
     const int nt = a.pos + 1;
@@ -347,15 +405,29 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
 
-    for (int n = grp; n < a.N_img; n += 32) {
-        float vv[8];
-        ld8(IMG + ((size_t)b * a.N_img + n) * ld3 + 2 * a.d + h * HD + sub * 8, vv);
+    for (int base = 0; base < a.N_img; base += 32 * PF) {
+        if (base > 0) {
 #pragma unroll
-        for (int j = 0; j < KMAX; ++j) {
-            if (j < k) {
-                const float p = sc[(size_t)j * Nk + n];
+            for (int u = 0; u < PF; ++u) {
+                const int n = base + grp + 32 * u;
+                if (n < a.N_img) vr[u].load(vbase + (size_t)n * ld3);
+                else vr[u].zero();
+            }
+        }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[j][e] += p * vv[e];
+        for (int u = 0; u < PF; ++u) {
+            const int n = base + grp + 32 * u;
+            if (n < a.N_img) {
+                float vv[8];
+                vr[u].get(vv);
+#pragma unroll
+                for (int j = 0; j < KMAX; ++j) {
+                    if (j < k) {
+                        const float p = sc[(size_t)j * Nk + n];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[j][e] += p * vv[e];
+                    }
+                }
             }
         }
     }
@@ -369,7 +441,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
             ld8(TV + ((size_t)srow * a.T_max + s) * a.d + h * HD + sub * 8, vv);
         }
         const float p = sc[(size_t)j * Nk + a.N_img + s];
-        // beam index is data dependent here: accumulate through LDS-free select
 #pragma unroll
         for (int jj = 0; jj < KMAX; ++jj) {
             if (jj == j) {

@@ -256,9 +256,17 @@ static hipError_t launch_gemm_tiles(const GemmArgs& g, hipStream_t s) {
     return launch_gemm_t<TIn, TOut, 128, 128>(g, s);
 }
 
+static int g_gemm_impl = -1;
+void set_gemm_impl(int impl) { g_gemm_impl = impl; }
+
 // in_f32/out_f32: element types of A,W and of C
 hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    // impl: -1 auto | 0 first generation | 1 direct-to-LDS 128x128 | 2 256x128 3-stage ring
+    if (g_gemm_impl != 0 && gemm_dlds_supported(g, in_f32, out_f32)) {
+        if (g_gemm_impl == 2 || (g_gemm_impl == -1 && g.M > 512)) return launch_gemm_ring(g, out_f32, s);
+        if (g_gemm_impl == 1 || (g_gemm_impl == -1 && g.M > 256)) return launch_gemm_dlds(g, out_f32, s);
+    }
     if (in_f32) {
         if (g.K % 16 != 0) return hipErrorInvalidValue;
         return out_f32 ? launch_gemm_tiles<float, float>(g, s) : launch_gemm_tiles<float, bf16_t>(g, s);

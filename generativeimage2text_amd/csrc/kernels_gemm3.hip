@@ -1,0 +1,225 @@
+// bf16 GEMM for the large-M phases -- third generation: 256x128x64 tile, 8 waves, 3 LDS stages.
+//
+//   C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) (+ residual[M,N])      K % 64 == 0, N % 8 == 0
+//
+//   * 512 threads = 8 waves as 4 (M) x 2 (N), each wave a 64x64 output (4x4 MFMA 16x16x32 tiles,
+//     swapped orientation: accumulator = C^T, see kernels_gemm.hip);
+//   * operands stream HBM -> LDS with global_load_lds_dwordx4 into a 3-deep ring (3 x 48 KiB): the
+//     loads of K step t+2 are issued at the top of step t, and the step ends with a COUNTED
+//     `s_waitcnt vmcnt(6)` (this wave's 6 loads of step t+1 have landed, the 6 of step t+2 stay in
+//     flight) followed by a raw s_barrier -- no vmcnt(0) drain in the main loop;
+//   * LDS image: 128-byte rows paired into 256-byte bank rows; 16-byte chunk c of row r lives at
+//         (r>>1)*256 + ((r&1) ^ ((r>>3)&1))*128 + (c ^ ((r>>1)&7))*16
+//     which makes every ds_read_b128 lane group hit 16 distinct bank slots.  A direct-to-LDS load
+//     writes lane-linearly, so the permutation is applied to each lane's SOURCE address (and again
+//     on the fragment read);
+//   * epilogue staged through LDS: bias/activation in registers, then 16-byte row-contiguous
+//     stores (and 16/32-byte row-contiguous residual reads).
+#include "gitmi_common.h"
+#include "launchers.h"
+
+namespace gitmi {
+
+namespace {
+
+constexpr int BM = 256, BN = 128, BK = 64;
+constexpr int A_BYTES = BM * BK * 2;                 // 32 KiB
+constexpr int W_BYTES = BN * BK * 2;                 // 16 KiB
+constexpr int STAGE_BYTES = A_BYTES + W_BYTES;       // 48 KiB
+constexpr int NSTAGE = 3;
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;      // 144 KiB
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+__device__ __forceinline__ int xcd_remap3(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <typename TOut>
+__global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 3, wn = wave >> 2;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    const int swz = xcd_remap3(blockIdx.x, g.nwg);
+    const int tile_n = swz % g.tiles_n;
+    const int tile_m = swz / g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A);
+    const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+
+    // ---- staging sources: a wave instruction fills 1 KiB = 4 bank rows = 8 tile rows ---------
+    // lane -> bank row Rl = lane>>4, half hi = (lane>>3)&1, slot lo = lane&7; group parity p = q&1
+    const int Rl = lane >> 4, hi = (lane >> 3) & 1, lo = lane & 7;
+    const bf16_t* a_src[4];
+    const bf16_t* w_src[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int p = q & 1;
+        int r = m0 + (wave * 4 + q) * 8 + 2 * Rl + (hi ^ p);
+        r = r < g.M ? r : g.M - 1;
+        a_src[q] = A + (size_t)r * g.lda + (lo ^ (p * 4 + Rl)) * 8;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int p = q & 1;
+        int n = n0 + (wave * 2 + q) * 8 + 2 * Rl + (hi ^ p);
+        n = n < g.N ? n : g.N - 1;
+        w_src[q] = W + (size_t)n * g.K + (lo ^ (p * 4 + Rl)) * 8;
+    }
+    auto issue = [&](int kt, int stage) {
+        unsigned char* base = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((const void*)(a_src[q] + kt * BK),
+                                             (lds_void_t*)(base + (wave * 4 + q) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds((const void*)(w_src[q] + kt * BK),
+                                             (lds_void_t*)(base + A_BYTES + (wave * 2 + q) * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment addressing -----------------------------------------------------------------
+    const int rowpart = (l15 >> 1) * 256 + ((l15 & 1) ^ ((l15 >> 3) & 1)) * 128;
+    const int x = (l15 >> 1) & 7;
+    const int ch0 = ((0 * 4 + lg) ^ x) * 16;
+    const int ch1 = ((1 * 4 + lg) ^ x) * 16;
+    const int a_off = wm * 64 * 128 + rowpart;
+    const int w_off = A_BYTES + wn * 64 * 128 + rowpart;
+
+    f32x4_t acc[4][4];   // [j: n-tile][i: m-tile]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    issue(0, 0);
+    if (nk > 1) {
+        issue(1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        int nxt2 = stage + 2;
+        nxt2 = nxt2 >= NSTAGE ? nxt2 - NSTAGE : nxt2;
+        if (kt + 2 < nk) issue(kt + 2, nxt2);
+        const unsigned char* sb = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ch = kk == 0 ? ch0 : ch1;
+            bf16x8_t wf[4], af[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wf[j] = *reinterpret_cast<const bf16x8_t*>(sb + w_off + j * 16 * 128 + ch);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[i] = *reinterpret_cast<const bf16x8_t*>(sb + a_off + i * 16 * 128 + ch);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        // this wave's loads of step kt+1 have landed; the ones just issued (kt+2) may stay in flight
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+    }
+
+    // ---- epilogue through LDS (whole 256x128 tile) --------------------------------------------
+    constexpr int EPS = sizeof(TOut) == 4 ? 132 : 136;           // padded row stride (elements)
+    constexpr int CPR = BN * (int)sizeof(TOut) / 16;             // 16-byte chunks per row
+    constexpr int EPC = 16 / (int)sizeof(TOut);                  // elements per chunk
+    static_assert(BM * EPS * sizeof(TOut) <= LDS_BYTES, "epilogue tile does not fit");
+    TOut* ep = reinterpret_cast<TOut*>(smem);
+    TOut* __restrict__ C = reinterpret_cast<TOut*>(g.C);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nl = wn * 64 + j * 16 + lg * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + nl + r < g.N) bv[r] = g.bias[n0 + nl + r];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[j][i][r] + bv[r], g.act);
+            TOut* p = ep + (wm * 64 + i * 16 + l15) * EPS + nl;
+            if constexpr (sizeof(TOut) == 4) {
+                *reinterpret_cast<f32x4_t*>(p) = f32x4_t{v[0], v[1], v[2], v[3]};
+            } else {
+                uint2 t;
+                t.x = pack2bf(v[0], v[1]);
+                t.y = pack2bf(v[2], v[3]);
+                *reinterpret_cast<uint2*>(p) = t;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int q = 0; q < BM * CPR / 512; ++q) {
+        const int chunk = tid + q * 512;
+        const int row = chunk / CPR, cc = chunk % CPR;
+        const int m = m0 + row;
+        const int n = n0 + cc * EPC;
+        if (m < g.M && n < g.N) {
+            if constexpr (sizeof(TOut) == 4) {
+                f32x4_t v = *reinterpret_cast<const f32x4_t*>(ep + row * EPS + cc * EPC);
+                if (g.res) {
+                    const f32x4_t rr = *reinterpret_cast<const f32x4_t*>(g.res + (size_t)m * g.ldr + n);
+                    v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+                }
+                *reinterpret_cast<f32x4_t*>(C + (size_t)m * g.ldc + n) = v;
+            } else {
+                u32x4_t v = *reinterpret_cast<const u32x4_t*>(ep + row * EPS + cc * EPC);
+                if (g.res) {
+                    const float* rp = g.res + (size_t)m * g.ldr + n;
+                    const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(rp);
+                    const f32x4_t r1 = *reinterpret_cast<const f32x4_t*>(rp + 4);
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        f[2 * e] = __uint_as_float(v[e] << 16);
+                        f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { f[e] += r0[e]; f[4 + e] += r1[e]; }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = pack2bf(f[2 * e], f[2 * e + 1]);
+                }
+                *reinterpret_cast<u32x4_t*>(C + (size_t)m * g.ldc + n) = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_gemm_ring(GemmArgs g, bool out_f32, hipStream_t s) {
+    const int tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    g.nwg = tiles_m * g.tiles_n;
+    if (out_f32) hipLaunchKernelGGL(gemm_ring_kernel<float>, dim3(g.nwg), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL(gemm_ring_kernel<bf16_t>, dim3(g.nwg), dim3(512), 0, s, g);
+    return hipGetLastError();
+}
+
+}  // namespace gitmi

@@ -54,8 +54,7 @@ __global__ __launch_bounds__(256) void row_topm_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < MMAX; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
     float mx = -INFINITY, sm = 0.f;
-    for (int i = tid; i < V; i += 256) {
-        float v = x[i];
+    auto feed = [&](float v, int i) {
         if (suppress_last && i == last) v = -10000.f;
         // online log-sum-exp
         if (v > mx) { sm = sm * __expf(mx - v) + 1.f; mx = v; }
@@ -70,6 +69,29 @@ __global__ __launch_bounds__(256) void row_topm_kernel(const float* __restrict__
                 }
             }
         }
+    };
+    if ((ldl & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+        // 16-byte loads, four of them in flight per thread before the first compare
+        const int nchunk = V >> 2;
+        const f32x4_t* x4 = reinterpret_cast<const f32x4_t*>(x);
+        int c = tid;
+        for (; c + 3 * 256 < nchunk; c += 4 * 256) {
+            f32x4_t q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = x4[c + u * 256];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) feed(q[u][r], (c + u * 256) * 4 + r);
+        }
+        for (; c < nchunk; c += 256) {
+            const f32x4_t q = x4[c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) feed(q[r], c * 4 + r);
+        }
+        for (int i = (nchunk << 2) + tid; i < V; i += 256) feed(x[i], i);
+    } else {
+        for (int i = tid; i < V; i += 256) feed(x[i], i);
     }
     // block log-sum-exp
     float bmx = wave_max(mx);

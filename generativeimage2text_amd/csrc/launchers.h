@@ -13,6 +13,23 @@ struct GemmArgs {
     int tiles_n, nwg;
 };
 hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t s);
+// second-generation bf16 kernel (direct-to-LDS staging, swizzled LDS, LDS-staged epilogue)
+bool gemm_dlds_supported(const GemmArgs& g, bool in_f32, bool out_f32);
+hipError_t launch_gemm_dlds(GemmArgs g, bool out_f32, hipStream_t s);
+hipError_t launch_gemm_ring(GemmArgs g, bool out_f32, hipStream_t s);   // 256x128 tile, 3-stage ring
+void set_gemm_impl(int impl);   // -1 auto, 0 first-generation kernel only, 1 force direct-to-LDS kernel
+
+// weight-streaming GEMM for decode (bf16 operands): C or fp32 partial slabs [S][M][N]
+struct SkinnyArgs {
+    const void* A; const void* W; const float* bias; const float* res; void* C; float* partial;
+    int M, N, K;
+    int lda, ldc, ldr;
+    int act;
+    int S;      // K slices across workgroups (1 = fused epilogue, >1 = partial slabs)
+};
+hipError_t launch_skinny_gemm(SkinnyArgs g, bool out_f32, int NT, hipStream_t s);
+hipError_t launch_splitk_ln(const float* partial, int S, const float* bias, const float* res, const float* gamma,
+                            const float* beta, float eps, float* y_f, void* y_t, int rows, int D, hipStream_t s);
 
 hipError_t launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps,
                             const float* add_after, void* y_t, int ld_t, bool t_is_f32, float* y_f, int ld_f,

@@ -25,7 +25,8 @@ EXPORTED_SYMBOLS = [
     "gitmi_finalize_weights", "gitmi_encode_frames", "gitmi_prefill", "gitmi_step_logits",
     "gitmi_generate", "gitmi_search_begin", "gitmi_search_rows", "gitmi_search_advance",
     "gitmi_search_finish", "gitmi_profile_enable", "gitmi_profile_read", "gitmi_set_graph",
-    "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention",
+    "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_gemm_skinny",
+    "gitmi_op_gemm_splitk_ln", "gitmi_debug_set_gemm_impl", "gitmi_clone",
 ]
 
 
@@ -91,6 +92,10 @@ def load_library() -> C.CDLL:
     lib.gitmi_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_attention.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.gitmi_op_gemm_skinny.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.gitmi_debug_set_gemm_impl.argtypes = [i32]
+    lib.gitmi_clone.argtypes = [vp, C.POINTER(vp)]
+    lib.gitmi_op_gemm_splitk_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, i32, vp, vp, i32, i32, i32, vp]
     for name in EXPORTED_SYMBOLS:
         if name not in ("gitmi_last_error", "gitmi_destroy"):
             getattr(lib, name).restype = C.c_int
@@ -144,6 +149,18 @@ class Engine:
         self._cur_F = 0
 
     # -- lifecycle ---------------------------------------------------------------------------
+    def clone(self) -> "Engine":
+        """A second context sharing this engine's packed weights (own workspaces / KV caches / graph),
+        for keeping several batches in flight on different streams.  Keep `self` alive while it is used."""
+        other = object.__new__(Engine)
+        other.lib, other.device, other.cfg, other.precision, other.c = self.lib, self.device, self.cfg, self.precision, self.c
+        other.n_tok = self.n_tok
+        other._h = C.c_void_p()
+        _ck(self.lib.gitmi_clone(self._h, C.byref(other._h)))
+        other._finalized, other._cur_B, other._cur_F = True, 0, 0
+        other._parent = self
+        return other
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.gitmi_destroy(self._h)
@@ -300,3 +317,35 @@ def op_attention(qkv: torch.Tensor, B: int, N: int, H: int, impl: int) -> torch.
     out = torch.empty(B * N, H * 64, device=qkv.device, dtype=qkv.dtype)
     _ck(lib.gitmi_op_attention(qkv.data_ptr(), out.data_ptr(), B, N, H, _torch_dtype_code(qkv), impl, _stream()))
     return out
+
+
+def op_gemm_skinny(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                   residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+                   out_dtype: torch.dtype = torch.float32, NT: int = 1) -> torch.Tensor:
+    lib = load_library()
+    assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and A.is_contiguous() and W.is_contiguous()
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty(M, N, device=A.device, dtype=out_dtype)
+    _ck(lib.gitmi_op_gemm_skinny(A.data_ptr(), W.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K,
+                                 _torch_dtype_code(out), act, NT, _stream()))
+    return out
+
+
+def op_gemm_splitk_ln(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, residual: torch.Tensor,
+                      gamma: torch.Tensor, beta: torch.Tensor, eps: float, S: int):
+    lib = load_library()
+    M, K = A.shape
+    N = W.shape[0]
+    ws = torch.empty(S, M, N, device=A.device, dtype=torch.float32)
+    y_f = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    y_t = torch.empty(M, N, device=A.device, dtype=torch.bfloat16)
+    _ck(lib.gitmi_op_gemm_splitk_ln(A.data_ptr(), W.data_ptr(), bias.data_ptr(), residual.data_ptr(), gamma.data_ptr(),
+                                    beta.data_ptr(), eps, ws.data_ptr(), S, y_f.data_ptr(), y_t.data_ptr(), M, N, K,
+                                    _stream()))
+    return y_f, y_t
+
+
+def set_gemm_impl(impl: int) -> None:
+    """-1 auto, 0 first-generation GEMM kernel, 1 direct-to-LDS kernel (A/B measurements)."""
+    _ck(load_library().gitmi_debug_set_gemm_impl(int(impl)))

@@ -111,6 +111,11 @@ int  gitmi_load_tensor(gitmi_engine* e, const char* key, const void* data_host,
  * textual.output.weight to embedding.words.weight if it was not loaded (decoder.py:503-505) */
 int  gitmi_finalize_weights(gitmi_engine* e);
 
+/* second execution context on the same device that borrows the packed weights of `src` (own
+ * workspaces / KV caches / search state / graph): several batches in flight on different streams.
+ * `src` must outlive the clone; destroy clones with gitmi_destroy. */
+int  gitmi_clone(gitmi_engine* src, gitmi_engine** out);
+
 /* ---- image encoder: replaces model.image_encoder(x) + the multi-frame branch of
  * CaptioningModel.forward_one (CLIP/model.py:240-274, decoder.py:845-857).
  * frames: F device pointers to fp32 [B,3,H,W] (H=W=image_size).  The visual features
@@ -176,6 +181,21 @@ int  gitmi_op_layernorm(const float* x, const float* gamma, const float* beta, f
  * out [B*N, D].  impl: 0 = reference VALU kernel, 1 = MFMA flash kernel (bf16 only). */
 int  gitmi_op_attention(const void* qkv, void* out, int B, int N, int H, int dtype, int impl,
                         void* stream);
+
+/* decode-step weight-streaming GEMM (bf16 A,W; M small): same contract as gitmi_op_gemm, dense
+ * lda=K, ldc=N.  NT in {1,2}: 16*NT output columns per workgroup. */
+int  gitmi_op_gemm_skinny(const void* A, const void* W, const float* bias, const float* residual,
+                          void* C, int M, int N, int K, int out_dtype, int act, int NT, void* stream);
+/* y = LayerNorm(A W^T + bias + residual): split-K over S workgroup slices into fp32 slabs
+ * partial_ws [S,M,N], summed in fixed order with the LayerNorm fused (BertSelfOutput / BertOutput,
+ * modeling_bert.py:171-178, 243-250).  Outputs fp32 and bf16 copies.  N <= 1024. */
+int  gitmi_op_gemm_splitk_ln(const void* A, const void* W, const float* bias, const float* residual,
+                             const float* gamma, const float* beta, float eps, float* partial_ws, int S,
+                             float* y_f32, void* y_bf16, int M, int N, int K, void* stream);
+
+/* kernel selection for A/B measurements: -1 auto (default), 0 first-generation GEMM only,
+ * 1 force the direct-to-LDS GEMM wherever its constraints hold */
+int  gitmi_debug_set_gemm_impl(int impl);
 
 #ifdef __cplusplus
 }

@@ -109,3 +109,38 @@ def test_attention_softmax_rescale_branch():
     ref_b = _attn_ref(qb.float(), B, N, H)
     out_b = E.op_attention(qb.cuda(), B, N, H, impl=1).cpu().double()
     assert (out_b - ref_b).abs().max().item() < 5e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 768, 768), (64, 2304, 768), (64, 30522, 768), (256, 3072, 768),
+                                   (5, 130, 128), (100, 1002, 96), (64, 768, 3072)])
+@pytest.mark.parametrize("NT", [1, 2])
+@pytest.mark.parametrize("act", [0, 2])
+def test_gemm_skinny(M, N, K, NT, act):
+    from generativeimage2text_amd import engine as E
+    A = _rand(M, K, seed=21).bfloat16()
+    W = _rand(N, K, seed=22, scale=K ** -0.5).bfloat16()
+    bias = _rand(N, seed=23)
+    res = _rand(M, N, seed=24)
+    ref = _act(A.double() @ W.double().t() + bias.double(), act) + res.double()
+    out = E.op_gemm_skinny(A.cuda(), W.cuda(), bias.cuda(), res.cuda(), act, torch.float32, NT).cpu().double()
+    assert (out - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+    out_b = E.op_gemm_skinny(A.cuda(), W.cuda(), bias.cuda(), None, act, torch.bfloat16, NT).cpu().double()
+    ref_b = _act(A.double() @ W.double().t() + bias.double(), act)
+    assert (out_b - ref_b).abs().max().item() < 1e-2 * max(1.0, ref_b.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K,S", [(64, 768, 768, 3), (64, 768, 3072, 4), (256, 768, 3072, 2), (7, 128, 512, 4),
+                                     (33, 128, 128, 2), (64, 768, 768, 8)])
+def test_gemm_splitk_layernorm(M, N, K, S):
+    from generativeimage2text_amd import engine as E
+    A = _rand(M, K, seed=31).bfloat16()
+    W = _rand(N, K, seed=32, scale=K ** -0.5).bfloat16()
+    bias, res = _rand(N, seed=33), _rand(M, N, seed=34)
+    g, b = 1 + _rand(N, seed=35, scale=0.1), _rand(N, seed=36, scale=0.1)
+    pre = A.double() @ W.double().t() + bias.double() + res.double()
+    ref = torch.nn.functional.layer_norm(pre, (N,), g.double(), b.double(), 1e-12)
+    y_f, y_t = E.op_gemm_splitk_ln(A.cuda(), W.cuda(), bias.cuda(), res.cuda(), g.cuda(), b.cuda(), 1e-12, S)
+    assert (y_f.cpu().double() - ref).abs().max().item() < 3e-4
+    assert (y_t.cpu().double() - ref).abs().max().item() < 3e-2
+    y_f2, _ = E.op_gemm_splitk_ln(A.cuda(), W.cuda(), bias.cuda(), res.cuda(), g.cuda(), b.cuda(), 1e-12, S)
+    assert torch.equal(y_f, y_f2)            # fixed summation order: bitwise reproducible

@@ -275,3 +275,24 @@ def test_full_size_b16_matches_oracle_tokens_f32():
     assert torch.equal(tokens[:, :L].cpu(), ref["predictions"])
     assert torch.allclose(logprobs.cpu(), ref["logprobs"], atol=2e-3)
     eng.close()
+
+
+def test_cloned_context_shares_weights_and_overlaps(base_engine):
+    # a clone borrows the packed weights: same captions, and two contexts may run on two streams at once
+    from generativeimage2text_amd.engine import Engine
+    from generativeimage2text_amd.synthetic import random_frames
+    cfg, eng = base_engine
+    other = eng.clone()
+    fa, fb = random_frames(cfg, 16, 1, seed=11), random_frames(cfg, 16, 1, seed=12)
+    s = Engine.make_search("greedy", 20, 1, 1)
+    ta, _, _ = eng.generate(fa, s)
+    tb, _, _ = eng.generate(fb, s)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        ta2, _, _ = eng.generate(fa, s, sync=False)
+    with torch.cuda.stream(s2):
+        tb2, _, _ = other.generate(fb, s, sync=False)
+    torch.cuda.synchronize()
+    assert torch.equal(ta, ta2) and torch.equal(tb, tb2)
+    other.close()
