@@ -850,18 +850,8 @@ extern "C" int gitmi_generate(gitmi_engine* e, const float* const* frames, int F
     if (sp->max_steps < P || sp->max_steps > c.max_text_len) return fail("generate: max_steps %d outside [P,%d]", sp->max_steps, c.max_text_len);
     hipStream_t s = (hipStream_t)stream;
 
-    // start tokens [B, P] on device (shared prefix, or [CLS])
-    std::vector<long long> start((size_t)B * P);
-    if (prefix) {
-        std::vector<long long> pf(P);
-        HIPCK(hipMemcpyAsync(pf.data(), prefix, (size_t)P * sizeof(long long), hipMemcpyDeviceToHost, s));
-        HIPCK(hipStreamSynchronize(s));
-        for (int b = 0; b < B; ++b) std::copy(pf.begin(), pf.end(), start.begin() + (size_t)b * P);
-    } else {
-        std::fill(start.begin(), start.end(), (long long)c.sos);
-    }
-    HIPCK(hipMemcpyAsync(e->start_dev, start.data(), start.size() * sizeof(long long), hipMemcpyHostToDevice, s));
-    HIPCK(hipStreamSynchronize(s));   // `start` is a stack-lifetime host buffer
+    // start tokens [B, P] on device (shared prefix, or [CLS]) -- filled by a kernel, no host copy
+    HIPCK(launch_fill_start(e->start_dev, (const long long*)prefix, c.sos, B, P, s));
 
     const bool long_budget = sp->max_steps - P > 32;
     const bool graph = e->use_graph && !e->profiling && !long_budget;

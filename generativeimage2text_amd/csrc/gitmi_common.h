@@ -10,16 +10,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 #define GITMI_WAVE 64
 
-// ---- bf16 <-> f32 (round-to-nearest-even; NaN kept quiet) --------------------------
+// ---- bf16 <-> f32: gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even, NaN-safe);
+// a (__bf16) cast is what makes hipcc emit it -- no branches, one instruction per pair
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 // ---- typed element access: T is float (exact path) or bf16_t (fast path) ----------
@@ -76,8 +77,35 @@ __device__ __forceinline__ float wave_max(float v) {
 #define GITMI_ACT_QUICKGELU 1   // x * sigmoid(1.702 x)            CLIP/model.py:171-173
 #define GITMI_ACT_GELU_ERF 2    // 0.5 x (1 + erf(x / sqrt 2))     bert/activations.py:15-22
 
+// v_exp_f32 / v_rcp_f32 directly (1 ulp class): expf()/division expand to ~20 instructions with branches
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+__device__ __forceinline__ float quick_gelu(float x) { return x * fast_rcp(1.0f + fast_exp(-1.702f * x)); }
+
+// erf via Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7), branch-free:
+//   erf(z) = sign(z) * (1 - (a1 t + a2 t^2 + a3 t^3 + a4 t^4 + a5 t^5) exp(-z^2)),  t = 1 / (1 + p |z|)
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = x * 0.70710678118654752440f;
+    const float az = fabsf(z);
+    const float t = fast_rcp(1.0f + 0.3275911f * az);
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    poly *= t;
+    const float e = 1.0f - poly * fast_exp(-az * az);
+    return 0.5f * x * (1.0f + copysignf(e, z));
+}
+
+template <int ACT> __device__ __forceinline__ float apply_act_t(float x) {
+    if constexpr (ACT == GITMI_ACT_QUICKGELU) return quick_gelu(x);
+    else if constexpr (ACT == GITMI_ACT_GELU_ERF) return gelu_erf(x);
+    else return x;
+}
 __device__ __forceinline__ float apply_act(float x, int act) {
-    if (act == GITMI_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
-    if (act == GITMI_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    if (act == GITMI_ACT_QUICKGELU) return quick_gelu(x);
+    if (act == GITMI_ACT_GELU_ERF) return gelu_erf(x);
     return x;
 }

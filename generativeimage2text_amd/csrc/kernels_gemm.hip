@@ -204,9 +204,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             const bool full = n + 3 < g.N;
             float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
             if (g.bias) {
+                if (full) {   // unguarded loads: hipcc keeps them in flight together
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (full || n + r < g.N) v[r] += g.bias[n + r];
+                    for (int r = 0; r < 4; ++r) v[r] += g.bias[n + r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) v[r] += g.bias[n + r];
+                }
             }
             if (g.act != GITMI_ACT_NONE) {
 #pragma unroll
@@ -257,10 +262,16 @@ static hipError_t launch_gemm_tiles(const GemmArgs& g, hipStream_t s) {
 }
 
 static int g_gemm_impl = -1;
-void set_gemm_impl(int impl) { g_gemm_impl = impl; }
+static int g_gemm_dbg = 0;
+void set_gemm_impl(int impl) {
+    if (impl >= 0) { g_gemm_dbg = impl >> 8; impl &= 0xff; } else g_gemm_dbg = 0;
+    g_gemm_impl = impl;
+}
 
 // in_f32/out_f32: element types of A,W and of C
-hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t s) {
+hipError_t launch_gemm(const GemmArgs& g_in, bool in_f32, bool out_f32, hipStream_t s) {
+    GemmArgs g = g_in;
+    g.dbg = g_gemm_dbg;
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     // impl: -1 auto | 0 first generation | 1 direct-to-LDS 128x128 | 2 256x128 3-stage ring
     if (g_gemm_impl != 0 && gemm_dlds_supported(g, in_f32, out_f32)) {

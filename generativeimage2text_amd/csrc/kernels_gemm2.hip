@@ -128,10 +128,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dlds_kernel(GemmArgs g) {
             for (int j = 0; j < 4; ++j) {
                 const int nl = wn * 64 + j * 16 + lg * 4;           // column inside the tile
                 float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (g.bias) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n0 + nl + r < g.N) bv[r] = g.bias[n0 + nl + r];
+                if (g.bias && n0 + nl + 3 < g.N) {      // N % 8 == 0: one unconditional 16-byte load
+                    const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(g.bias + n0 + nl);
+                    bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {

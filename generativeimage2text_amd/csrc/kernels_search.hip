@@ -372,7 +372,19 @@ __global__ void load_ids_kernel(const long long* __restrict__ tokens, int R, int
     }
 }
 
+// start tokens [B,P]: the shared prefix (device pointer) or [CLS] (decoder.py:979-989) -- no host round trip
+__global__ void fill_start_kernel(long long* __restrict__ start, const long long* __restrict__ prefix, int sos, int B,
+                                  int P) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * P; i += gridDim.x * blockDim.x)
+        start[i] = prefix ? prefix[i % P] : (long long)sos;
+}
+
 // ---- host launchers ------------------------------------------------------------------
+hipError_t launch_fill_start(long long* start, const long long* prefix, int sos, int B, int P, hipStream_t s) {
+    hipLaunchKernelGGL(fill_start_kernel, dim3(8), dim3(256), 0, s, start, prefix, sos, B, P);
+    return hipGetLastError();
+}
+
 hipError_t launch_load_ids(const long long* tokens, int R, int t, int* ids, int* kv_src, int ld, hipStream_t s) {
     hipLaunchKernelGGL(load_ids_kernel, dim3(64), dim3(256), 0, s, tokens, R, t, ids, kv_src, ld);
     return hipGetLastError();

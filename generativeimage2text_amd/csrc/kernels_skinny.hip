@@ -128,18 +128,28 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs g) {
         }
         const bool full = n + 3 < g.N;
         if (g.bias) {
+            if (full) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (full || n + r < g.N) v[r] += g.bias[n + r];
+                for (int r = 0; r < 4; ++r) v[r] += g.bias[n + r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < g.N) v[r] += g.bias[n + r];
+            }
         }
         if (g.act != GITMI_ACT_NONE) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], g.act);
         }
         if (g.res) {
+            if (full) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (full || n + r < g.N) v[r] += g.res[(size_t)m * g.ldr + n + r];
+                for (int r = 0; r < 4; ++r) v[r] += g.res[(size_t)m * g.ldr + n + r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < g.N) v[r] += g.res[(size_t)m * g.ldr + n + r];
+            }
         }
         TOut* cp = reinterpret_cast<TOut*>(g.C) + (size_t)m * g.ldc + n;
         if (full && (g.ldc & 3) == 0) sk_store4<TOut>(cp, v);

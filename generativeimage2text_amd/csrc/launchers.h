@@ -11,6 +11,7 @@ struct GemmArgs {
     int lda, ldc, ldr;
     int act;
     int tiles_n, nwg;
+    int dbg;    // timing experiments only (gemm_ring_kernel): 1 no C stores, 2 no epilogue, 4 no MFMA, 8 no loads in loop
 };
 hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t s);
 // second-generation bf16 kernel (direct-to-LDS staging, swizzled LDS, LDS-staged epilogue)
@@ -89,6 +90,7 @@ hipError_t launch_search_init(const SearchState& st, const long long* start_dev,
 hipError_t launch_search_finish(const SearchState& st, int cur, int cur_len, long long* tokens_out,
                                 float* logprob_out, int* info_out, hipStream_t s);
 hipError_t launch_search_rows(const SearchState& st, int cur, int cur_len, long long* out, hipStream_t s);
+hipError_t launch_fill_start(long long* start, const long long* prefix, int sos, int B, int P, hipStream_t s);
 hipError_t launch_load_ids(const long long* tokens, int R, int t, int* ids, int* kv_src, int ld, hipStream_t s);
 
 }  // namespace gitmi
