@@ -275,6 +275,8 @@ hipError_t launch_gemm(const GemmArgs& g_in, bool in_f32, bool out_f32, hipStrea
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     // impl: -1 auto | 0 first generation | 1 direct-to-LDS 128x128 | 2 256x128 3-stage ring
     if (g_gemm_impl != 0 && gemm_dlds_supported(g, in_f32, out_f32)) {
+        if (g_gemm_impl == 3) return launch_gemm_pring(g, out_f32, s);
+        if (g_gemm_impl == 4) return launch_gemm_ring32(g, out_f32, s);
         if (g_gemm_impl == 2 || (g_gemm_impl == -1 && g.M > 512)) return launch_gemm_ring(g, out_f32, s);
         if (g_gemm_impl == 1 || (g_gemm_impl == -1 && g.M > 256)) return launch_gemm_dlds(g, out_f32, s);
     }

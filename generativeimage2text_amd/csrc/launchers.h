@@ -18,6 +18,8 @@ hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t
 bool gemm_dlds_supported(const GemmArgs& g, bool in_f32, bool out_f32);
 hipError_t launch_gemm_dlds(GemmArgs g, bool out_f32, hipStream_t s);
 hipError_t launch_gemm_ring(GemmArgs g, bool out_f32, hipStream_t s);   // 256x128 tile, 3-stage ring
+hipError_t launch_gemm_pring(GemmArgs g, bool out_f32, hipStream_t s);  // persistent ring (one workgroup per CU)
+hipError_t launch_gemm_ring32(GemmArgs g, bool out_f32, hipStream_t s); // 256x128x32, 72 KiB ring, 2 workgroups/CU
 void set_gemm_impl(int impl);   // -1 auto, 0 first-generation kernel only, 1 force direct-to-LDS kernel
 
 // weight-streaming GEMM for decode (bf16 operands): C or fp32 partial slabs [S][M][N]
