@@ -11,6 +11,7 @@ struct GemmArgs {
     int lda, ldc, ldr;
     int act;
     int tiles_n, nwg;
+    int ng;     // XCD tile partition: N split into ng groups, M into 8/ng (kernels_gemm3.hip)
     int dbg;    // timing experiments only (gemm_ring_kernel): 1 no C stores, 2 no epilogue, 4 no MFMA, 8 no loads in loop
 };
 hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t s);
@@ -20,6 +21,8 @@ hipError_t launch_gemm_dlds(GemmArgs g, bool out_f32, hipStream_t s);
 hipError_t launch_gemm_ring(GemmArgs g, bool out_f32, hipStream_t s);   // 256x128 tile, 3-stage ring
 hipError_t launch_gemm_pring(GemmArgs g, bool out_f32, hipStream_t s);  // persistent ring (one workgroup per CU)
 hipError_t launch_gemm_ring32(GemmArgs g, bool out_f32, hipStream_t s); // 256x128x32, 72 KiB ring, 2 workgroups/CU
+hipError_t launch_gemm_ring32w(GemmArgs g, bool out_f32, hipStream_t s); // 256x128x32, 4 waves of 128x64, 2 workgroups/CU
+hipError_t launch_gemm_ring256(GemmArgs g, bool out_f32, hipStream_t s); // 256x256x32, 8 waves of 128x64, 4-stage ring
 void set_gemm_impl(int impl);   // -1 auto, 0 first-generation kernel only, 1 force direct-to-LDS kernel
 
 // weight-streaming GEMM for decode (bf16 operands): C or fp32 partial slabs [S][M][N]
