@@ -100,7 +100,8 @@ struct gitmi_engine {
     // prefill workspaces
     float *p_y = nullptr, *p_hf = nullptr;
     void *p_ht = nullptr, *p_ctx = nullptr, *p_u = nullptr;
-    std::vector<void*> img_kv;      // per layer [B*N_img, 3d]
+    std::vector<void*> img_kv;      // per layer [B*N_img, 3d] (prefill layout)
+    std::vector<void*> img_kh, img_vh;   // per layer head-major [B][H][N_img][64] (decode layout)
     // decode workspaces
     float *d_y = nullptr, *d_hf = nullptr, *logits = nullptr;
     void *d_ht = nullptr, *d_qkv = nullptr, *d_ctx = nullptr, *d_u = nullptr;
@@ -365,10 +366,14 @@ static int alloc_workspaces(gitmi_engine* e) {
     RCK(dev_alloc(e, &e->p_ctx, Mp * d * esz));
     RCK(dev_alloc(e, &e->p_u, Mp * c.dec_ffn * esz));
     e->img_kv.resize(c.dec_layers);
+    e->img_kh.resize(c.dec_layers);
+    e->img_vh.resize(c.dec_layers);
     e->txt_k.resize(c.dec_layers);
     e->txt_v.resize(c.dec_layers);
     for (int l = 0; l < c.dec_layers; ++l) {
         RCK(dev_alloc(e, &e->img_kv[l], Mp * 3 * d * esz));
+        RCK(dev_alloc(e, &e->img_kh[l], Mp * d * esz));
+        RCK(dev_alloc(e, &e->img_vh[l], Mp * d * esz));
         RCK(dev_alloc(e, &e->txt_k[l], R * T * d * esz));
         RCK(dev_alloc(e, &e->txt_v[l], R * T * d * esz));
     }
@@ -577,10 +582,12 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
         const bool last = l + 1 == c.dec_layers;
         if (!last) {
             RCK(gemm(e, s, e->p_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->img_kv[l], 3 * d, e->f32, M, 3 * d, d, 0, TAG_GEMM_OTHER));
+            HIPCK(launch_kv_repack(e->img_kv[l], e->img_kh[l], e->img_vh[l], B, Nimg, c.dec_heads, d, e->f32, s));
         } else {
             // the last layer's image-row outputs are never consumed: only its K and V are needed
             RCK(gemm(e, s, e->p_ht, d, (char*)L.wqkv + (size_t)d * d * e->esz, L.bqkv + d, nullptr, 0,
                      (char*)e->img_kv[l] + (size_t)d * e->esz, 3 * d, e->f32, M, 2 * d, d, 0, TAG_GEMM_OTHER));
+            HIPCK(launch_kv_repack(e->img_kv[l], e->img_kh[l], e->img_vh[l], B, Nimg, c.dec_heads, d, e->f32, s));
             break;
         }
         AttnFullArgs a{};
@@ -650,7 +657,7 @@ static int decode_step_impl(gitmi_engine* e, const int* ids, const int* kv_src, 
         if (sk) RCK(skinny(e, s, e->d_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->d_qkv, 3 * d, false, R, 3 * d, d, 0, 1));
         else RCK(gemm(e, s, e->d_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->d_qkv, 3 * d, e->f32, R, 3 * d, d, 0, TAG_GEMM_OTHER));
         AttnDecodeArgs a{};
-        a.qkv = e->d_qkv; a.img_kv = e->img_kv[l]; a.txt_k = e->txt_k[l]; a.txt_v = e->txt_v[l]; a.out = e->d_ctx;
+        a.qkv = e->d_qkv; a.img_k = e->img_kh[l]; a.img_v = e->img_vh[l]; a.txt_k = e->txt_k[l]; a.txt_v = e->txt_v[l]; a.out = e->d_ctx;
         a.kv_src = kv_src; a.ld_src = ld_ids; a.d = d; a.N_img = e->cur_Nimg; a.T_max = c.max_text_len;
         a.pos = pos; a.beams = beams; a.scale = 0.125f;
         HIPCK(launch_attn_decode(a, B, c.dec_heads, e->f32, s));

@@ -253,6 +253,29 @@ __global__ __launch_bounds__(256) void attn_full_mfma_kernel(AttnFullArgs a) {
 //   out      : [R, d]
 // dynamic LDS: scores[k][Nk] + q[k][64] + red[32][k][64]   (Nk = N_img + pos + 1)
 // ---------------------------------------------------------------------------------------
+// Image K/V cache in HEAD-MAJOR layout: kh/vh[b][h][n][64].  The prefill GEMM writes q|k|v token-major
+// ([B*N, 3d], what the prefill attention wants); a decode workgroup (image b, head h) would then touch one
+// 128-byte slice per 4.6-KB token row -- a new DRAM page per access (measured 2.4 TB/s).  Repacked once per
+// generate, every decode step streams two contiguous 25-KB runs per workgroup instead.
+template <typename T>
+__global__ void kv_repack_kernel(const T* __restrict__ qkv, T* __restrict__ kh, T* __restrict__ vh, int B, int N, int H,
+                                 int d) {
+    constexpr int CH = 16 / (int)sizeof(T);                // elements per 16-byte chunk
+    constexpr int CPH = HD / CH;                           // chunks per head row (8 bf16 / 16 f32)
+    const size_t per = (size_t)B * H * N * CPH;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < 2 * per; i += (size_t)gridDim.x * blockDim.x) {
+        const int kv = i >= per;
+        size_t r = kv ? i - per : i;
+        const int c = (int)(r % CPH); r /= CPH;
+        const int n = (int)(r % N); r /= N;
+        const int h = (int)(r % H);
+        const int b = (int)(r / H);
+        const T* src = qkv + ((size_t)b * N + n) * 3 * d + (kv ? 2 : 1) * d + h * HD + c * CH;
+        T* dst = (kv ? vh : kh) + (((size_t)b * H + h) * N + n) * HD + c * CH;
+        *reinterpret_cast<u32x4_t*>(dst) = *reinterpret_cast<const u32x4_t*>(src);
+    }
+}
+
 // 16 bytes-or-32 of one key/value row slice kept raw in registers until it is consumed
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> {
@@ -292,7 +315,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     float* red = qs + k * HD;               // [32][k][64]
 
     const T* QKV = reinterpret_cast<const T*>(a.qkv);
-    const T* IMG = reinterpret_cast<const T*>(a.img_kv);
+    const T* IMGK = reinterpret_cast<const T*>(a.img_k);
+    const T* IMGV = reinterpret_cast<const T*>(a.img_v);
     T* TK = reinterpret_cast<T*>(a.txt_k);
     T* TV = reinterpret_cast<T*>(a.txt_v);
     T* O = reinterpret_cast<T*>(a.out);
@@ -300,16 +324,43 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     const int row0 = b * k;
     const int grp = tid >> 3, sub = tid & 7;    // 32 groups of 8 lanes; a group reads one 64-dim row
     constexpr int PF = 8;                       // image keys per group kept in flight (covers N_img <= 256)
+    constexpr int TI = 5;                       // text (beam, position) items per group: k*(pos+1) <= 160
 
-    // image K rows of the first chunk: issued before anything else so HBM latency overlaps the q staging
-    const T* kbase = IMG + (size_t)b * a.N_img * ld3 + a.d + h * HD + sub * 8;
-    const T* vbase = kbase + a.d;
-    Raw8<T> kr[PF];
+    // ---- every global load of the step is issued up front: the kernel is one dependent-latency chain
+    // per workgroup (all workgroups are co-resident), so round trips must overlap, not follow each other
+    const int H = gridDim.x;
+    const T* kbase = IMGK + ((size_t)b * H + h) * a.N_img * HD + sub * 8;   // head-major: contiguous per (b, h)
+    const T* vbase = IMGV + ((size_t)b * H + h) * a.N_img * HD + sub * 8;
+    const int nt = a.pos + 1;
+    // text items of this group: (beam j, position s) -> cache row through the beam indirection
+    int t_j[TI], t_s[TI], t_row[TI];
+#pragma unroll
+    for (int u = 0; u < TI; ++u) {
+        const int it = grp + 32 * u;
+        t_j[u] = it < k * nt ? it / nt : -1;
+        t_s[u] = it < k * nt ? it % nt : 0;
+        t_row[u] = (t_j[u] >= 0 && t_s[u] != a.pos) ? a.kv_src[(size_t)(row0 + t_j[u]) * a.ld_src + t_s[u]] : 0;
+    }
+    Raw8<T> kr[PF], vr[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int n = grp + 32 * u;
-        if (n < a.N_img) kr[u].load(kbase + (size_t)n * ld3);
-        else kr[u].zero();
+        if (n < a.N_img) { kr[u].load(kbase + (size_t)n * HD); vr[u].load(vbase + (size_t)n * HD); }
+        else { kr[u].zero(); vr[u].zero(); }
+    }
+    Raw8<T> tk[TI], tv[TI];
+#pragma unroll
+    for (int u = 0; u < TI; ++u) {
+        if (t_j[u] < 0) { tk[u].zero(); tv[u].zero(); }
+        else if (t_s[u] == a.pos) {
+            const T* src = QKV + (size_t)(row0 + t_j[u]) * ld3 + a.d + h * HD + sub * 8;
+            tk[u].load(src);
+            tv[u].load(src + a.d);
+        } else {
+            const size_t off = ((size_t)t_row[u] * a.T_max + t_s[u]) * a.d + h * HD + sub * 8;
+            tk[u].load(TK + off);
+            tv[u].load(TV + off);
+        }
     }
 
     // stage q (scaled) and append this position's K/V of every beam to the text cache
@@ -329,7 +380,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int n = base + grp + 32 * u;
-                if (n < a.N_img) kr[u].load(kbase + (size_t)n * ld3);
+                if (n < a.N_img) kr[u].load(kbase + (size_t)n * HD);
                 else kr[u].zero();
             }
         }
@@ -349,17 +400,23 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
             }
         }
     }
-    // image V rows of the first chunk: in flight across the softmax
-    Raw8<T> vr[PF];
+    // ---- scores over text keys ------------------------------------------------------------
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int n = grp + 32 * u;
-        if (n < a.N_img) vr[u].load(vbase + (size_t)n * ld3);
-        else vr[u].zero();
+    for (int u = 0; u < TI; ++u) {
+        if (t_j[u] >= 0) {                        // uniform within the 8-lane group
+            float kv[8];
+            tk[u].get(kv);
+            float p = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) p += qs[t_j[u] * HD + sub * 8 + e] * kv[e];
+            p += __shfl_xor(p, 1, 64);
+            p += __shfl_xor(p, 2, 64);
+            p += __shfl_xor(p, 4, 64);
+            if (sub == 0) sc[(size_t)t_j[u] * Nk + a.N_img + t_s[u]] = p;
+        }
     }
-    // ---- scores over text keys (per beam, through the indirection) ---------------------
-    const int nt = a.pos + 1;
-    for (int it = grp; it < k * nt; it += 32) {
+    // long texts (k * (pos+1) > 32*TI): the remaining items take the slow, dependent-load path
+    for (int it = grp + 32 * TI; it < k * nt; it += 32) {
         const int j = it / nt, s = it % nt;
         float kv[8];
         if (s == a.pos) {
@@ -387,7 +444,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
         mx = wave_max(mx);
         float sum = 0.f;
         for (int n = lane; n < Nk; n += 64) {
-            const float p = __expf(row[n] - mx);
+            const float p = fast_exp(row[n] - mx);
             row[n] = p;
             sum += p;
         }
@@ -410,7 +467,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int n = base + grp + 32 * u;
-                if (n < a.N_img) vr[u].load(vbase + (size_t)n * ld3);
+                if (n < a.N_img) vr[u].load(vbase + (size_t)n * HD);
                 else vr[u].zero();
             }
         }
@@ -431,7 +488,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
             }
         }
     }
-    for (int it = grp; it < k * nt; it += 32) {
+#pragma unroll
+    for (int u = 0; u < TI; ++u) {
+        if (t_j[u] >= 0) {
+            float vv[8];
+            tv[u].get(vv);
+            const float p = sc[(size_t)t_j[u] * Nk + a.N_img + t_s[u]];
+#pragma unroll
+            for (int jj = 0; jj < KMAX; ++jj) {
+                if (jj == t_j[u]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[jj][e] += p * vv[e];
+                }
+            }
+        }
+    }
+    for (int it = grp + 32 * TI; it < k * nt; it += 32) {
         const int j = it / nt, s = it % nt;
         float vv[8];
         if (s == a.pos) {
@@ -483,6 +555,18 @@ hipError_t launch_attn_full(const AttnFullArgs& a, int B, bool is_f32, int impl,
 size_t attn_decode_lds_bytes(int beams, int N_img, int pos) {
     const size_t Nk = (size_t)N_img + pos + 1;
     return sizeof(float) * ((size_t)beams * Nk + (size_t)beams * HD + (size_t)32 * beams * HD);
+}
+
+hipError_t launch_kv_repack(const void* qkv, void* kh, void* vh, int B, int N, int H, int d, bool is_f32, hipStream_t s) {
+    if (B <= 0 || N <= 0) return hipSuccess;
+    const size_t total = 2 * (size_t)B * H * N * (is_f32 ? 16 : 8);
+    size_t grid = (total + 255) / 256;
+    grid = grid > 8192 ? 8192 : grid;
+    if (is_f32) hipLaunchKernelGGL(kv_repack_kernel<float>, dim3((int)grid), dim3(256), 0, s, (const float*)qkv, (float*)kh,
+                                   (float*)vh, B, N, H, d);
+    else hipLaunchKernelGGL(kv_repack_kernel<bf16_t>, dim3((int)grid), dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)kh,
+                            (bf16_t*)vh, B, N, H, d);
+    return hipGetLastError();
 }
 
 hipError_t attn_decode_configure() {

@@ -31,36 +31,57 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         TOut* __restrict__ y_t, int ld_t,
                                                         float* __restrict__ y_f, int ld_f, int rows, int D,
                                                         RowMap map) {
+    // one wave per row, 16-byte accesses: lane handles columns (lane + 64*i)*4 .. +4  (D % 4 == 0, D <= 1024)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (size_t)row * ldx;
-    float v[LN_MAXV];
+    constexpr int NV = LN_MAXV / 4;
+    f32x4_t v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = c < D ? xr[c] : 0.f;
-        s += v[i];
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        v[i] = c < D ? *reinterpret_cast<const f32x4_t*>(xr + c) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        const float d = c < D ? v[i] - mean : 0.f;
-        q += d * d;
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = v[i][r] - mean; q += d * d; }
+        }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
     const size_t orow = map_row(map, row);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
         if (c < D) {
-            float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
-            if (add_after) o += add_after[c];
-            if (y_t) st<TOut>(y_t + orow * ld_t + c, o);
-            if (y_f) y_f[orow * ld_f + c] = o;
+            const f32x4_t g4 = *reinterpret_cast<const f32x4_t*>(gamma + c);
+            const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(beta + c);
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (v[i][r] - mean) * rstd * g4[r] + b4[r];
+            if (add_after) {
+                const f32x4_t a4 = *reinterpret_cast<const f32x4_t*>(add_after + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] += a4[r];
+            }
+            if (y_t) {
+                if constexpr (sizeof(TOut) == 4) {
+                    *reinterpret_cast<f32x4_t*>(y_t + orow * ld_t + c) = f32x4_t{o[0], o[1], o[2], o[3]};
+                } else {
+                    uint2 t;
+                    t.x = pack2bf(o[0], o[1]);
+                    t.y = pack2bf(o[2], o[3]);
+                    *reinterpret_cast<uint2*>(y_t + orow * ld_t + c) = t;
+                }
+            }
+            if (y_f) *reinterpret_cast<f32x4_t*>(y_f + orow * ld_f + c) = f32x4_t{o[0], o[1], o[2], o[3]};
         }
     }
 }
@@ -196,7 +217,7 @@ hipError_t launch_layernorm(const float* x, int ldx, const float* gamma, const f
                             const float* add_after, void* y_t, int ld_t, bool t_is_f32, float* y_f, int ld_f,
                             int rows, int D, int map_n_in, int map_n_out, int map_off, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
-    if (D > 64 * LN_MAXV) return hipErrorInvalidValue;
+    if (D > 64 * LN_MAXV || (D & 3) || (ldx & 3) || (ld_t & 3) || (y_f && (ld_f & 3))) return hipErrorInvalidValue;
     RowMap m{map_n_in > 0 ? map_n_in : rows, map_n_in > 0 ? map_n_out : rows, map_off};
     dim3 grid((rows + 3) / 4), block(256);
     if (t_is_f32)

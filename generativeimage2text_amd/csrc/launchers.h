@@ -60,13 +60,14 @@ struct AttnFullArgs {
 hipError_t launch_attn_full(const AttnFullArgs& a, int B, bool is_f32, int impl, hipStream_t s);
 
 struct AttnDecodeArgs {
-    const void* qkv; const void* img_kv; void* txt_k; void* txt_v; void* out;
+    const void* qkv; const void* img_k; const void* img_v; void* txt_k; void* txt_v; void* out;   // img_k/v head-major [B][H][N_img][64]
     const int* kv_src;
     int ld_src;
     int d;
     int N_img, T_max, pos, beams;
     float scale;
 };
+hipError_t launch_kv_repack(const void* qkv, void* kh, void* vh, int B, int N, int H, int d, bool is_f32, hipStream_t s);
 size_t attn_decode_lds_bytes(int beams, int N_img, int pos);
 hipError_t launch_attn_decode(const AttnDecodeArgs& a, int B, int H, bool is_f32, hipStream_t s);
 hipError_t attn_decode_configure();
