@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __res
     }
 }
 
-// x = words[ids[r, pos]] + positions[pos];  LayerNorm(eps);  -> fp32 hidden + compute-dtype hidden
+// x = words[ids[r, pos]] + positions[pos];  LayerNorm(eps);  -> fp32 hidden + compute-dtype hidden.
+// One 256-thread workgroup per row, one float4 per thread (D <= 1024, D % 4 == 0): a single round of loads.
 template <typename TOut>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, int ld_ids, int pos,
                                                        const float* __restrict__ words,
@@ -151,37 +152,47 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
                                                        const float* __restrict__ beta, float eps,
                                                        float* __restrict__ h_f, TOut* __restrict__ h_t, int R,
                                                        int D, int vocab) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= R) return;
+    __shared__ float s_part[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x;
     int tok = ids[(size_t)row * ld_ids + pos];
     tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
-    const float* wr = words + (size_t)tok * D;
-    const float* pr = positions + (size_t)pos * D;
-    float v[LN_MAXV];
-    float s = 0.f;
+    const int c = tid * 4;
+    const bool on = c < D;
+    f32x4_t a = {0.f, 0.f, 0.f, 0.f}, g4 = a, b4 = a;
+    if (on) {
+        const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(words + (size_t)tok * D + c);
+        const f32x4_t p4 = *reinterpret_cast<const f32x4_t*>(positions + (size_t)pos * D + c);
+        g4 = *reinterpret_cast<const f32x4_t*>(gamma + c);
+        b4 = *reinterpret_cast<const f32x4_t*>(beta + c);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = c < D ? wr[c] + pr[c] : 0.f;
-        s += v[i];
+        for (int r = 0; r < 4; ++r) a[r] = w4[r] + p4[r];
     }
-    const float mean = wave_sum(s) / (float)D;
+    float sum = wave_sum(a[0] + a[1] + a[2] + a[3]);
+    if (lane == 0) s_part[wave] = sum;
+    __syncthreads();
+    const float mean = (s_part[0] + s_part[1] + s_part[2] + s_part[3]) / (float)D;
     float q = 0.f;
+    if (on) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        const float d = c < D ? v[i] - mean : 0.f;
-        q += d * d;
+        for (int r = 0; r < 4; ++r) { const float d = a[r] - mean; q += d * d; }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    q = wave_sum(q);
+    if (lane == 0) s_part[4 + wave] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((s_part[4] + s_part[5] + s_part[6] + s_part[7]) / (float)D + eps);
+    if (on) {
+        float o[4];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < D) {
-            const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
-            h_f[(size_t)row * D + c] = o;
-            st<TOut>(h_t + (size_t)row * D + c, o);
+        for (int r = 0; r < 4; ++r) o[r] = (a[r] - mean) * rstd * g4[r] + b4[r];
+        *reinterpret_cast<f32x4_t*>(h_f + (size_t)row * D + c) = f32x4_t{o[0], o[1], o[2], o[3]};
+        if constexpr (sizeof(TOut) == 4) {
+            *reinterpret_cast<f32x4_t*>(h_t + (size_t)row * D + c) = f32x4_t{o[0], o[1], o[2], o[3]};
+        } else {
+            uint2 t;
+            t.x = pack2bf(o[0], o[1]);
+            t.y = pack2bf(o[2], o[3]);
+            *reinterpret_cast<uint2*>(h_t + (size_t)row * D + c) = t;
         }
     }
 }
@@ -253,8 +264,8 @@ hipError_t launch_vit_assemble_ln(const float* patch_out, const float* cls, cons
 hipError_t launch_embed_ln(const int* ids, int ld_ids, int pos, const float* words, const float* positions,
                            const float* gamma, const float* beta, float eps, float* h_f, void* h_t, bool t_is_f32,
                            int R, int D, int vocab, hipStream_t s) {
-    if (D > 64 * LN_MAXV) return hipErrorInvalidValue;
-    dim3 grid((R + 3) / 4), block(256);
+    if (D > 1024 || (D & 3)) return hipErrorInvalidValue;
+    dim3 grid(R), block(256);
     if (t_is_f32)
         hipLaunchKernelGGL(embed_ln_kernel<float>, grid, block, 0, s, ids, ld_ids, pos, words, positions, gamma,
                            beta, eps, h_f, (float*)h_t, R, D, vocab);

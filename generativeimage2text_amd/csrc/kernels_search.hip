@@ -23,15 +23,16 @@
 namespace gitmi {
 
 // ---------------------------------------------------------------------------------------
-template <int MMAX>
-__global__ __launch_bounds__(256) void row_topm_kernel(const float* __restrict__ logits, int ldl, int V,
+template <int MMAX, int NT>
+__global__ __launch_bounds__(NT) void row_topm_kernel(const float* __restrict__ logits, int ldl, int V,
                                                        const int* __restrict__ ids, int ld_ids, int cur_len,
                                                        int eos, int suppress_last, int force_eos, int M,
                                                        float* __restrict__ cand_val, int* __restrict__ cand_idx) {
-    __shared__ float s_val[256 * MMAX];
-    __shared__ int s_idx[256 * MMAX];
-    __shared__ float s_red[8];
-    __shared__ int s_redi[8];
+    constexpr int NW = NT / 64;
+    __shared__ float s_val[NT * MMAX];
+    __shared__ int s_idx[NT * MMAX];
+    __shared__ float s_red[2 * NW];
+    __shared__ int s_redi[2 * NW];
     __shared__ int s_owner;
 
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,36 +76,41 @@ __global__ __launch_bounds__(256) void row_topm_kernel(const float* __restrict__
         const int nchunk = V >> 2;
         const f32x4_t* x4 = reinterpret_cast<const f32x4_t*>(x);
         int c = tid;
-        for (; c + 3 * 256 < nchunk; c += 4 * 256) {
+        for (; c + 3 * NT < nchunk; c += 4 * NT) {
             f32x4_t q[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) q[u] = x4[c + u * 256];
+            for (int u = 0; u < 4; ++u) q[u] = x4[c + u * NT];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) feed(q[u][r], (c + u * 256) * 4 + r);
+                for (int r = 0; r < 4; ++r) feed(q[u][r], (c + u * NT) * 4 + r);
         }
-        for (; c < nchunk; c += 256) {
+        for (; c < nchunk; c += NT) {
             const f32x4_t q = x4[c];
 #pragma unroll
             for (int r = 0; r < 4; ++r) feed(q[r], c * 4 + r);
         }
-        for (int i = (nchunk << 2) + tid; i < V; i += 256) feed(x[i], i);
+        for (int i = (nchunk << 2) + tid; i < V; i += NT) feed(x[i], i);
     } else {
-        for (int i = tid; i < V; i += 256) feed(x[i], i);
+        for (int i = tid; i < V; i += NT) feed(x[i], i);
     }
     // block log-sum-exp
     float bmx = wave_max(mx);
     if (lane == 0) s_red[wave] = bmx;
     __syncthreads();
-    bmx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    bmx = s_red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) bmx = fmaxf(bmx, s_red[w]);
     float part = mx == -INFINITY ? 0.f : sm * __expf(mx - bmx);
     part = wave_sum(part);
-    if (lane == 0) s_red[4 + wave] = part;
+    if (lane == 0) s_red[NW + wave] = part;
 #pragma unroll
     for (int j = 0; j < MMAX; ++j) { s_val[tid * MMAX + j] = tv[j]; s_idx[tid * MMAX + j] = ti[j]; }
     __syncthreads();
-    const float lse = bmx + logf(s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += s_red[NW + w];
+    const float lse = bmx + logf(tot);
     __syncthreads();
 
     // M rounds of block arg-max over the heads of the 256 sorted per-thread lists
@@ -120,13 +126,13 @@ __global__ __launch_bounds__(256) void row_topm_kernel(const float* __restrict__
             const int ow = __shfl_xor(who, o, 64);
             if (ov > v || (ov == v && oi < id)) { v = ov; id = oi; who = ow; }
         }
-        if (lane == 0) { s_red[wave] = v; s_redi[wave] = id; s_redi[4 + wave] = who; }
+        if (lane == 0) { s_red[wave] = v; s_redi[wave] = id; s_redi[NW + wave] = who; }
         __syncthreads();
         if (tid == 0) {
-            float bv = s_red[0]; int bi = s_redi[0], bw = s_redi[4];
+            float bv = s_red[0]; int bi = s_redi[0], bw = s_redi[NW];
 #pragma unroll
-            for (int w = 1; w < 4; ++w)
-                if (s_red[w] > bv || (s_red[w] == bv && s_redi[w] < bi)) { bv = s_red[w]; bi = s_redi[w]; bw = s_redi[4 + w]; }
+            for (int w = 1; w < NW; ++w)
+                if (s_red[w] > bv || (s_red[w] == bv && s_redi[w] < bi)) { bv = s_red[w]; bi = s_redi[w]; bw = s_redi[NW + w]; }
             cv[round] = bv - lse;
             ci[round] = bi == 0x7fffffff ? 0 : bi;
             s_owner = bw;
@@ -394,14 +400,15 @@ hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, 
                            int suppress_last, int force_eos, int M, int R, float* cand_val, int* cand_idx,
                            hipStream_t s) {
     if (M < 1 || M > 16) return hipErrorInvalidValue;
-#define GITMI_TOPM(MM)                                                                                          \
-    hipLaunchKernelGGL(row_topm_kernel<MM>, dim3(R), dim3(256), 0, s, logits, ldl, V, ids, ld_ids, cur_len, eos, \
+    // one workgroup per row; more threads per row when the per-thread candidate list is short (LDS: NT*MMAX*8 B)
+#define GITMI_TOPM(MM, NTT)                                                                                         \
+    hipLaunchKernelGGL((row_topm_kernel<MM, NTT>), dim3(R), dim3(NTT), 0, s, logits, ldl, V, ids, ld_ids, cur_len, eos, \
                        suppress_last, force_eos, M, cand_val, cand_idx)
-    if (M <= 1) GITMI_TOPM(1);
-    else if (M <= 2) GITMI_TOPM(2);
-    else if (M <= 4) GITMI_TOPM(4);
-    else if (M <= 8) GITMI_TOPM(8);
-    else GITMI_TOPM(16);
+    if (M <= 1) GITMI_TOPM(1, 1024);
+    else if (M <= 2) GITMI_TOPM(2, 1024);
+    else if (M <= 4) GITMI_TOPM(4, 1024);
+    else if (M <= 8) GITMI_TOPM(8, 512);
+    else GITMI_TOPM(16, 256);
 #undef GITMI_TOPM
     return hipGetLastError();
 }
