@@ -74,6 +74,30 @@ def cpu_baseline(sample_batch: int, max_steps: int, threads: int = 0):
                       f"(reference semantics), {dt:.1f}s wall on {threads} threads"}
 
 
+def pmc_traffic(kernel_substr: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/*pmc_summary.tsv; FETCH_SIZE and WRITE_SIZE collected in separate passes, KiB per dispatch;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).
+    PMC counters cannot be collected from inside this process, so the figure is the profiled one."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.tsv")))
+    if not files:
+        return None
+    rows = [l.rstrip("\n").split("\t") for l in open(files[-1]) if not l.startswith("#")]
+    hdr = rows[0]
+    if "FETCH_SIZE" not in hdr or "WRITE_SIZE" not in hdr:
+        return None
+    fi, wi = hdr.index("FETCH_SIZE"), hdr.index("WRITE_SIZE")
+    vals = []
+    for r in rows[1:]:
+        if kernel_substr in r[0] and r[fi] != "-" and r[wi] != "-":
+            vals.append((2.0 * float(r[fi]) + float(r[wi])) * 1024.0)
+    if not vals:
+        return None
+    return {"bytes_per_launch": sum(vals) / len(vals), "source": os.path.relpath(files[-1], ROOT),
+            "note": "2*FETCH_SIZE + WRITE_SIZE, averaged over the gemm_ring kernel variants"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,7 +110,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--frames", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4)
+    ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--contexts", type=int, default=4,
@@ -193,10 +217,13 @@ def main():
                       else "gitmi::gemm_kernel<f32>",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "traffic_detail": pmc_traffic("gemm_ring"),
             "launches_per_step": prof["vit_gemm_launches"], "avg_launch_ms": round(avg_ms, 4),
             "flops_per_launch": flops_per_launch,
             "method": "HIP events around each launch on the launch stream, eager (no graph) pass after the timed region",
         }
+        if result["roofline"]["traffic_detail"]:
+            result["roofline"]["traffic"] = round(result["roofline"]["traffic_detail"]["bytes_per_launch"])
         step_gbs = prof["decode_step_bytes"] / (prof["decode_step_ms"] * 1e-3) / 1e9 if prof["decode_step_ms"] > 0 else 0.0
         result["roofline_decode"] = {
             "bound": "hbm", "achieved": round(step_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",

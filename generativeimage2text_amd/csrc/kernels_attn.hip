@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void attn_full_valu_kernel(AttnFullArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// MFMA flash kernel (bf16).  Block = 4 waves, 64 query rows (16 per wave), key tiles of 64.
+// MFMA flash kernel (bf16).  Block = 4 waves, up to 256 query rows (4 tiles of 16 per wave), key tiles of 64.
 //   S^T[key][query] = K_tile . Q^T      (MFMA A = K rows from LDS, B = Q rows from registers)
 //   O^T[dim][query] += V^T_tile . P^T   (MFMA A = V^T rows from LDS, B = P^T from registers)
 // In both products the lane's column is its query (lane & 15), so row max / row sum / the
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void attn_full_valu_kernel(AttnFullArgs a) {
 // The 32-deep contraction of the second product enumerates keys in the order the first
 // product's accumulators already hold them: slot j<4 -> key 4g+j, slot j>=4 -> key 16+4g+(j-4)
 // (g = lane>>4) inside each 32-key half tile; V^T is read with the same permutation.
-// grid = (ceil(N/64), H, B)
+// grid = (ceil(N/256), H, B)
 // ---------------------------------------------------------------------------------------
 constexpr int FA_LDK = HD + 8;    // K tile row stride (bf16): 144 B, conflict-free b128 reads
 constexpr int FA_LDV = 64 + 8;    // V^T tile row stride (keys)
@@ -113,30 +113,36 @@ __global__ __launch_bounds__(256) void attn_full_mfma_kernel(AttnFullArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * FA_LDK];   // [key][dim]
     __shared__ __attribute__((aligned(16))) bf16_t Vt[HD * FA_LDV];   // [dim][key]
 
+    // One workgroup = up to 256 queries of one (image, head): wave w owns the 16-query tiles w, w+4, w+8, w+12
+    // of the chunk, so each 64-key K/V tile is fetched from HBM and transposed into LDS ONCE for all of them
+    // (a workgroup per 64 queries re-read K/V four times: measured 174 MB fetched for 77 MB of operands).
+    constexpr int QT = 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int qbase = blockIdx.x * 256;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q);
     const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k);
     const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v);
     bf16_t* O = reinterpret_cast<bf16_t*>(a.out);
     const size_t base_row = (size_t)b * a.N;
 
-    // Q^T operand (B of the first product): lane = query l15, dims lg*8 + 32*s .. +8
-    bf16x8_t qf[2];
-    {
-        int qr = q0 + l15;
+    // Q^T operands (B of the first product): lane = query l15, dims lg*8 + 32*s .. +8
+    bf16x8_t qf[QT][2];
+    f32x4_t o_acc[QT][4];   // O^T[dim = dt*16 + lg*4 + r][query = l15]
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        int qr = qbase + (t * 4 + wave) * 16 + l15;
         qr = qr < a.N ? qr : a.N - 1;
         const bf16_t* qp = Q + (base_row + qr) * a.ldq + h * HD + lg * 8;
-        qf[0] = *reinterpret_cast<const bf16x8_t*>(qp);
-        qf[1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
-    }
-
-    f32x4_t o_acc[4];   // O^T[dim = dt*16 + lg*4 + r][query = l15]
+        qf[t][0] = *reinterpret_cast<const bf16x8_t*>(qp);
+        qf[t][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o_acc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+        for (int dt = 0; dt < 4; ++dt) o_acc[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        m_run[t] = -INFINITY;
+        l_run[t] = 0.f;
+    }
 
     // cooperative tile load mapping: 64 rows x 8 chunks(16 B) = 512 chunks, 2 per thread
     const int ld_row = tid >> 3;          // 0..31 (+32)
@@ -160,99 +166,96 @@ __global__ __launch_bounds__(256) void attn_full_mfma_kernel(AttnFullArgs a) {
         }
         __syncthreads();
 
-        // ---- S^T tile: 4 key sub-tiles of 16 -------------------------------------------
-        f32x4_t s_acc[4];
 #pragma unroll
-        for (int st_ = 0; st_ < 4; ++st_) {
-            s_acc[st_] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < QT; ++t) {
+            if (qbase + (t * 4 + wave) * 16 >= a.N) continue;        // wave-uniform: this query tile is empty
+            // ---- S^T tile: 4 key sub-tiles of 16 ---------------------------------------
+            f32x4_t s_acc[4];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (st_ * 16 + l15) * FA_LDK + ks * 32 + lg * 8);
-                s_acc[st_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s_acc[st_], 0, 0, 0);
+            for (int st_ = 0; st_ < 4; ++st_) {
+                s_acc[st_] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (st_ * 16 + l15) * FA_LDK + ks * 32 + lg * 8);
+                    s_acc[st_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s_acc[st_], 0, 0, 0);
+                }
             }
-        }
-        // lane holds keys kt + st*16 + lg*4 + r for its query
-        float tmax = -INFINITY;
+            // lane holds keys kt + st*16 + lg*4 + r for its query
+            float tmax = -INFINITY;
 #pragma unroll
-        for (int st_ = 0; st_ < 4; ++st_)
+            for (int st_ = 0; st_ < 4; ++st_)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt + st_ * 16 + lg * 4 + r;
-                const float sv = key < a.N ? s_acc[st_][r] * a.scale : -INFINITY;
-                s_acc[st_][r] = sv;
-                tmax = fmaxf(tmax, sv);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __expf(m_run - m_new);
-        float psum = 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt + st_ * 16 + lg * 4 + r;
+                    const float sv = key < a.N ? s_acc[st_][r] * a.scale : -INFINITY;
+                    s_acc[st_][r] = sv;
+                    tmax = fmaxf(tmax, sv);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run[t], tmax);
+            const float alpha = fast_exp(m_run[t] - m_new);
+            float psum = 0.f;
 #pragma unroll
-        for (int st_ = 0; st_ < 4; ++st_)
+            for (int st_ = 0; st_ < 4; ++st_)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __expf(s_acc[st_][r] - m_new);
-                s_acc[st_][r] = p;
-                psum += p;
-            }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fast_exp(s_acc[st_][r] - m_new);
+                    s_acc[st_][r] = p;
+                    psum += p;
+                }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            l_run[t] = l_run[t] * alpha + psum;
+            m_run[t] = m_new;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o_acc[dt][r] *= alpha;
+                for (int r = 0; r < 4; ++r) o_acc[t][dt][r] *= alpha;
 
-        // ---- O^T += V^T . P^T, two 32-key halves ----------------------------------------
+            // ---- O^T += V^T . P^T, two 32-key halves ------------------------------------
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            // P^T operand: slots 0-3 <- sub-tile 2*hf, slots 4-7 <- sub-tile 2*hf+1
-            bf16x8_t pf;
-            {
-                union { bf16x8_t v; uint32_t u[4]; } pk;
-                pk.u[0] = pack2bf(s_acc[2 * hf][0], s_acc[2 * hf][1]);
-                pk.u[1] = pack2bf(s_acc[2 * hf][2], s_acc[2 * hf][3]);
-                pk.u[2] = pack2bf(s_acc[2 * hf + 1][0], s_acc[2 * hf + 1][1]);
-                pk.u[3] = pack2bf(s_acc[2 * hf + 1][2], s_acc[2 * hf + 1][3]);
-                pf = pk.v;
-            }
+            for (int hf = 0; hf < 2; ++hf) {
+                // P^T operand: slots 0-3 <- sub-tile 2*hf, slots 4-7 <- sub-tile 2*hf+1
+                bf16x8_t pf;
+                {
+                    union { bf16x8_t v; uint32_t u[4]; } pk;
+                    pk.u[0] = pack2bf(s_acc[2 * hf][0], s_acc[2 * hf][1]);
+                    pk.u[1] = pack2bf(s_acc[2 * hf][2], s_acc[2 * hf][3]);
+                    pk.u[2] = pack2bf(s_acc[2 * hf + 1][0], s_acc[2 * hf + 1][1]);
+                    pk.u[3] = pack2bf(s_acc[2 * hf + 1][2], s_acc[2 * hf + 1][3]);
+                    pf = pk.v;
+                }
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                // V^T operand: row = dim dt*16 + l15, keys hf*32 + {4lg..4lg+3, 16+4lg..16+4lg+3}
-                union { bf16x8_t v; uint2 h2[2]; } vf;
-                const bf16_t* vp = Vt + (dt * 16 + l15) * FA_LDV + hf * 32 + lg * 4;
-                vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
-                vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 16);
-                o_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf, o_acc[dt], 0, 0, 0);
+                for (int dt = 0; dt < 4; ++dt) {
+                    // V^T operand: row = dim dt*16 + l15, keys hf*32 + {4lg..4lg+3, 16+4lg..16+4lg+3}
+                    union { bf16x8_t v; uint2 h2[2]; } vf;
+                    const bf16_t* vp = Vt + (dt * 16 + l15) * FA_LDV + hf * 32 + lg * 4;
+                    vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
+                    vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 16);
+                    o_acc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf, o_acc[t][dt], 0, 0, 0);
+                }
             }
         }
     }
 
-    const int qr = q0 + l15;
-    if (qr < a.N) {
-        const float inv = 1.0f / l_run;
-        bf16_t* op = O + (base_row + qr) * a.ldo + h * HD;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            uint2 t;
-            t.x = pack2bf(o_acc[dt][0] * inv, o_acc[dt][1] * inv);
-            t.y = pack2bf(o_acc[dt][2] * inv, o_acc[dt][3] * inv);
-            *reinterpret_cast<uint2*>(op + dt * 16 + lg * 4) = t;
+    for (int t = 0; t < QT; ++t) {
+        const int qr = qbase + (t * 4 + wave) * 16 + l15;
+        if (qr < a.N) {
+            const float inv = 1.0f / l_run[t];
+            bf16_t* op = O + (base_row + qr) * a.ldo + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 tt;
+                tt.x = pack2bf(o_acc[t][dt][0] * inv, o_acc[t][dt][1] * inv);
+                tt.y = pack2bf(o_acc[t][dt][2] * inv, o_acc[t][dt][3] * inv);
+                *reinterpret_cast<uint2*>(op + dt * 16 + lg * 4) = tt;
+            }
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Decode attention.  grid = (H, B); block = 256 threads.  The k beams of image b share one
-// pass over the image keys/values (read once per block), text keys/values are fetched through
-// kv_src[row][pos] -> cache row, so re-ordering beams never moves KV data.
-//   qkv      : [R, 3d] this step's projections (q | k | v) for position `pos`
-//   img_kv   : [B*N_img, 3d] layer cache written by the prefill (k at +d, v at +2d)
-//   txt_k/v  : [R, T_max, d] text cache (this kernel appends position `pos`)
-//   out      : [R, d]
-// dynamic LDS: scores[k][Nk] + q[k][64] + red[32][k][64]   (Nk = N_img + pos + 1)
-// ---------------------------------------------------------------------------------------
 // Image K/V cache in HEAD-MAJOR layout: kh/vh[b][h][n][64].  The prefill GEMM writes q|k|v token-major
 // ([B*N, 3d], what the prefill attention wants); a decode workgroup (image b, head h) would then touch one
 // 128-byte slice per 4.6-KB token row -- a new DRAM page per access (measured 2.4 TB/s).  Repacked once per
@@ -543,7 +546,7 @@ hipError_t launch_attn_full(const AttnFullArgs& a, int B, bool is_f32, int impl,
     if (B <= 0 || a.N <= 0) return hipSuccess;
     if (impl == 1) {
         if (is_f32) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(attn_full_mfma_kernel, dim3((a.N + 63) / 64, a.H, B), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attn_full_mfma_kernel, dim3((a.N + 255) / 256, a.H, B), dim3(256), 0, s, a);
     } else if (is_f32) {
         hipLaunchKernelGGL(attn_full_valu_kernel<float>, dim3((a.N + 15) / 16, a.H, B), dim3(256), 0, s, a);
     } else {
