@@ -213,8 +213,8 @@ def main():
         avg_ms = prof["vit_gemm_ms"] / n
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         result["roofline"] = {
-            "kernel": "gitmi::gemm_kernel<bf16> (image-encoder launches)" if args.precision == "bf16"
-                      else "gitmi::gemm_kernel<f32>",
+            "kernel": "gitmi::gemm_ring_kernel / gemm_ring256_kernel <bf16> (the 49 image-encoder GEMM launches)"
+                      if args.precision == "bf16" else "gitmi::gemm_kernel<f32>",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
             "traffic_detail": pmc_traffic("gemm_ring"),
