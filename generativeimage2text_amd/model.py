@@ -127,7 +127,7 @@ class CaptioningModel:
         return self
 
     def load_state_dict(self, state_dict: Mapping[str, torch.Tensor], strict: bool = False):
-        tied = "textual.output.weight" not in state_dict
+        tied = not any(k.endswith("textual.output.weight") for k in state_dict)   # keys may carry 'module.' prefixes
         keys = expected_state_dict_keys(self.cfg, tied_output=tied)
         aligned = load_state_dict_by_suffix(keys, state_dict)
         missing = [k for k in keys if k not in aligned]

@@ -296,3 +296,72 @@ def test_cloned_context_shares_weights_and_overlaps(base_engine):
     torch.cuda.synchronize()
     assert torch.equal(ta, ta2) and torch.equal(tb, tb2)
     other.close()
+
+
+# ---- the reference-named task functions, end to end through a checkpoint file ---------------------------
+def test_task_function_single_image_end_to_end(tmp_path, monkeypatch, caplog):
+    """test_git_inference_single_image(image_path, model_name, prefix): JPEG on disk -> PIL transform ->
+    checkpoint file ({'model': state_dict}, module.-prefixed keys) -> engine -> logged ids, vs the oracle."""
+    import logging
+    from PIL import Image
+    from oracle import git_oracle as O
+    from generativeimage2text_amd import inference as I
+    cfg = O.CONFIGS["GIT_BASE"]
+    w = O.make_weights(cfg, seed=1239, tie_output=False, eos_bias=0.3)
+    ckpt = tmp_path / "model.pt"
+    torch.save({"model": {"module." + k: v for k, v in w.items()}}, str(ckpt))
+    rng = np.random.RandomState(3)
+    img_path = tmp_path / "img.png"
+    Image.fromarray(rng.randint(0, 255, (260, 340, 3), dtype=np.uint8)).save(str(img_path))
+    monkeypatch.setenv("GIT_VOCAB", str(tmp_path / "no_vocab.txt"))
+    monkeypatch.setattr(I, "get_tokenizer", lambda: I.IdTokenizer())
+    # the shipped decoder (beam 4, length_penalty 0.6) with a bounded step budget for the oracle's sake
+    from generativeimage2text_amd.model import GeneratorWithBeamSearch
+    real_build = I.build_model
+    monkeypatch.setattr(I, "build_model", lambda name, tok, c, **kw: real_build(
+        name, tok, c, decoder=GeneratorWithBeamSearch(eos_index=102, max_steps=12, beam_size=4, length_penalty=0.6),
+        **kw))
+    with caplog.at_level(logging.INFO):
+        I.test_git_inference_single_image(str(img_path), "GIT_BASE", "2054 2003", checkpoint=str(ckpt), precision="f32")
+    got = I.test_git_inference_single_image.last_output
+    x = I.image_transform(I.load_image_by_pil(str(img_path)), 224)[None]
+    with torch.no_grad():
+        ref = O.caption(cfg, w, [x], O.SearchConfig("beam", 12, 4, 2, 0.6), prefix=torch.tensor([[101, 2054, 2003]]),
+                        cached=True)
+    want = I.IdTokenizer().decode(ref["predictions"][0].tolist())
+    assert got == want, (got, want)
+    assert any("output:" in r.message for r in caplog.records)
+
+
+def test_task_function_single_tsv(tmp_path, monkeypatch):
+    """test_git_inference_single_tsv: base64 JPEG rows in, `key \\t [{"caption": ...}]` rows out, batched."""
+    import base64, io, json
+    from PIL import Image
+    from oracle import git_oracle as O
+    from generativeimage2text_amd import inference as I, tsv_io
+    from generativeimage2text_amd.model import AutoRegressiveBeamSearch
+    cfg = O.CONFIGS["GIT_BASE"]
+    w = O.make_weights(cfg, seed=1240, tie_output=False, eos_bias=0.3)
+    rng = np.random.RandomState(5)
+    rows, imgs = [], []
+    for i in range(5):
+        im = Image.fromarray(rng.randint(0, 255, (230 + 7 * i, 300, 3), dtype=np.uint8))
+        buf = io.BytesIO()
+        im.save(buf, format="PNG")
+        rows.append(["img%d" % i, base64.b64encode(buf.getvalue()).decode()])
+        imgs.append(I.image_transform(im.convert("RGB"), 224))
+    tsv_io.tsv_writer(rows, str(tmp_path / "in.tsv"))
+    monkeypatch.setattr(I, "get_tokenizer", lambda: I.IdTokenizer())
+    real_build = I.build_model
+    monkeypatch.setattr(I, "build_model", lambda name, tok, c, **kw: real_build(
+        name, tok, c, decoder=AutoRegressiveBeamSearch(eos_index=102, max_steps=10, beam_size=1, per_node_beam_size=1,
+                                                       fix_missing_prefix=True), **kw))
+    out = str(tmp_path / "out.tsv")
+    I.test_git_inference_single_tsv(str(tmp_path / "in.tsv"), "GIT_BASE", None, out, checkpoint=w, batch_size=4,
+                                    precision="f32")
+    got = list(tsv_io.tsv_reader(out))
+    assert [r[0] for r in got] == ["img%d" % i for i in range(5)]
+    with torch.no_grad():
+        ref = O.caption(cfg, w, [torch.stack(imgs)], O.SearchConfig("greedy", 10, 1, 1), cached=True)
+    for r, pred in zip(got, ref["predictions"].tolist()):
+        assert json.loads(r[1])[0]["caption"] == I.IdTokenizer().decode(pred)
