@@ -348,12 +348,12 @@ static int alloc_workspaces(gitmi_engine* e) {
     const gitmi_config& c = e->cfg;
     const size_t esz = e->esz;
     const int D = c.vit_width, d = c.dec_hidden;
-    const size_t Mv = (size_t)c.max_batch * e->N;                 // ViT rows per frame
+    const size_t Mv = (size_t)c.max_batch * c.max_frames * e->N;  // ViT rows: all frames of a call in one pass
     const size_t Mp = (size_t)c.max_batch * c.max_frames * e->N;  // prefill rows
     const size_t R = (size_t)c.max_batch * c.max_beams;
     const int T = c.max_text_len;
-    RCK(dev_alloc(e, &e->patches, (size_t)c.max_batch * e->g * e->g * e->Kp_pad * esz));
-    RCK(dev_alloc_t(e, &e->patch_out, (size_t)c.max_batch * e->g * e->g * D));
+    RCK(dev_alloc(e, &e->patches, (size_t)c.max_batch * c.max_frames * e->g * e->g * e->Kp_pad * esz));
+    RCK(dev_alloc_t(e, &e->patch_out, (size_t)c.max_batch * c.max_frames * e->g * e->g * D));
     RCK(dev_alloc_t(e, &e->v_x, Mv * D));
     RCK(dev_alloc(e, &e->v_h, Mv * D * esz));
     RCK(dev_alloc(e, &e->v_qkv, Mv * 3 * D * esz));
@@ -533,36 +533,44 @@ extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
 static int encode_frames_impl(gitmi_engine* e, const float* const* frames, int F, int B, float* feats_out,
                               hipStream_t s) {
     const gitmi_config& c = e->cfg;
-    const int D = c.vit_width, N = e->N, M = B * N;
+    const int D = c.vit_width, N = e->N;
     const int F_eff = c.num_frames > 0 ? std::min(F, c.num_frames) : F;   // zip() truncation, decoder.py:849
     const int Nimg = F_eff * N;
     SpanGuard phase(e, s, TAG_VIT, 0);
+    // all frames of the call go through the encoder as ONE batch of F*B images (the reference encodes frame by
+    // frame, decoder.py:847; per-image results are identical, the GEMMs just see M = F*B*197 rows)
+    const int BI = F_eff * B;                // images in the pass
+    const int M = BI * N;
+    const int g2 = e->g * e->g;
+    for (int fr = 0; fr < F_eff; ++fr)
+        HIPCK(launch_im2col(frames[fr], (char*)e->patches + (size_t)fr * B * g2 * e->Kp_pad * e->esz, e->f32, B,
+                            c.image_size, c.patch, e->Kp, e->Kp_pad, s));
+    RCK(gemm(e, s, e->patches, e->Kp_pad, e->conv_w, nullptr, nullptr, 0, e->patch_out, D, true, BI * g2, D, e->Kp_pad, 0,
+             TAG_GEMM_VIT));
+    HIPCK(launch_vit_assemble_ln(e->patch_out, e->cls, e->pos, e->lnpre_g, e->lnpre_b, 1e-5f, e->v_x, BI, N, D, s));
+    for (int l = 0; l < c.vit_layers; ++l) {
+        const VitLayerW& L = e->vit[l];
+        HIPCK(launch_layernorm(e->v_x, D, L.ln1g, L.ln1b, 1e-5f, nullptr, e->v_h, D, e->f32, nullptr, 0, M, D, 0, 0, 0, s));
+        RCK(gemm(e, s, e->v_h, D, L.wqkv, L.bqkv, nullptr, 0, e->v_qkv, 3 * D, e->f32, M, 3 * D, D, 0, TAG_GEMM_VIT));
+        AttnFullArgs a{};
+        a.q = e->v_qkv;
+        a.k = (char*)e->v_qkv + (size_t)D * e->esz;
+        a.v = (char*)e->v_qkv + (size_t)2 * D * e->esz;
+        a.out = e->v_ctx;
+        a.ldq = a.ldk = a.ldv = 3 * D;
+        a.ldo = D;
+        a.N = N; a.H = c.vit_heads; a.scale = 0.125f;
+        HIPCK(launch_attn_full(a, BI, e->f32, e->attn_impl, s));
+        RCK(gemm(e, s, e->v_ctx, D, L.wo, L.bo, e->v_x, D, e->v_x, D, true, M, D, D, 0, TAG_GEMM_VIT));
+        HIPCK(launch_layernorm(e->v_x, D, L.ln2g, L.ln2b, 1e-5f, nullptr, e->v_h, D, e->f32, nullptr, 0, M, D, 0, 0, 0, s));
+        RCK(gemm(e, s, e->v_h, D, L.w1, L.b1, nullptr, 0, e->v_u, 4 * D, e->f32, M, 4 * D, D, 1, TAG_GEMM_VIT));
+        RCK(gemm(e, s, e->v_u, 4 * D, L.w2, L.b2, e->v_x, D, e->v_x, D, true, M, D, 4 * D, 0, TAG_GEMM_VIT));
+    }
+    // ln_post (+ temporal embedding of the frame), scattered into the concatenated [B, F*N, D] feature tensor
     for (int fr = 0; fr < F_eff; ++fr) {
-        HIPCK(launch_im2col(frames[fr], e->patches, e->f32, B, c.image_size, c.patch, e->Kp, e->Kp_pad, s));
-        RCK(gemm(e, s, e->patches, e->Kp_pad, e->conv_w, nullptr, nullptr, 0, e->patch_out, D, true, B * e->g * e->g,
-                 D, e->Kp_pad, 0, TAG_GEMM_VIT));
-        HIPCK(launch_vit_assemble_ln(e->patch_out, e->cls, e->pos, e->lnpre_g, e->lnpre_b, 1e-5f, e->v_x, B, N, D, s));
-        for (int l = 0; l < c.vit_layers; ++l) {
-            const VitLayerW& L = e->vit[l];
-            HIPCK(launch_layernorm(e->v_x, D, L.ln1g, L.ln1b, 1e-5f, nullptr, e->v_h, D, e->f32, nullptr, 0, M, D, 0, 0, 0, s));
-            RCK(gemm(e, s, e->v_h, D, L.wqkv, L.bqkv, nullptr, 0, e->v_qkv, 3 * D, e->f32, M, 3 * D, D, 0, TAG_GEMM_VIT));
-            AttnFullArgs a{};
-            a.q = e->v_qkv;
-            a.k = (char*)e->v_qkv + (size_t)D * e->esz;
-            a.v = (char*)e->v_qkv + (size_t)2 * D * e->esz;
-            a.out = e->v_ctx;
-            a.ldq = a.ldk = a.ldv = 3 * D;
-            a.ldo = D;
-            a.N = N; a.H = c.vit_heads; a.scale = 0.125f;
-            HIPCK(launch_attn_full(a, B, e->f32, e->attn_impl, s));
-            RCK(gemm(e, s, e->v_ctx, D, L.wo, L.bo, e->v_x, D, e->v_x, D, true, M, D, D, 0, TAG_GEMM_VIT));
-            HIPCK(launch_layernorm(e->v_x, D, L.ln2g, L.ln2b, 1e-5f, nullptr, e->v_h, D, e->f32, nullptr, 0, M, D, 0, 0, 0, s));
-            RCK(gemm(e, s, e->v_h, D, L.w1, L.b1, nullptr, 0, e->v_u, 4 * D, e->f32, M, 4 * D, D, 1, TAG_GEMM_VIT));
-            RCK(gemm(e, s, e->v_u, 4 * D, L.w2, L.b2, e->v_x, D, e->v_x, D, true, M, D, 4 * D, 0, TAG_GEMM_VIT));
-        }
         const float* te = c.num_frames > 0 ? e->temb[fr] : nullptr;
-        HIPCK(launch_layernorm(e->v_x, D, e->lnpost_g, e->lnpost_b, 1e-5f, te, e->feats, D, e->f32, feats_out, D, M, D,
-                               N, Nimg, fr * N, s));
+        HIPCK(launch_layernorm(e->v_x + (size_t)fr * B * N * D, D, e->lnpost_g, e->lnpost_b, 1e-5f, te, e->feats, D, e->f32,
+                               feats_out, D, B * N, D, N, Nimg, fr * N, s));
     }
     e->cur_B = B; e->cur_F = F_eff; e->cur_Nimg = Nimg;
     e->have_feats = true;
