@@ -1021,3 +1021,15 @@ extern "C" int gitmi_debug_set_gemm_impl(int impl) {
     set_gemm_impl(impl);
     return 0;
 }
+
+extern "C" int gitmi_op_attn_decode(const void* qkv, const void* img_k, const void* img_v, void* txt_k, void* txt_v,
+                                    const int* kv_src, void* out, int B, int H, int N_img, int T_max, int pos, int beams,
+                                    int dtype, int dbg, void* stream) {
+    AttnDecodeArgs a{};
+    a.qkv = qkv; a.img_k = img_k; a.img_v = img_v; a.txt_k = txt_k; a.txt_v = txt_v; a.out = out;
+    a.kv_src = kv_src; a.ld_src = T_max; a.d = H * 64; a.N_img = N_img; a.T_max = T_max; a.pos = pos; a.beams = beams;
+    a.scale = 0.125f; a.dbg = dbg;
+    if (attn_decode_configure() != hipSuccess) return fail("configure failed");
+    HIPCK(launch_attn_decode(a, B, H, dtype == GITMI_DTYPE_F32, (hipStream_t)stream));
+    return 0;
+}

@@ -284,6 +284,7 @@ template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> {
     u32x4_t r;
     __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const u32x4_t*>(p); }
+    __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<u32x4_t*>(p) = r; }
     __device__ __forceinline__ void zero() { r = u32x4_t{0u, 0u, 0u, 0u}; }
     __device__ __forceinline__ void get(float (&v)[8]) const {
 #pragma unroll
@@ -299,6 +300,10 @@ template <> struct Raw8<float> {
         a = *reinterpret_cast<const f32x4_t*>(p);
         b = *reinterpret_cast<const f32x4_t*>(p + 4);
     }
+    __device__ __forceinline__ void store(float* p) const {
+        *reinterpret_cast<f32x4_t*>(p) = a;
+        *reinterpret_cast<f32x4_t*>(p + 4) = b;
+    }
     __device__ __forceinline__ void zero() { a = f32x4_t{0.f, 0.f, 0.f, 0.f}; b = a; }
     __device__ __forceinline__ void get(float (&v)[8]) const {
 #pragma unroll
@@ -306,17 +311,18 @@ template <> struct Raw8<float> {
     }
 };
 
-template <typename T>
+// Flash-style decode attention, ONE barrier: every 8-lane group owns a subset of the keys, keeps (max, sum,
+// 64-dim partial output) per beam in registers -- scores never touch LDS, there is no separate softmax pass --
+// the 8 groups of a wave are merged with shuffles and the 4 waves through a 1-KB-per-beam LDS exchange.
+// All global loads (q, image K/V of the first 256 keys, text K/V through the beam indirection) are issued
+// before the first use; the kernel is a single memory round trip + ~1 us of arithmetic.
+template <typename T, int KB>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float dsm[];
-    const int tid = threadIdx.x;
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int k = a.beams;
-    const int Nk = a.N_img + a.pos + 1;
-    float* sc = dsm;                        // [k][Nk]
-    float* qs = sc + (size_t)k * Nk;        // [k][64]
-    float* red = qs + k * HD;               // [32][k][64]
+    __shared__ float part[4][KB][HD + 2];      // per wave and beam: o[64], m, l
 
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x, b = blockIdx.y, H = gridDim.x;
+    const int k = a.beams;                       // k <= KB
     const T* QKV = reinterpret_cast<const T*>(a.qkv);
     const T* IMGK = reinterpret_cast<const T*>(a.img_k);
     const T* IMGV = reinterpret_cast<const T*>(a.img_v);
@@ -325,17 +331,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     T* O = reinterpret_cast<T*>(a.out);
     const int ld3 = 3 * a.d;
     const int row0 = b * k;
-    const int grp = tid >> 3, sub = tid & 7;    // 32 groups of 8 lanes; a group reads one 64-dim row
-    constexpr int PF = 8;                       // image keys per group kept in flight (covers N_img <= 256)
-    constexpr int TI = 5;                       // text (beam, position) items per group: k*(pos+1) <= 160
+    const int grp = tid >> 3, sub = tid & 7;    // 32 groups of 8 lanes; a group reads one 64-dim row at a time
+    const int wave = tid >> 6;
+    constexpr int PF = 8;                       // image keys per group per chunk (256 keys per chunk)
+    constexpr int TI = 5;                       // text (beam, position) items per group held in registers
 
-    // ---- every global load of the step is issued up front: the kernel is one dependent-latency chain
-    // per workgroup (all workgroups are co-resident), so round trips must overlap, not follow each other
-    const int H = gridDim.x;
     const T* kbase = IMGK + ((size_t)b * H + h) * a.N_img * HD + sub * 8;   // head-major: contiguous per (b, h)
     const T* vbase = IMGV + ((size_t)b * H + h) * a.N_img * HD + sub * 8;
     const int nt = a.pos + 1;
-    // text items of this group: (beam j, position s) -> cache row through the beam indirection
+
+    // ---- issue every load up front -------------------------------------------------------------------
     int t_j[TI], t_s[TI], t_row[TI];
 #pragma unroll
     for (int u = 0; u < TI; ++u) {
@@ -344,11 +349,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
         t_s[u] = it < k * nt ? it % nt : 0;
         t_row[u] = (t_j[u] >= 0 && t_s[u] != a.pos) ? a.kv_src[(size_t)(row0 + t_j[u]) * a.ld_src + t_s[u]] : 0;
     }
+    Raw8<T> qr[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        if (j < k) qr[j].load(QKV + (size_t)(row0 + j) * ld3 + h * HD + sub * 8);
+        else qr[j].zero();
+    }
     Raw8<T> kr[PF], vr[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int n = grp + 32 * u;
-        if (n < a.N_img) { kr[u].load(kbase + (size_t)n * HD); vr[u].load(vbase + (size_t)n * HD); }
+        if (n < a.N_img && !(a.dbg & 1)) { kr[u].load(kbase + (size_t)n * HD); vr[u].load(vbase + (size_t)n * HD); }
         else { kr[u].zero(); vr[u].zero(); }
     }
     Raw8<T> tk[TI], tv[TI];
@@ -365,179 +376,164 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
             tv[u].load(TV + off);
         }
     }
+    // append this position's K/V of every beam to the text cache (16-byte copies by the first k*8 threads)
+    if (tid < k * 8) {
+        const int j = tid >> 3;
+        const T* src = QKV + (size_t)(row0 + j) * ld3 + a.d + h * HD + sub * 8;
+        const size_t dst = ((size_t)(row0 + j) * a.T_max + a.pos) * a.d + h * HD + sub * 8;
+        Raw8<T> ck, cv;
+        ck.load(src);
+        cv.load(src + a.d);
+        ck.store(TK + dst);
+        cv.store(TV + dst);
+    }
 
-    // stage q (scaled) and append this position's K/V of every beam to the text cache
-    for (int i = tid; i < k * HD; i += 256) {
-        const int j = i / HD, dd = i % HD;
-        const T* src = QKV + (size_t)(row0 + j) * ld3 + h * HD + dd;
-        qs[i] = ld<T>(src) * a.scale;
-        const size_t dst = ((size_t)(row0 + j) * a.T_max + a.pos) * a.d + h * HD + dd;
-        TK[dst] = src[a.d];
-        TV[dst] = src[2 * a.d];
+    float q[KB][8], m[KB], l[KB], o[KB][8];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        qr[j].get(q[j]);
+        m[j] = -INFINITY;
+        l[j] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { q[j][e] *= a.scale; o[j][e] = 0.f; }
     }
-    __syncthreads();
-
-    // ---- scores over image keys: every beam uses the same key row ----------------------
-    for (int base = 0; base < a.N_img; base += 32 * PF) {
-        if (base > 0) {
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int n = base + grp + 32 * u;
-                if (n < a.N_img) kr[u].load(kbase + (size_t)n * HD);
-                else kr[u].zero();
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int n = base + grp + 32 * u;
-            float kv[8];
-            kr[u].get(kv);
-            for (int j = 0; j < k; ++j) {
-                float p = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) p += qs[j * HD + sub * 8 + e] * kv[e];
-                p += __shfl_xor(p, 1, 64);
-                p += __shfl_xor(p, 2, 64);
-                p += __shfl_xor(p, 4, 64);
-                if (sub == 0 && n < a.N_img) sc[(size_t)j * Nk + n] = p;
-            }
-        }
-    }
-    // ---- scores over text keys ------------------------------------------------------------
-#pragma unroll
-    for (int u = 0; u < TI; ++u) {
-        if (t_j[u] >= 0) {                        // uniform within the 8-lane group
-            float kv[8];
-            tk[u].get(kv);
-            float p = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) p += qs[t_j[u] * HD + sub * 8 + e] * kv[e];
-            p += __shfl_xor(p, 1, 64);
-            p += __shfl_xor(p, 2, 64);
-            p += __shfl_xor(p, 4, 64);
-            if (sub == 0) sc[(size_t)t_j[u] * Nk + a.N_img + t_s[u]] = p;
-        }
-    }
-    // long texts (k * (pos+1) > 32*TI): the remaining items take the slow, dependent-load path
-    for (int it = grp + 32 * TI; it < k * nt; it += 32) {
-        const int j = it / nt, s = it % nt;
-        float kv[8];
-        if (s == a.pos) {
-            ld8(QKV + (size_t)(row0 + j) * ld3 + a.d + h * HD + sub * 8, kv);
-        } else {
-            const int srow = a.kv_src[(size_t)(row0 + j) * a.ld_src + s];
-            ld8(TK + ((size_t)srow * a.T_max + s) * a.d + h * HD + sub * 8, kv);
-        }
+    auto dot8 = [&](const float (&x)[8], const float (&y)[8]) {
         float p = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) p += qs[j * HD + sub * 8 + e] * kv[e];
+        for (int e = 0; e < 8; ++e) p += x[e] * y[e];
         p += __shfl_xor(p, 1, 64);
         p += __shfl_xor(p, 2, 64);
         p += __shfl_xor(p, 4, 64);
-        if (sub == 0) sc[(size_t)j * Nk + a.N_img + s] = p;
-    }
-    __syncthreads();
+        return p;                                   // all 8 lanes of the group hold the 64-dim dot product
+    };
 
-    // ---- softmax per beam (one wave per beam, looping if k > 4) -------------------------
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int j = wave; j < k; j += 4) {
-        float* row = sc + (size_t)j * Nk;
-        float mx = -INFINITY;
-        for (int n = lane; n < Nk; n += 64) mx = fmaxf(mx, row[n]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int n = lane; n < Nk; n += 64) {
-            const float p = fast_exp(row[n] - mx);
-            row[n] = p;
-            sum += p;
-        }
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-        for (int n = lane; n < Nk; n += 64) row[n] *= inv;
-    }
-    __syncthreads();
-
-    // ---- out = P . V : group g accumulates its keys for dims sub*8..+8, all beams -------
-    constexpr int KMAX = 8;
-    float acc[KMAX][8];
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
-
+    // ---- image keys: chunks of 256 keys; two passes inside a chunk (max, then exp/accumulate) -------------
     for (int base = 0; base < a.N_img; base += 32 * PF) {
         if (base > 0) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int n = base + grp + 32 * u;
-                if (n < a.N_img) vr[u].load(vbase + (size_t)n * HD);
-                else vr[u].zero();
+                if (n < a.N_img) { kr[u].load(kbase + (size_t)n * HD); vr[u].load(vbase + (size_t)n * HD); }
+                else { kr[u].zero(); vr[u].zero(); }
             }
+        }
+        float sc[KB][PF];
+        float cm[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) cm[j] = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const bool valid = base + grp + 32 * u < a.N_img;
+            float kv[8];
+            kr[u].get(kv);
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                const float sv = valid ? dot8(q[j], kv) : -INFINITY;
+                sc[j][u] = sv;
+                cm[j] = fmaxf(cm[j], sv);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            if (cm[j] == -INFINITY) continue;           // this group has no key in the chunk
+            const float mn = fmaxf(m[j], cm[j]);
+            const float al = fast_exp(m[j] - mn);       // exp(-inf) = 0 on the first chunk
+            l[j] *= al;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[j][e] *= al;
+            m[j] = mn;
         }
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int n = base + grp + 32 * u;
-            if (n < a.N_img) {
-                float vv[8];
-                vr[u].get(vv);
+            float vv[8];
+            vr[u].get(vv);
 #pragma unroll
-                for (int j = 0; j < KMAX; ++j) {
-                    if (j < k) {
-                        const float p = sc[(size_t)j * Nk + n];
+            for (int j = 0; j < KB; ++j) {
+                const float p = sc[j][u] == -INFINITY ? 0.f : fast_exp(sc[j][u] - m[j]);
+                l[j] += p;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[j][e] += p * vv[e];
-                    }
-                }
+                for (int e = 0; e < 8; ++e) o[j][e] += p * vv[e];
             }
         }
     }
+    // ---- text keys of this group (beam-specific): online update -------------------------------------------
+    auto text_item = [&](int jj, const float (&kv)[8], const float (&vv)[8]) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            if (j == jj) {                              // uniform within the 8-lane group
+                const float sv = dot8(q[j], kv);
+                const float mn = fmaxf(m[j], sv);
+                const float al = fast_exp(m[j] - mn);
+                const float p = fast_exp(sv - mn);
+                l[j] = l[j] * al + p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[j][e] = o[j][e] * al + p * vv[e];
+                m[j] = mn;
+            }
+        }
+    };
 #pragma unroll
     for (int u = 0; u < TI; ++u) {
         if (t_j[u] >= 0) {
-            float vv[8];
+            float kv[8], vv[8];
+            tk[u].get(kv);
             tv[u].get(vv);
-            const float p = sc[(size_t)t_j[u] * Nk + a.N_img + t_s[u]];
-#pragma unroll
-            for (int jj = 0; jj < KMAX; ++jj) {
-                if (jj == t_j[u]) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[jj][e] += p * vv[e];
-                }
-            }
+            text_item(t_j[u], kv, vv);
         }
     }
-    for (int it = grp + 32 * TI; it < k * nt; it += 32) {
-        const int j = it / nt, s = it % nt;
-        float vv[8];
-        if (s == a.pos) {
+    for (int it = grp + 32 * TI; it < k * nt; it += 32) {   // long texts: dependent-load path
+        const int j = it / nt, sidx = it % nt;
+        float kv[8], vv[8];
+        if (sidx == a.pos) {
+            ld8(QKV + (size_t)(row0 + j) * ld3 + a.d + h * HD + sub * 8, kv);
             ld8(QKV + (size_t)(row0 + j) * ld3 + 2 * a.d + h * HD + sub * 8, vv);
         } else {
-            const int srow = a.kv_src[(size_t)(row0 + j) * a.ld_src + s];
-            ld8(TV + ((size_t)srow * a.T_max + s) * a.d + h * HD + sub * 8, vv);
+            const int srow = a.kv_src[(size_t)(row0 + j) * a.ld_src + sidx];
+            ld8(TK + ((size_t)srow * a.T_max + sidx) * a.d + h * HD + sub * 8, kv);
+            ld8(TV + ((size_t)srow * a.T_max + sidx) * a.d + h * HD + sub * 8, vv);
         }
-        const float p = sc[(size_t)j * Nk + a.N_img + s];
-#pragma unroll
-        for (int jj = 0; jj < KMAX; ++jj) {
-            if (jj == j) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[jj][e] += p * vv[e];
-            }
-        }
+        text_item(j, kv, vv);
     }
+
+    // ---- merge the 8 groups of the wave (lanes with equal `sub`), then the 4 waves through LDS ---------------
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-        if (j < k) {
+    for (int j = 0; j < KB; ++j) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[((size_t)grp * k + j) * HD + sub * 8 + e] = acc[j][e];
+        for (int off = 8; off < 64; off <<= 1) {
+            const float m2 = __shfl_xor(m[j], off, 64);
+            const float l2 = __shfl_xor(l[j], off, 64);
+            const float mn = fmaxf(m[j], m2);
+            const float a1 = m[j] == -INFINITY ? 0.f : fast_exp(m[j] - mn);
+            const float a2 = m2 == -INFINITY ? 0.f : fast_exp(m2 - mn);
+            l[j] = l[j] * a1 + l2 * a2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float o2 = __shfl_xor(o[j][e], off, 64);
+                o[j][e] = o[j][e] * a1 + o2 * a2;
+            }
+            m[j] = mn;
+        }
+        if ((tid & 63) < 8 && j < k) {                  // lanes 0..7 of the wave hold the wave's partial
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part[wave][j][sub * 8 + e] = o[j][e];
+            if (sub == 0) { part[wave][j][HD] = m[j]; part[wave][j][HD + 1] = l[j]; }
         }
     }
     __syncthreads();
     for (int i = tid; i < k * HD; i += 256) {
         const int j = i / HD, dd = i % HD;
-        float s = 0.f;
-#pragma unroll 8
-        for (int g = 0; g < 32; ++g) s += red[((size_t)g * k + j) * HD + dd];
-        st<T>(O + (size_t)(row0 + j) * a.d + h * HD + dd, s);
+        float mm = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mm = fmaxf(mm, part[w][j][HD]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = part[w][j][HD];
+            const float aw = mw == -INFINITY ? 0.f : fast_exp(mw - mm);
+            num += aw * part[w][j][dd];
+            den += aw * part[w][j][HD + 1];
+        }
+        st<T>(O + (size_t)(row0 + j) * a.d + h * HD + dd, num / den);
     }
 }
 
@@ -555,11 +551,6 @@ hipError_t launch_attn_full(const AttnFullArgs& a, int B, bool is_f32, int impl,
     return hipGetLastError();
 }
 
-size_t attn_decode_lds_bytes(int beams, int N_img, int pos) {
-    const size_t Nk = (size_t)N_img + pos + 1;
-    return sizeof(float) * ((size_t)beams * Nk + (size_t)beams * HD + (size_t)32 * beams * HD);
-}
-
 hipError_t launch_kv_repack(const void* qkv, void* kh, void* vh, int B, int N, int H, int d, bool is_f32, hipStream_t s) {
     if (B <= 0 || N <= 0) return hipSuccess;
     const size_t total = 2 * (size_t)B * H * N * (is_f32 ? 16 : 8);
@@ -572,24 +563,26 @@ hipError_t launch_kv_repack(const void* qkv, void* kh, void* vh, int B, int N, i
     return hipGetLastError();
 }
 
-hipError_t attn_decode_configure() {
-    // allow the full 160 KiB of LDS as dynamic shared memory (k = 8 beams or long video contexts)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<float>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<bf16_t>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+hipError_t attn_decode_configure() { return hipSuccess; }   // (no dynamic LDS any more)
+
+size_t attn_decode_lds_bytes(int beams, int N_img, int pos) {
+    (void)N_img; (void)pos;
+    return sizeof(float) * 4 * (size_t)beams * (HD + 2);
+}
+
+template <typename T>
+static void launch_attn_decode_t(const AttnDecodeArgs& a, int B, int H, hipStream_t s) {
+    if (a.beams <= 1) hipLaunchKernelGGL((attn_decode_kernel<T, 1>), dim3(H, B), dim3(256), 0, s, a);
+    else if (a.beams <= 2) hipLaunchKernelGGL((attn_decode_kernel<T, 2>), dim3(H, B), dim3(256), 0, s, a);
+    else if (a.beams <= 4) hipLaunchKernelGGL((attn_decode_kernel<T, 4>), dim3(H, B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<T, 8>), dim3(H, B), dim3(256), 0, s, a);
 }
 
 hipError_t launch_attn_decode(const AttnDecodeArgs& a, int B, int H, bool is_f32, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (a.beams > 8) return hipErrorInvalidValue;
-    const size_t lds = attn_decode_lds_bytes(a.beams, a.N_img, a.pos);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (is_f32)
-        hipLaunchKernelGGL(attn_decode_kernel<float>, dim3(H, B), dim3(256), lds, s, a);
-    else
-        hipLaunchKernelGGL(attn_decode_kernel<bf16_t>, dim3(H, B), dim3(256), lds, s, a);
+    if (is_f32) launch_attn_decode_t<float>(a, B, H, s);
+    else launch_attn_decode_t<bf16_t>(a, B, H, s);
     return hipGetLastError();
 }
 

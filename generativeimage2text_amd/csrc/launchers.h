@@ -67,6 +67,7 @@ struct AttnDecodeArgs {
     int d;
     int N_img, T_max, pos, beams;
     float scale;
+    int dbg;             // timing experiments: 1 skip image K/V loads, 2 skip scores, 4 skip PV
 };
 hipError_t launch_kv_repack(const void* qkv, void* kh, void* vh, int B, int N, int H, int d, bool is_f32, hipStream_t s);
 size_t attn_decode_lds_bytes(int beams, int N_img, int pos);

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_generate", "gitmi_search_begin", "gitmi_search_rows", "gitmi_search_advance",
     "gitmi_search_finish", "gitmi_profile_enable", "gitmi_profile_read", "gitmi_set_graph",
     "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_gemm_skinny",
-    "gitmi_op_gemm_splitk_ln", "gitmi_debug_set_gemm_impl", "gitmi_clone",
+    "gitmi_op_gemm_splitk_ln", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode",
 ]
 
 
@@ -95,6 +95,7 @@ def load_library() -> C.CDLL:
     lib.gitmi_op_gemm_skinny.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_debug_set_gemm_impl.argtypes = [i32]
     lib.gitmi_clone.argtypes = [vp, C.POINTER(vp)]
+    lib.gitmi_op_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_gemm_splitk_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, i32, vp, vp, i32, i32, i32, vp]
     for name in EXPORTED_SYMBOLS:
         if name not in ("gitmi_last_error", "gitmi_destroy"):
@@ -349,3 +350,14 @@ def op_gemm_splitk_ln(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, resi
 def set_gemm_impl(impl: int) -> None:
     """-1 auto, 0 first-generation GEMM kernel, 1 direct-to-LDS kernel (A/B measurements)."""
     _ck(load_library().gitmi_debug_set_gemm_impl(int(impl)))
+
+
+def op_attn_decode(qkv, img_k, img_v, txt_k, txt_v, kv_src, B, H, N_img, T_max, pos, beams, dbg=0):
+    """qkv [R,3d]; img_k/img_v [B,H,N_img,64]; txt_k/txt_v [R,T_max,d] (position pos gets appended); kv_src int32 [R,T_max]."""
+    lib = load_library()
+    R, d = B * beams, H * 64
+    out = torch.empty(R, d, device=qkv.device, dtype=qkv.dtype)
+    _ck(lib.gitmi_op_attn_decode(qkv.data_ptr(), img_k.data_ptr(), img_v.data_ptr(), txt_k.data_ptr(), txt_v.data_ptr(),
+                                 kv_src.data_ptr(), out.data_ptr(), B, H, N_img, T_max, pos, beams, _torch_dtype_code(qkv),
+                                 dbg, _stream()))
+    return out

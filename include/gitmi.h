@@ -193,6 +193,13 @@ int  gitmi_op_gemm_splitk_ln(const void* A, const void* W, const float* bias, co
                              const float* gamma, const float* beta, float eps, float* partial_ws, int S,
                              float* y_f32, void* y_bf16, int M, int N, int K, void* stream);
 
+/* decode attention for one new text position (unit parity / timing): qkv [R,3d] (R = B*beams), image K/V
+ * head-major [B][H][N_img][64], text caches [R][T_max][d] (position `pos` is appended), kv_src int32 [R][T_max],
+ * out [R,d].  dbg: 0, or timing-experiment bits (results undefined). */
+int  gitmi_op_attn_decode(const void* qkv, const void* img_k, const void* img_v, void* txt_k, void* txt_v,
+                          const int* kv_src, void* out, int B, int H, int N_img, int T_max, int pos, int beams,
+                          int dtype, int dbg, void* stream);
+
 /* kernel selection for A/B measurements: -1 auto (default), 0 first-generation GEMM only,
  * 1 force the direct-to-LDS GEMM wherever its constraints hold */
 int  gitmi_debug_set_gemm_impl(int impl);

@@ -144,3 +144,35 @@ def test_gemm_splitk_layernorm(M, N, K, S):
     assert (y_t.cpu().double() - ref).abs().max().item() < 3e-2
     y_f2, _ = E.op_gemm_splitk_ln(A.cuda(), W.cuda(), bias.cuda(), res.cuda(), g.cuda(), b.cuda(), 1e-12, S)
     assert torch.equal(y_f, y_f2)            # fixed summation order: bitwise reproducible
+
+
+@pytest.mark.parametrize("B,H,N_img,pos,beams", [(2, 2, 17, 0, 1), (3, 12, 197, 5, 1), (2, 12, 197, 7, 4), (1, 2, 300, 3, 3),
+                                                  (1, 1, 1182, 11, 2), (2, 2, 40, 60, 4)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_decode(B, H, N_img, pos, beams, dtype):
+    """one new text position per row against [shared image K/V | per-beam text K/V through kv_src]"""
+    from generativeimage2text_amd import engine as E
+    d, R, T = H * 64, B * beams, max(pos + 1, 8) + 3
+    g = torch.Generator().manual_seed(100 + N_img + pos)
+    qkv = (torch.randn(R, 3 * d, generator=g) * 1.2).to(dtype)
+    ik = torch.randn(B, H, N_img, 64, generator=g).to(dtype)
+    iv = torch.randn(B, H, N_img, 64, generator=g).to(dtype)
+    tk = torch.randn(R, T, d, generator=g).to(dtype)
+    tv = torch.randn(R, T, d, generator=g).to(dtype)
+    src = torch.stack([torch.randint(b * beams, (b + 1) * beams, (T,), generator=g) for b in range(B) for _ in range(beams)]).int()
+    out = E.op_attn_decode(qkv.cuda(), ik.cuda(), iv.cuda(), tk.cuda().clone(), tv.cuda().clone(), src.cuda(), B, H, N_img, T, pos,
+                           beams).cpu().double()
+    ref = torch.zeros(R, d, dtype=torch.float64)
+    for r in range(R):
+        b = r // beams
+        for h in range(H):
+            q = qkv[r, h * 64:(h + 1) * 64].double() * 0.125
+            ks = [ik[b, h].double()] + [tk[src[r, s], s, h * 64:(h + 1) * 64].double()[None] for s in range(pos)] + \
+                 [qkv[r, d + h * 64: d + (h + 1) * 64].double()[None]]
+            vs = [iv[b, h].double()] + [tv[src[r, s], s, h * 64:(h + 1) * 64].double()[None] for s in range(pos)] + \
+                 [qkv[r, 2 * d + h * 64: 2 * d + (h + 1) * 64].double()[None]]
+            Kc, Vc = torch.cat(ks), torch.cat(vs)
+            p = torch.softmax(Kc @ q, 0)
+            ref[r, h * 64:(h + 1) * 64] = p @ Vc
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    assert (out - ref).abs().max().item() < tol
