@@ -74,6 +74,19 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // bias of the columns this lane will finish (wave w finishes m-tile w of every n-tile): fetched together
+    // with the first operand loads so the epilogue has no dependent memory round trip of its own
+    float bias_pf[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 16 + lg * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nn = n + r < g.N ? n + r : g.N - 1;
+            bias_pf[j][r] = (g.bias && g.S == 1) ? g.bias[nn] : 0.f;
+        }
+    }
+
     // k-steps in chunks whose loads are all issued before the first MFMA (6, then 2, then 1)
     auto chunk = [&](auto UC, int k0) {
         constexpr int U = decltype(UC)::value;
@@ -127,16 +140,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs g) {
             continue;
         }
         const bool full = n + 3 < g.N;
-        if (g.bias) {
-            if (full) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += g.bias[n + r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < g.N) v[r] += g.bias[n + r];
-            }
-        }
+        for (int r = 0; r < 4; ++r) v[r] += bias_pf[j][r];
         if (g.act != GITMI_ACT_NONE) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], g.act);
