@@ -284,6 +284,7 @@ template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> {
     u32x4_t r;
     __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const u32x4_t*>(p); }
+    __device__ __forceinline__ void load_nt(const bf16_t* p) { r = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); }
     __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<u32x4_t*>(p) = r; }
     __device__ __forceinline__ void zero() { r = u32x4_t{0u, 0u, 0u, 0u}; }
     __device__ __forceinline__ void get(float (&v)[8]) const {
@@ -299,6 +300,10 @@ template <> struct Raw8<float> {
     __device__ __forceinline__ void load(const float* p) {
         a = *reinterpret_cast<const f32x4_t*>(p);
         b = *reinterpret_cast<const f32x4_t*>(p + 4);
+    }
+    __device__ __forceinline__ void load_nt(const float* p) {
+        a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+        b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p + 4));
     }
     __device__ __forceinline__ void store(float* p) const {
         *reinterpret_cast<f32x4_t*>(p) = a;
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         const int n = grp + 32 * u;
-        if (n < a.N_img && !(a.dbg & 1)) { kr[u].load(kbase + (size_t)n * HD); vr[u].load(vbase + (size_t)n * HD); }
+        if (n < a.N_img && !(a.dbg & 1)) { kr[u].load_nt(kbase + (size_t)n * HD); vr[u].load_nt(vbase + (size_t)n * HD); }   // streamed once per step
         else { kr[u].zero(); vr[u].zero(); }
     }
     Raw8<T> tk[TI], tv[TI];
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int n = base + grp + 32 * u;
-                if (n < a.N_img) { kr[u].load(kbase + (size_t)n * HD); vr[u].load(vbase + (size_t)n * HD); }
+                if (n < a.N_img) { kr[u].load_nt(kbase + (size_t)n * HD); vr[u].load_nt(vbase + (size_t)n * HD); }
                 else { kr[u].zero(); vr[u].zero(); }
             }
         }
