@@ -37,7 +37,9 @@ __device__ __forceinline__ void sk_store4<bf16_t>(bf16_t* p, const float (&v)[4]
 // grid = (ceil(N / (16*NT)), ceil(M / 64), S); block = 256
 template <typename TOut, int NT>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs g) {
-    __shared__ __attribute__((aligned(16))) f32x4_t red[4][NT][4][64];   // [wave][n-tile][m-tile][lane]
+    // cross-wave exchange: a wave publishes only the 3 m-tiles it does NOT finish itself -> 12 KiB per n-tile,
+    // which lets a decode workgroup share a CU with a 144-KiB ring-GEMM workgroup of another stream
+    __shared__ __attribute__((aligned(16))) f32x4_t red[4][NT][3][64];   // [writer wave][n-tile][foreign m-tile][lane]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -115,18 +117,25 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs g) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[wave][j][i][lane] = acc[j][i];
+        for (int i = 0; i < 4; ++i)
+            if (i != wave) red[wave][j][i < wave ? i : i - 1][lane] = acc[j][i];
     __syncthreads();
     const int i = wave;
     const int m = m0 + i * 16 + l15;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        f32x4_t s = red[0][j][i][lane];
+        f32x4_t s = acc[j][0];                       // own partial of tile `wave` (static-index select)
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const f32x4_t t = red[w][j][i][lane];
-            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        for (int ii = 1; ii < 4; ++ii)
+            if (ii == wave) s = acc[j][ii];
+        // fixed summation order over the writer waves (own partial takes its place in that order)
+        f32x4_t tot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const f32x4_t t = w == wave ? s : red[w][j][i < w ? i : i - 1][lane];
+            tot[0] += t[0]; tot[1] += t[1]; tot[2] += t[2]; tot[3] += t[3];
         }
+        s = tot;
         const int n = n0 + j * 16 + lg * 4;
         if (m >= g.M || n >= g.N) continue;
         float v[4] = {s[0], s[1], s[2], s[3]};
