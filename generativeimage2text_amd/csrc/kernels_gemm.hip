@@ -280,6 +280,7 @@ hipError_t launch_gemm(const GemmArgs& g_in, bool in_f32, bool out_f32, hipStrea
         if (g_gemm_impl == 5) return launch_gemm_ring32w(g, out_f32, s);
         if (g_gemm_impl == 6) return launch_gemm_ring256(g, out_f32, s);
         if (g_gemm_impl == 7) return launch_gemm_ring2p(g, out_f32, s);
+        if (g_gemm_impl == 8 && g.K >= 128) return launch_gemm_pring2(g, out_f32, s);
         // auto: narrow outputs (N <= 1024: out-proj, c_proj, patch embed) have too few 256x128 tiles per CU and
         // run faster on the 256x256 4-stage ring; wide outputs on the 256x128 3-stage ring (measured, profiles/)
         if (g_gemm_impl == -1 && g.M > 512 && g.N <= 1024 && g.N % 256 == 0) return launch_gemm_ring256(g, out_f32, s);
