@@ -39,7 +39,7 @@ template <typename TOut, int NT>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs g) {
     // cross-wave exchange: a wave publishes only the 3 m-tiles it does NOT finish itself -> 12 KiB per n-tile,
     // which lets a decode workgroup share a CU with a 144-KiB ring-GEMM workgroup of another stream
-    __shared__ __attribute__((aligned(16))) f32x4_t red[4][NT][3][64];   // [writer wave][n-tile][foreign m-tile][lane]
+    __shared__ __attribute__((aligned(16))) f32x4_t red[4][3][64];   // [writer wave][foreign m-tile][lane], reused per n-tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -113,17 +113,16 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs g) {
     for (; k + 2 <= ke; k += 2) chunk(std::integral_constant<int, 2>{}, k);
     for (; k < ke; ++k) chunk(std::integral_constant<int, 1>{}, k);
 
-    // ---- cross-wave reduction: wave w finishes m-tile w -------------------------------------
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i != wave) red[wave][j][i < wave ? i : i - 1][lane] = acc[j][i];
-    __syncthreads();
+    // ---- cross-wave reduction, one n-tile at a time: wave w finishes m-tile w ----------------------
     const int i = wave;
     const int m = m0 + i * 16 + l15;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
+        if (j > 0) __syncthreads();                  // the exchange buffer of the previous n-tile has been consumed
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+            if (ii != wave) red[wave][ii < wave ? ii : ii - 1][lane] = acc[j][ii];
+        __syncthreads();
         f32x4_t s = acc[j][0];                       // own partial of tile `wave` (static-index select)
 #pragma unroll
         for (int ii = 1; ii < 4; ++ii)
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs g) {
         f32x4_t tot = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const f32x4_t t = w == wave ? s : red[w][j][i < w ? i : i - 1][lane];
+            const f32x4_t t = w == wave ? s : red[w][i < w ? i : i - 1][lane];
             tot[0] += t[0]; tot[1] += t[1]; tot[2] += t[2]; tot[3] += t[3];
         }
         s = tot;

@@ -365,3 +365,27 @@ def test_task_function_single_tsv(tmp_path, monkeypatch):
         ref = O.caption(cfg, w, [torch.stack(imgs)], O.SearchConfig("greedy", 10, 1, 1), cached=True)
     for r, pred in zip(got, ref["predictions"].tolist()):
         assert json.loads(r[1])[0]["caption"] == I.IdTokenizer().decode(pred)
+
+
+@pytest.mark.parametrize("kind", ["greedy", "beam"])
+def test_long_step_budget_polling_path(kind):
+    """The shipped step budget is max_steps=1024 (model.py:37): far beyond 32 steps the engine launches eagerly
+    and polls the device-side 'every sentence finished' flag every 8 steps.  Results must not depend on when it
+    notices (decoder.py:319 / :1251 semantics), tokens bit-identical to the oracle in fp32 mode."""
+    from oracle import git_oracle as O
+    cfg = O.CONFIGS["TINY"]
+    w = O.make_weights(cfg, seed=77, tie_output=False, eos_bias=2.2)
+    frames = O.make_images(cfg, 5, 1, seed=8)
+    search = O.SearchConfig("greedy", 60, 1, 1) if kind == "greedy" else O.SearchConfig("beam", 60, 4, 2, 0.6)
+    with torch.no_grad():
+        ref = O.caption(cfg, w, frames, search, cached=True)
+    for prec in ("f32", "bf16"):
+        eng = make_engine(cfg, w, prec, 5, search)
+        tokens, logprobs, info = eng.generate([f.cuda() for f in frames], search_struct(search))
+        preds, lps = format_like_reference(search, tokens, logprobs, info, None)
+        if prec == "f32":
+            assert preds.shape == ref["predictions"].shape, (preds.shape, ref["predictions"].shape)
+            assert torch.equal(preds, ref["predictions"])
+            assert torch.allclose(lps, ref["logprobs"], atol=2e-3)
+            assert info.tolist()[2] < 59          # stopped early: fewer decode steps than the budget
+        eng.close()
