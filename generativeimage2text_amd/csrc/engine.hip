@@ -1033,3 +1033,13 @@ extern "C" int gitmi_op_attn_decode(const void* qkv, const void* img_k, const vo
     HIPCK(launch_attn_decode(a, B, H, dtype == GITMI_DTYPE_F32, (hipStream_t)stream));
     return 0;
 }
+
+// ---- GPU image transform -------------------------------------------------------
+extern "C" int gitmi_preprocess_image(const uint8_t* rgb_hwc, int H, int W, int crop, uint8_t* tmp, size_t tmp_bytes,
+                                      float* out_chw, void* stream) {
+    if (!rgb_hwc || !out_chw || H < 1 || W < 1 || crop < 1) return fail("preprocess: bad argument");
+    const int nw = W <= H ? crop : (int)((double)crop * W / H);
+    if (nw != W && (!tmp || tmp_bytes < (size_t)H * nw * 3)) return fail("preprocess: workspace must hold H * %d * 3 bytes", nw);
+    HIPCK(launch_preprocess(rgb_hwc, H, W, crop, tmp, out_chw, (hipStream_t)stream));
+    return 0;
+}

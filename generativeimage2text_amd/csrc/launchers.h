@@ -102,4 +102,7 @@ hipError_t launch_search_rows(const SearchState& st, int cur, int cur_len, long 
 hipError_t launch_fill_start(long long* start, const long long* prefix, int sos, int B, int P, hipStream_t s);
 hipError_t launch_load_ids(const long long* tokens, int R, int t, int* ids, int* kv_src, int ld, hipStream_t s);
 
+// GPU image transform (Pillow-exact bicubic resize + centre crop + CLIP normalisation)
+hipError_t launch_preprocess(const unsigned char* rgb, int H, int W, int crop, unsigned char* tmp, float* out, hipStream_t s);
+
 }  // namespace gitmi

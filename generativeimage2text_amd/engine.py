@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_generate", "gitmi_search_begin", "gitmi_search_rows", "gitmi_search_advance",
     "gitmi_search_finish", "gitmi_profile_enable", "gitmi_profile_read", "gitmi_set_graph",
     "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_gemm_skinny",
-    "gitmi_op_gemm_splitk_ln", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode",
+    "gitmi_op_gemm_splitk_ln", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
 ]
 
 
@@ -95,6 +95,7 @@ def load_library() -> C.CDLL:
     lib.gitmi_op_gemm_skinny.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_debug_set_gemm_impl.argtypes = [i32]
     lib.gitmi_clone.argtypes = [vp, C.POINTER(vp)]
+    lib.gitmi_preprocess_image.argtypes = [vp, i32, i32, i32, vp, C.c_size_t, vp, vp]
     lib.gitmi_op_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_gemm_splitk_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, i32, vp, vp, i32, i32, i32, vp]
     for name in EXPORTED_SYMBOLS:
@@ -360,4 +361,18 @@ def op_attn_decode(qkv, img_k, img_v, txt_k, txt_v, kv_src, B, H, N_img, T_max, 
     _ck(lib.gitmi_op_attn_decode(qkv.data_ptr(), img_k.data_ptr(), img_v.data_ptr(), txt_k.data_ptr(), txt_v.data_ptr(),
                                  kv_src.data_ptr(), out.data_ptr(), B, H, N_img, T_max, pos, beams, _torch_dtype_code(qkv),
                                  dbg, _stream()))
+    return out
+
+
+def preprocess_image(rgb_hwc: torch.Tensor, crop: int = 224) -> torch.Tensor:
+    """uint8 [H,W,3] device tensor (a decoded RGB image) -> fp32 [3,crop,crop], bit-exact with the reference's
+    PIL/torchvision transform (Resize(crop, BICUBIC) -> CenterCrop -> ToTensor -> Normalize)."""
+    lib = load_library()
+    assert rgb_hwc.is_cuda and rgb_hwc.dtype == torch.uint8 and rgb_hwc.dim() == 3 and rgb_hwc.shape[2] == 3
+    rgb_hwc = rgb_hwc.contiguous()
+    H, W = int(rgb_hwc.shape[0]), int(rgb_hwc.shape[1])
+    nw = crop if W <= H else int(crop * W / H)
+    tmp = torch.empty(H * nw * 3, dtype=torch.uint8, device=rgb_hwc.device)
+    out = torch.empty(3, crop, crop, dtype=torch.float32, device=rgb_hwc.device)
+    _ck(lib.gitmi_preprocess_image(rgb_hwc.data_ptr(), H, W, crop, tmp.data_ptr(), tmp.numel(), out.data_ptr(), _stream()))
     return out

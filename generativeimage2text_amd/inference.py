@@ -106,12 +106,23 @@ def image_transform(img, crop_size: int = 224) -> torch.Tensor:
     return (x - mean) / std
 
 
-def get_image_transform(param: dict):
+def gpu_image_transform(img, crop_size: int = 224) -> torch.Tensor:
+    """Same transform on the GPU (csrc/kernels_preproc.hip): the decoded uint8 RGB image is uploaded as is and
+    Pillow's bicubic resampler, the centre crop and the normalisation run in two HIP kernels -- bit-exact with
+    image_transform() (tests/test_preprocess.py).  JPEG decoding stays on the host (PIL)."""
+    from .engine import preprocess_image
+    arr = np.asarray(img.convert("RGB"), dtype=np.uint8)
+    return preprocess_image(torch.from_numpy(arr.copy()).cuda(non_blocking=True), crop_size)
+
+
+def get_image_transform(param: dict, gpu: bool = False):
     if "test_respect_ratio_max" in param:
         raise NotImplementedError(
             "aspect-preserving resize (MinMaxResizeForTest, inference.py:29-64) needs the variable-resolution "
             "ViT path, which is a 'next' row (SURVEY.md 8f-3)")
     crop = param.get("test_crop_size", 224)
+    if gpu:
+        return lambda im: gpu_image_transform(im, crop)
     return lambda im: image_transform(im, crop)
 
 
@@ -154,7 +165,7 @@ def test_git_inference_single_image(image_path, model_name, prefix, *, checkpoin
     tokenizer = get_tokenizer()
     if isinstance(image_path, str):
         image_path = [image_path]
-    transforms = get_image_transform(param)
+    transforms = get_image_transform(param, gpu=True)
     img = [transforms(load_image_by_pil(p)) for p in image_path]
     model = build_model(model_name, tokenizer, checkpoint, max_batch=1, precision=precision)
     model.cuda()
@@ -190,7 +201,7 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
     torch.cuda.set_device(get_mpi_local_rank())                             # inference.py:152
     is_vqa = question_tsv is not None
     model = build_model(model_name, tokenizer, checkpoint, max_batch=1 if is_vqa else batch_size, precision=precision)
-    transforms = get_image_transform(param)
+    transforms = get_image_transform(param, gpu=True)
     rank, world = get_mpi_rank(), get_mpi_size()
     tsv = TSVFile(image_tsv)
     start, end = shard_range(len(tsv), rank, world)

@@ -21,6 +21,7 @@
 #ifndef GITMI_H_
 #define GITMI_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -199,6 +200,13 @@ int  gitmi_op_gemm_splitk_ln(const void* A, const void* W, const float* bias, co
 int  gitmi_op_attn_decode(const void* qkv, const void* img_k, const void* img_v, void* txt_k, void* txt_v,
                           const int* kv_src, void* out, int B, int H, int N_img, int T_max, int pos, int beams,
                           int dtype, int dbg, void* stream);
+
+/* GPU-side image transform == get_image_transform(param) of the reference (inference.py:111-132):
+ * Resize(crop, BICUBIC) -> CenterCrop(crop) -> ToTensor -> Normalize(CLIP mean/std), bit-exact with the
+ * PIL/torchvision pipeline (Pillow's 8.22 fixed-point resampler is reproduced).  rgb_hwc: uint8 [H,W,3] on
+ * the device (a decoded image); tmp: device workspace of >= H * W_resized * 3 bytes; out_chw: fp32 [3,crop,crop]. */
+int  gitmi_preprocess_image(const uint8_t* rgb_hwc, int H, int W, int crop, uint8_t* tmp, size_t tmp_bytes,
+                            float* out_chw, void* stream);
 
 /* kernel selection for A/B measurements: -1 auto (default), 0 first-generation GEMM only,
  * 1 force the direct-to-LDS GEMM wherever its constraints hold */

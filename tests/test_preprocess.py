@@ -1,0 +1,44 @@
+"""Image transform.  CPU: the numpy restatement of Pillow's 8-bit bicubic resampler is
+bit-exact against Pillow itself.  GPU: the HIP transform is bit-exact against the reference's PIL/torch
+transform (Resize(224, BICUBIC) -> CenterCrop -> ToTensor -> Normalize), float for float."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle.pil_resize_oracle import resize_bicubic_u8, reference_transform_size
+
+SIZES = [(300, 400), (1279, 1706), (230, 300), (100, 80), (224, 224), (640, 480), (57, 91), (224, 500), (900, 224)]
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_oracle_resize_is_pillow_exact(h, w):
+    rng = np.random.RandomState(h * 31 + w)
+    img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+    nw, nh = reference_transform_size(w, h, 224)
+    ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BICUBIC))
+    assert np.array_equal(resize_bicubic_u8(img, nh, nw), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w", SIZES)
+def test_gpu_transform_bit_exact(h, w):
+    from generativeimage2text_amd import engine as E, inference as I
+    rng = np.random.RandomState(h * 17 + w)
+    img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+    ref = I.image_transform(Image.fromarray(img), 224)                     # the PIL + torch path of the reference
+    got = E.preprocess_image(torch.from_numpy(img).cuda(), 224).cpu()
+    assert got.shape == ref.shape == (3, 224, 224)
+    assert torch.equal(got, ref), (got - ref).abs().max()
+
+
+@pytest.mark.gpu
+def test_gpu_transform_smooth_image_and_repeat():
+    # smooth content (real photos are smooth; rounding ties behave differently than on noise) + coefficient cache reuse
+    from generativeimage2text_amd import engine as E, inference as I
+    yy, xx = np.mgrid[0:777, 0:1031]
+    img = np.stack([(yy * 255 // 776), (xx * 255 // 1030), ((yy + xx) % 256)], -1).astype(np.uint8)
+    ref = I.image_transform(Image.fromarray(img), 224)
+    for _ in range(2):
+        got = E.preprocess_image(torch.from_numpy(img).cuda(), 224).cpu()
+        assert torch.equal(got, ref)
