@@ -1,0 +1,328 @@
+// bf16 GEMM for the large-M phases -- tenth generation: 256x256x64 tile, 8 waves, half-tile granular LDS-DMA
+// pipeline in four phases per K tile, the two wave groups of a workgroup staggered by one barrier.
+//
+//   C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) (+ residual[M,N])      K % 64 == 0, K >= 128, N % 256 == 0
+//
+// Why: the 256x128 ring kernels (kernels_gemm3.hip ...) need one operand byte from L2 per 85 FLOP and all
+// saturate near 12 TB/s of operand feed.  A 256x256 tile needs one byte per 128 FLOP; the 128 KiB of LDS
+// that leaves room for only two K tiles are recycled at HALF-TILE granularity so that four half tiles
+// (64 KiB) are always in flight.
+//
+//   * 512 threads = 8 waves.  wave = 4*grp + wc.  A wave owns 128x64 of the output as FOUR quadrants of
+//     64x32:  rows  qm*128 + grp*64 + [0,64),  columns  qn*128 + wc*32 + [0,32)   (qm, qn in {0,1}),
+//     so that quadrant (qm,qn) of EVERY wave reads activation half qm (rows qm*128..) and weight half qn.
+//     MFMA 16x16x32 bf16 in swapped orientation (accumulator = C^T, see kernels_gemm.hip).
+//   * LDS: 2 K tiles x [A0 | A1 | B0 | B1], each half tile = 128 rows x 128 B = 16 KiB in the bank-conflict
+//     free image of kernels_gemm3.hip; a wave fills 2 KiB of every half tile (2 global_load_lds_dwordx4).
+//   * K tile t, phase p = 1..4, each phase = [ds_reads, one half-tile prefetch, counted vmcnt] s_barrier
+//     [16 MFMAs] s_barrier:
+//         P1: read B0,A0 (12 ds_read_b128)   prefetch B1(t+1)   MFMA quadrant (0,0)
+//         P2: read B1    (4)                 prefetch A1(t+1)   MFMA quadrant (0,1)
+//         P3: read A1    (8)                 prefetch A0(t+2)   MFMA quadrant (1,1)
+//         P4: -                              prefetch B0(t+2)   MFMA quadrant (1,0)
+//     A half tile is refilled no earlier than two phases after the phase that read it (the other wave group
+//     runs one barrier behind), and `s_waitcnt vmcnt(8)` at the end of a read segment confirms the half tile
+//     issued four phases ago -- the one the NEXT phase reads.  Group 1 executes one extra barrier up front:
+//     while one group issues MFMAs (s_setprio 1) the other one's ds_reads and LDS-DMA issues are in flight.
+//   * epilogue through LDS, one 128-row slab at a time; 16-byte row-contiguous stores / residual reads.
+#include "gitmi_common.h"
+#include "launchers.h"
+#include <type_traits>
+
+namespace gitmi {
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF_BYTES = 128 * BK * 2;             // 16 KiB
+constexpr int BUF_BYTES = 4 * HALF_BYTES;            // 64 KiB: A0 A1 B0 B1
+constexpr int LDS_BYTES = 2 * BUF_BYTES;             // 128 KiB
+constexpr int SLOT_A0 = 0, SLOT_A1 = HALF_BYTES, SLOT_B0 = 2 * HALF_BYTES, SLOT_B1 = 3 * HALF_BYTES;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+#define P8_BARRIER()                           \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        asm volatile("" ::: "memory");         \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <typename TOut, int ACT>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    // ---- tile of this workgroup: 2-D partition of the tile grid over the 8 XCDs (see kernels_gemm3.hip)
+    int tile_m, tile_n;
+    {
+        const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int ng = g.ng, mg = 8 / ng;
+        const int gn = x % ng, gm = x / ng;
+        const int tiles_m = (g.M + BM - 1) / BM;
+        const int n_lo = gn * g.tiles_n / ng, n_hi = (gn + 1) * g.tiles_n / ng;
+        const int m_lo = gm * tiles_m / mg, m_hi = (gm + 1) * tiles_m / mg;
+        const int nn = n_hi - n_lo;
+        if (nn <= 0 || idx >= nn * (m_hi - m_lo)) return;      // surplus workgroup of an uneven split
+        tile_m = m_lo + idx / nn;
+        tile_n = n_lo + idx % nn;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const char* __restrict__ Ab = reinterpret_cast<const char*>(g.A);
+    const char* __restrict__ Wb = reinterpret_cast<const char*>(g.W);
+
+    // ---- staging sources.  A wave instruction fills 1 KiB = 4 bank rows = 8 tile rows; this wave owns
+    // pieces P = 2*wave + q (q = 0,1) of every half tile.  lane -> bank row Rl, half hi, slot lo.
+    const int Rl = lane >> 4, hi = (lane >> 3) & 1, lo = lane & 7;
+    uint32_t a_off[2][2], w_off[2][2];                  // byte offsets [half][q]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int rr = h * 128 + (wave * 2 + q) * 8 + 2 * Rl + (hi ^ q);
+            const int ch = lo ^ (q * 4 + Rl);
+            int m = m0 + rr;
+            m = m < g.M ? m : g.M - 1;
+            a_off[h][q] = ((uint32_t)m * (uint32_t)g.lda + ch * 8) * 2u;
+            w_off[h][q] = ((uint32_t)(n0 + rr) * (uint32_t)g.K + ch * 8) * 2u;
+        }
+    // half tile `half` (0/1) of operand `isw` for K tile kt -> slot of buffer kt & 1
+    auto issue = [&](int isw, int half, int kt) {
+        const char* src = (isw ? Wb : Ab) + (size_t)kt * (BK * 2);
+        unsigned char* dst = smem + (kt & 1) * BUF_BYTES + (isw ? SLOT_B0 : SLOT_A0) + half * HALF_BYTES + wave * 2048;
+        const uint32_t o0 = isw ? w_off[half][0] : a_off[half][0];
+        const uint32_t o1 = isw ? w_off[half][1] : a_off[half][1];
+        __builtin_amdgcn_global_load_lds((const void*)(src + o0), (lds_void_t*)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(src + o1), (lds_void_t*)(dst + 1024), 16, 0, 0);
+    };
+
+    // ---- fragment addressing (bank-conflict free image, kernels_gemm3.hip) ---------------------------
+    const int rowpart = (l15 >> 1) * 256 + ((l15 & 1) ^ ((l15 >> 3) & 1)) * 128;
+    const int x7 = (l15 >> 1) & 7;
+    const int ch0 = ((0 * 4 + lg) ^ x7) * 16;
+    const int ch1 = ((1 * 4 + lg) ^ x7) * 16;
+    const int a_rd = grp * 64 * 128 + rowpart;                     // + half*HALF_BYTES + i*2048 + ch
+    const int w_rd = SLOT_B0 + wc * 32 * 128 + rowpart;            // + half*HALF_BYTES + j*2048 + ch
+
+    f32x4_t acc[2][2][2][4];   // [qm][qn][j: n-frag][i: m-frag]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[a][b][j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8_t af[4][2], wf0[2][2], wf1[2][2];
+
+    auto read_a = [&](const unsigned char* sb, int half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *reinterpret_cast<const bf16x8_t*>(sb + a_rd + half * HALF_BYTES + i * 2048 + ch0);
+            af[i][1] = *reinterpret_cast<const bf16x8_t*>(sb + a_rd + half * HALF_BYTES + i * 2048 + ch1);
+        }
+    };
+    auto read_w = [&](const unsigned char* sb, int half, bf16x8_t (&wf)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wf[j][0] = *reinterpret_cast<const bf16x8_t*>(sb + w_rd + half * HALF_BYTES + j * 2048 + ch0);
+            wf[j][1] = *reinterpret_cast<const bf16x8_t*>(sb + w_rd + half * HALF_BYTES + j * 2048 + ch1);
+        }
+    };
+    auto mma = [&](f32x4_t (&c)[2][4], const bf16x8_t (&wf)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    c[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], af[i][kk], c[j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // MODE 0: steady state (t <= nk-3)   MODE 1: t == nk-2   MODE 2: t == nk-1
+    auto ktile = [&](auto mode_c, int t) {
+        constexpr int MODE = decltype(mode_c)::value;
+        const unsigned char* sb = smem + (t & 1) * BUF_BYTES;
+        // ---- P1
+        read_w(sb, 0, wf0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(sb, 0);
+        if constexpr (MODE <= 1) { issue(1, 1, t + 1); wait_vm<8>(); } else { wait_vm<2>(); }
+        P8_BARRIER();
+        mma(acc[0][0], wf0);
+        P8_BARRIER();
+        // ---- P2
+        read_w(sb, 1, wf1);
+        if constexpr (MODE <= 1) { issue(0, 1, t + 1); wait_vm<8>(); } else { wait_vm<0>(); }
+        P8_BARRIER();
+        mma(acc[0][1], wf1);
+        P8_BARRIER();
+        // ---- P3
+        read_a(sb, 1);
+        if constexpr (MODE == 0) { issue(0, 0, t + 2); wait_vm<8>(); }
+        P8_BARRIER();
+        mma(acc[1][1], wf1);
+        P8_BARRIER();
+        // ---- P4
+        if constexpr (MODE == 0) { issue(1, 0, t + 2); wait_vm<8>(); }
+        else if constexpr (MODE == 1) { wait_vm<4>(); }
+        P8_BARRIER();
+        mma(acc[1][0], wf0);
+        P8_BARRIER();
+    };
+
+    const int nk = g.K / BK;                                       // >= 2 (launcher)
+    issue(0, 0, 0); issue(1, 0, 0); issue(1, 1, 0); issue(0, 1, 0); issue(0, 0, 1); issue(1, 0, 1);
+    wait_vm<8>();                                                  // A0(0), B0(0) of this wave have landed
+    P8_BARRIER();
+    if (grp == 1) P8_BARRIER();                                    // group 1 runs one barrier behind
+    for (int t = 0; t < nk - 2; ++t) ktile(std::integral_constant<int, 0>{}, t);
+    ktile(std::integral_constant<int, 1>{}, nk - 2);
+    ktile(std::integral_constant<int, 2>{}, nk - 1);
+    if (grp == 0) P8_BARRIER();
+
+    // ---- epilogue through LDS: slab = 128 rows (qm) x WCOL columns ---------------------------------
+    constexpr int NQN = sizeof(TOut) == 2 ? 2 : 1;                 // weight halves per slab
+    constexpr int WCOL = 128 * NQN;
+    constexpr int EPC = 16 / (int)sizeof(TOut);                    // elements per 16-byte chunk
+    constexpr int EPS = WCOL + EPC;                                // padded row stride (elements)
+    constexpr int CPR = WCOL / EPC;                                // chunks per row
+    static_assert(128 * EPS * sizeof(TOut) <= LDS_BYTES, "epilogue slab does not fit");
+    TOut* ep = reinterpret_cast<TOut*>(smem);
+    TOut* __restrict__ C = reinterpret_cast<TOut*>(g.C);
+
+    f32x4_t bias4[2][2];
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            bias4[qn][j] = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + n0 + qn * 128 + wc * 32 + j * 16 + lg * 4)
+                                  : f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+        for (int s = 0; s < 2 / NQN; ++s) {
+#pragma unroll
+            for (int u = 0; u < NQN; ++u) {
+                const int qn = s * NQN + u;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int nl = u * 128 + wc * 32 + j * 16 + lg * 4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = apply_act_t<ACT>(acc[qm][qn][j][i][r] + bias4[qn][j][r]);
+                        TOut* p = ep + (grp * 64 + i * 16 + l15) * EPS + nl;
+                        if constexpr (sizeof(TOut) == 4) {
+                            *reinterpret_cast<f32x4_t*>(p) = f32x4_t{v[0], v[1], v[2], v[3]};
+                        } else {
+                            uint2 t2;
+                            t2.x = pack2bf(v[0], v[1]);
+                            t2.y = pack2bf(v[2], v[3]);
+                            *reinterpret_cast<uint2*>(p) = t2;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int q = 0; q < 128 * CPR / 512; ++q) {
+                const int chunk = tid + q * 512;
+                const int row = chunk / CPR, cc = chunk % CPR;
+                const int m = m0 + qm * 128 + row;
+                const int n = n0 + s * WCOL + cc * EPC;
+                if (m < g.M) {
+                    if constexpr (sizeof(TOut) == 4) {
+                        f32x4_t v = *reinterpret_cast<const f32x4_t*>(ep + row * EPS + cc * EPC);
+                        if (g.res) {
+                            const f32x4_t rr = *reinterpret_cast<const f32x4_t*>(g.res + (size_t)m * g.ldr + n);
+                            v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+                        }
+                        *reinterpret_cast<f32x4_t*>(C + (size_t)m * g.ldc + n) = v;
+                    } else {
+                        u32x4_t v = *reinterpret_cast<const u32x4_t*>(ep + row * EPS + cc * EPC);
+                        if (g.res) {
+                            const float* rp = g.res + (size_t)m * g.ldr + n;
+                            const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(rp);
+                            const f32x4_t r1 = *reinterpret_cast<const f32x4_t*>(rp + 4);
+                            float f[8];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                f[2 * e] = __uint_as_float(v[e] << 16);
+                                f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { f[e] += r0[e]; f[4 + e] += r1[e]; }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = pack2bf(f[2 * e], f[2 * e + 1]);
+                        }
+                        *reinterpret_cast<u32x4_t*>(C + (size_t)m * g.ldc + n) = v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+}  // namespace
+
+template <typename TOut>
+static void launch_p8_t(const GemmArgs& g, hipStream_t s) {
+    switch (g.act) {
+        case GITMI_ACT_QUICKGELU:
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_QUICKGELU>), dim3(g.nwg), dim3(512), 0, s, g); break;
+        case GITMI_ACT_GELU_ERF:
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_GELU_ERF>), dim3(g.nwg), dim3(512), 0, s, g); break;
+        default:
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_NONE>), dim3(g.nwg), dim3(512), 0, s, g); break;
+    }
+}
+
+bool gemm_p8_supports(const GemmArgs& g) {
+    return g.K % BK == 0 && g.K >= 2 * BK && g.N % BN == 0 &&
+           (double)g.M * g.lda * 2.0 < 4.0e9 && (double)g.N * g.K * 2.0 < 4.0e9;
+}
+
+hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s) {
+    const int tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = g.N / BN;
+    int ng = 1;
+    const double wbytes = (double)g.N * g.K * 2.0;
+    while (ng < 8 && wbytes / ng > 2.5e6 && ng * 2 <= g.tiles_n && 8 / (ng * 2) <= tiles_m) ng *= 2;
+    if (8 / ng > tiles_m) ng = 8;
+    if (ng > g.tiles_n) ng = 1;
+    g.ng = ng;
+    const int mg = 8 / ng;
+    int max_cnt = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int gn = x % ng, gm = x / ng;
+        const int nn = (gn + 1) * g.tiles_n / ng - gn * g.tiles_n / ng;
+        const int mm = (gm + 1) * tiles_m / mg - gm * tiles_m / mg;
+        max_cnt = nn * mm > max_cnt ? nn * mm : max_cnt;
+    }
+    g.nwg = 8 * max_cnt;
+    if (out_f32) launch_p8_t<float>(g, s);
+    else launch_p8_t<bf16_t>(g, s);
+    return hipGetLastError();
+}
+
+}  // namespace gitmi

@@ -42,15 +42,22 @@ def main():
         if use_res:
             ref = ref + res[:512]
         line = f"{name:10s} M={M} N={N} K={K} out={'f32' if odt == torch.float32 else 'bf16'}:"
+        base = None
         for impl in impls:
             E.set_gemm_impl(impl)
             out = E.op_gemm(A, W, bias, res, act, odt)
+            if base is None:
+                base = out.clone()
             err = (out[:512].float() - ref).abs().max().item()
             tail = (out[-64:].float() - (lambda r: r)(
                 (A[-64:].float() @ W.float().t() + bias))).abs().max().item() if (act == 0 and not use_res) else 0.0
             ms = bench(lambda: E.op_gemm(A, W, bias, res, act, odt))
             tf = 2.0 * M * N * K / ms / 1e9
-            line += f"  impl{impl}: {ms*1e3:8.1f}us {tf:7.1f}TF err={err:.3g}/{tail:.3g}"
+            # same K order in every variant -> bitwise equal to the first one; a rerun after the timing loop screens races
+            again = E.op_gemm(A, W, bias, res, act, odt)
+            dv = (out.float() - base.float()).abs().max().item()
+            dr = (again.float() - out.float()).abs().max().item()
+            line += f"  impl{impl}: {ms*1e3:8.1f}us {tf:7.1f}TF err={err:.3g}/{tail:.3g} dbase={dv:.3g} drerun={dr:.3g}"
         print(line, flush=True)
     E.set_gemm_impl(-1)
 
