@@ -56,7 +56,8 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     else if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <typename TOut, int ACT>
+// DBG (measurement builds only): 1 no global stores / residual reads, 2 no epilogue, 4 no ds_reads / MFMAs, 8 no loads
+template <typename TOut, int ACT, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
@@ -66,7 +67,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     const int grp = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, lg = lane >> 4;
 
-    // ---- tile of this workgroup: 2-D partition of the tile grid over the 8 XCDs (see kernels_gemm3.hip)
+    // ---- tile of this workgroup.  Workgroup b runs on XCD b % 8 (observed; only speed depends on it).  The N tiles
+    // are cut into ng groups; the 8/ng XCDs of a group share its (M-major, N-fastest) tile list in contiguous,
+    // equally long chunks, so that no XCD needs an extra round of its 32 CUs because of an uneven rectangular split
+    // (450 tiles: 57 per XCD instead of 65 on one of them) while its tiles still share activation / weight panels.
     int tile_m, tile_n;
     {
         const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -74,11 +78,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         const int gn = x % ng, gm = x / ng;
         const int tiles_m = (g.M + BM - 1) / BM;
         const int n_lo = gn * g.tiles_n / ng, n_hi = (gn + 1) * g.tiles_n / ng;
-        const int m_lo = gm * tiles_m / mg, m_hi = (gm + 1) * tiles_m / mg;
         const int nn = n_hi - n_lo;
-        if (nn <= 0 || idx >= nn * (m_hi - m_lo)) return;      // surplus workgroup of an uneven split
-        tile_m = m_lo + idx / nn;
-        tile_n = n_lo + idx % nn;
+        const int tg = tiles_m * nn;
+        const int lo_t = gm * tg / mg, hi_t = (gm + 1) * tg / mg;
+        if (idx >= hi_t - lo_t) return;                         // surplus workgroup
+        const int L = lo_t + idx;
+        tile_m = L / nn;
+        tile_n = n_lo + L % nn;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -102,6 +108,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         }
     // half tile `half` (0/1) of operand `isw` for K tile kt -> slot of buffer kt & 1
     auto issue = [&](int isw, int half, int kt) {
+        if constexpr (DBG & 8) return;
         const char* src = (isw ? Wb : Ab) + (size_t)kt * (BK * 2);
         unsigned char* dst = smem + (kt & 1) * BUF_BYTES + (isw ? SLOT_B0 : SLOT_A0) + half * HALF_BYTES + wave * 2048;
         const uint32_t o0 = isw ? w_off[half][0] : a_off[half][0];
@@ -131,6 +138,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     bf16x8_t af[4][2], wf0[2][2], wf1[2][2];
 
     auto read_a = [&](const unsigned char* sb, int half) {
+        if constexpr (DBG & 4) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             af[i][0] = *reinterpret_cast<const bf16x8_t*>(sb + a_rd + half * HALF_BYTES + i * 2048 + ch0);
@@ -138,6 +146,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         }
     };
     auto read_w = [&](const unsigned char* sb, int half, bf16x8_t (&wf)[2][2]) {
+        if constexpr (DBG & 4) return;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             wf[j][0] = *reinterpret_cast<const bf16x8_t*>(sb + w_rd + half * HALF_BYTES + j * 2048 + ch0);
@@ -145,6 +154,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         }
     };
     auto mma = [&](f32x4_t (&c)[2][4], const bf16x8_t (&wf)[2][2]) {
+        if constexpr (DBG & 4) return;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -208,6 +218,19 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     TOut* ep = reinterpret_cast<TOut*>(smem);
     TOut* __restrict__ C = reinterpret_cast<TOut*>(g.C);
 
+    if constexpr (DBG & 2) {
+        float sum = 0.f;                                 // keeps every accumulator live
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sum += acc[a][b][j][i][0] + acc[a][b][j][i][1] + acc[a][b][j][i][2] + acc[a][b][j][i][3];
+        if (sum == 12345.678f) C[0] = (TOut)0;
+        return;
+    }
     f32x4_t bias4[2][2];
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn)
@@ -250,7 +273,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                 const int row = chunk / CPR, cc = chunk % CPR;
                 const int m = m0 + qm * 128 + row;
                 const int n = n0 + s * WCOL + cc * EPC;
-                if (m < g.M) {
+                if (m < g.M && !(DBG & 1)) {
                     if constexpr (sizeof(TOut) == 4) {
                         f32x4_t v = *reinterpret_cast<const f32x4_t*>(ep + row * EPS + cc * EPC);
                         if (g.res) {
@@ -287,6 +310,15 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 
 template <typename TOut>
 static void launch_p8_t(const GemmArgs& g, hipStream_t s) {
+    if (g.dbg) {      // measurement builds (tools/gemm_dbg.py); act is ignored
+        switch (g.dbg) {
+            case 1: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 1>), dim3(g.nwg), dim3(512), 0, s, g); return;
+            case 2: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 2>), dim3(g.nwg), dim3(512), 0, s, g); return;
+            case 6: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 6>), dim3(g.nwg), dim3(512), 0, s, g); return;
+            case 10: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 10>), dim3(g.nwg), dim3(512), 0, s, g); return;
+            default: break;
+        }
+    }
     switch (g.act) {
         case GITMI_ACT_QUICKGELU:
             hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_QUICKGELU>), dim3(g.nwg), dim3(512), 0, s, g); break;
@@ -305,19 +337,20 @@ bool gemm_p8_supports(const GemmArgs& g) {
 hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s) {
     const int tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = g.N / BN;
+    // N groups: smallest power of two that brings an XCD's share of W under ~2.5 MB (it stays L2 resident while
+    // activation panels stream through)
     int ng = 1;
     const double wbytes = (double)g.N * g.K * 2.0;
-    while (ng < 8 && wbytes / ng > 2.5e6 && ng * 2 <= g.tiles_n && 8 / (ng * 2) <= tiles_m) ng *= 2;
-    if (8 / ng > tiles_m) ng = 8;
-    if (ng > g.tiles_n) ng = 1;
+    while (ng < 8 && wbytes / ng > 2.5e6 && ng * 2 <= g.tiles_n) ng *= 2;
     g.ng = ng;
     const int mg = 8 / ng;
     int max_cnt = 0;
     for (int x = 0; x < 8; ++x) {
         const int gn = x % ng, gm = x / ng;
         const int nn = (gn + 1) * g.tiles_n / ng - gn * g.tiles_n / ng;
-        const int mm = (gm + 1) * tiles_m / mg - gm * tiles_m / mg;
-        max_cnt = nn * mm > max_cnt ? nn * mm : max_cnt;
+        const int tg = tiles_m * nn;
+        const int cnt = (gm + 1) * tg / mg - gm * tg / mg;
+        max_cnt = cnt > max_cnt ? cnt : max_cnt;
     }
     g.nwg = 8 * max_cnt;
     if (out_f32) launch_p8_t<float>(g, s);
