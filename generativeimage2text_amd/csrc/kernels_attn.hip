@@ -14,6 +14,7 @@
 // text keys <= their own position.
 #include "gitmi_common.h"
 #include "launchers.h"
+#include <type_traits>
 
 namespace gitmi {
 
@@ -253,6 +254,184 @@ __global__ __launch_bounds__(256) void attn_full_mfma_kernel(AttnFullArgs a) {
                 *reinterpret_cast<uint2*>(op + dt * 16 + lg * 4) = tt;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Single-pass MFMA kernel for SHORT sequences (N <= 16*NSUB, NSUB = 13 for the 197 tokens of ViT-B/16 at 224 px,
+// 17 for the 257 of ViT-L/14): grid = (H, B), one workgroup per (image, head).
+// The whole K ([key][dim]) and V^T ([dim][key]) of the head are staged in LDS ONCE (60 / 75 KiB, one
+// __syncthreads in the kernel); a wave then takes two 16-query tiles at a time through
+//     S^T = K . Q^T  over ALL keys (accumulators stay in registers: 2 x NSUB x 4 floats per lane),
+//     one max / exp2 / sum per lane (no running rescale: every key is present), O^T = V^T . P^T.
+// Against the 64-key flash kernel above: no per-tile barriers and load round trips, no online rescaling
+// (half the VALU work per score), and only ceil(N/16) key sub-tiles instead of ceil(N/64)*4.
+// Same operand conventions as attn_full_mfma_kernel (swapped products, permuted key order inside a 32-key block).
+// ---------------------------------------------------------------------------------------
+template <int NSUB>
+__global__ __launch_bounds__(256, 2) void attn_full_mfma_short_kernel(AttnFullArgs a) {
+    constexpr int NK = NSUB * 16;               // padded keys of the first product
+    constexpr int NB = (NSUB + 1) / 2;          // 32-key blocks of the second product
+    constexpr int LDV = NB * 32 + 8;            // V^T row stride (bf16): 16 B x odd -> conflict-free b64 reads
+    static_assert((LDV / 8) % 2 == 1, "V^T row stride must be an odd multiple of 16 bytes");
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[NK * FA_LDK];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[HD * LDV];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q);
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k);
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v);
+    bf16_t* O = reinterpret_cast<bf16_t*>(a.out);
+    const size_t base_row = (size_t)b * a.N;
+
+    // ---- stage K: 16-byte chunks, rows >= N are copies of the last row (masked below) ------------
+#pragma unroll
+    for (int it = 0; it < (NK * 8 + 255) / 256; ++it) {
+        int idx = tid + it * 256;
+        const bool ok = idx < NK * 8;
+        idx = ok ? idx : NK * 8 - 1;
+        const int key = idx >> 3, c = idx & 7;
+        const int kr = key < a.N ? key : a.N - 1;
+        const u32x4_t kc = *reinterpret_cast<const u32x4_t*>(K + (base_row + kr) * a.ldk + h * HD + c * 8);
+        if (ok) *reinterpret_cast<u32x4_t*>(Ks + key * FA_LDK + c * 8) = kc;
+    }
+    // ---- stage V^T: a task = 4 consecutive keys x 8 dims -> eight 8-byte stores; keys >= N are zeros ----
+#pragma unroll
+    for (int it = 0; it < (NB * 8 * 8 + 255) / 256; ++it) {
+        int task = tid + it * 256;
+        const bool ok = task < NB * 8 * 8;
+        task = ok ? task : NB * 8 * 8 - 1;
+        const int kg = task % (NB * 8), c = task / (NB * 8);     // key group fastest: conflict-free LDS stores
+        u32x4_t vc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = kg * 4 + e;
+            const int kr = key < a.N ? key : a.N - 1;
+            vc[e] = *reinterpret_cast<const u32x4_t*>(V + (base_row + kr) * a.ldv + h * HD + c * 8);
+            if (key >= a.N) vc[e] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+        if (ok) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {                        // dims c*8 + 2w, c*8 + 2w + 1
+                uint2 even, odd;
+                even.x = (vc[0][w] & 0xffffu) | (vc[1][w] << 16);
+                even.y = (vc[2][w] & 0xffffu) | (vc[3][w] << 16);
+                odd.x = (vc[0][w] >> 16) | (vc[1][w] & 0xffff0000u);
+                odd.y = (vc[2][w] >> 16) | (vc[3][w] & 0xffff0000u);
+                *reinterpret_cast<uint2*>(Vt + (c * 8 + 2 * w) * LDV + kg * 4) = even;
+                *reinterpret_cast<uint2*>(Vt + (c * 8 + 2 * w + 1) * LDV + kg * 4) = odd;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int nqt = (a.N + 15) >> 4;
+    const float c2 = a.scale * 1.4426950408889634f;           // exp(scale * (s - m)) = exp2(c2 * s - c2 * m)
+
+    auto process = [&](auto nt_c, int t0) {
+        constexpr int NT = decltype(nt_c)::value;
+        bf16x8_t qf[NT][2];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            int qr = (t0 + 4 * u) * 16 + l15;
+            qr = qr < a.N ? qr : a.N - 1;
+            const bf16_t* qp = Q + (base_row + qr) * a.ldq + h * HD + lg * 8;
+            qf[u][0] = *reinterpret_cast<const bf16x8_t*>(qp);
+            qf[u][1] = *reinterpret_cast<const bf16x8_t*>(qp + 32);
+        }
+        // ---- S^T over all keys --------------------------------------------------------------
+        f32x4_t sacc[NT][NSUB];
+#pragma unroll
+        for (int st_ = 0; st_ < NSUB; ++st_) {
+            const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t*>(Ks + (st_ * 16 + l15) * FA_LDK + lg * 8);
+            const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t*>(Ks + (st_ * 16 + l15) * FA_LDK + 32 + lg * 8);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                sacc[u][st_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[u][0], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                sacc[u][st_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[u][1], sacc[u][st_], 0, 0, 0);
+            }
+        }
+        // ---- softmax: the lane holds keys st*16 + lg*4 + r of its query; only the last sub-tile can hold keys >= N
+        float inv_l[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if ((NSUB - 1) * 16 + lg * 4 + r >= a.N) sacc[u][NSUB - 1][r] = -INFINITY;
+            float m = -INFINITY;
+#pragma unroll
+            for (int st_ = 0; st_ < NSUB; ++st_)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, sacc[u][st_][r]);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const float mc = m * c2;
+            float psum = 0.f;
+#pragma unroll
+            for (int st_ = 0; st_ < NSUB; ++st_)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[u][st_][r] * c2 - mc);
+                    sacc[u][st_][r] = p;
+                    psum += p;
+                }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            inv_l[u] = 1.0f / psum;
+        }
+        // ---- O^T = V^T . P^T ------------------------------------------------------------------
+        f32x4_t o_acc[NT][4];
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o_acc[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            bf16x8_t pf[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                union { bf16x8_t v; uint32_t w[4]; } pk;
+                pk.w[0] = pack2bf(sacc[u][2 * blk][0], sacc[u][2 * blk][1]);
+                pk.w[1] = pack2bf(sacc[u][2 * blk][2], sacc[u][2 * blk][3]);
+                const bool has1 = 2 * blk + 1 < NSUB;              // odd NSUB: the last block has one sub-tile
+                const int s1 = has1 ? 2 * blk + 1 : 0;
+                pk.w[2] = has1 ? pack2bf(sacc[u][s1][0], sacc[u][s1][1]) : 0u;
+                pk.w[3] = has1 ? pack2bf(sacc[u][s1][2], sacc[u][s1][3]) : 0u;
+                pf[u] = pk.v;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                union { bf16x8_t v; uint2 h2[2]; } vf;
+                const bf16_t* vp = Vt + (dt * 16 + l15) * LDV + blk * 32 + lg * 4;
+                vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
+                vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 16);
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    o_acc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[u], o_acc[u][dt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int qr = (t0 + 4 * u) * 16 + l15;
+            if (qr < a.N) {
+                bf16_t* op = O + (base_row + qr) * a.ldo + h * HD;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    uint2 tt;
+                    tt.x = pack2bf(o_acc[u][dt][0] * inv_l[u], o_acc[u][dt][1] * inv_l[u]);
+                    tt.y = pack2bf(o_acc[u][dt][2] * inv_l[u], o_acc[u][dt][3] * inv_l[u]);
+                    *reinterpret_cast<uint2*>(op + dt * 16 + lg * 4) = tt;
+                }
+            }
+        }
+    };
+
+    // wave w owns query tiles w, w+4, w+8, ...; two at a time
+    for (int t0 = wave; t0 < nqt; t0 += 8) {
+        if (t0 + 4 < nqt) process(std::integral_constant<int, 2>{}, t0);
+        else process(std::integral_constant<int, 1>{}, t0);
     }
 }
 
@@ -546,6 +725,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
 hipError_t launch_attn_full(const AttnFullArgs& a, int B, bool is_f32, int impl, hipStream_t s) {
     if (B <= 0 || a.N <= 0) return hipSuccess;
     if (impl == 1) {
+        if (is_f32) return hipErrorInvalidValue;
+        const int nsub = (a.N + 15) / 16;
+        if (nsub == 13) hipLaunchKernelGGL(attn_full_mfma_short_kernel<13>, dim3(a.H, B), dim3(256), 0, s, a);
+        else if (nsub == 17) hipLaunchKernelGGL(attn_full_mfma_short_kernel<17>, dim3(a.H, B), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(attn_full_mfma_kernel, dim3((a.N + 255) / 256, a.H, B), dim3(256), 0, s, a);
+    } else if (impl == 2) {                        // the 64-key flash kernel, forced (A/B and tests)
         if (is_f32) return hipErrorInvalidValue;
         hipLaunchKernelGGL(attn_full_mfma_kernel, dim3((a.N + 255) / 256, a.H, B), dim3(256), 0, s, a);
     } else if (is_f32) {

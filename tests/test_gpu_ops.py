@@ -109,7 +109,8 @@ def _attn_ref(qkv, B, N, H):
     return (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * N, D)
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 17, 2), (3, 197, 12), (1, 257, 16), (2, 300, 3), (1, 1182, 2), (1, 64, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 17, 2), (3, 197, 12), (1, 257, 16), (2, 300, 3), (1, 1182, 2), (1, 64, 1),
+                                   (2, 193, 3), (2, 208, 2), (2, 272, 2), (1, 209, 1)])
 def test_attention_full(B, N, H):
     from generativeimage2text_amd import engine as E
     qkv = _rand(B * N, 3 * H * 64, seed=11, scale=1.5)
@@ -118,7 +119,7 @@ def test_attention_full(B, N, H):
     assert (out - ref).abs().max().item() < 2e-5
     qb = qkv.bfloat16()
     ref_b = _attn_ref(qb.float(), B, N, H)
-    for impl in (0, 1):
+    for impl in (0, 1, 2):      # fp32-math VALU twin | auto (single-pass kernel for 193..208 / 257..272 keys) | 64-key flash
         out_b = E.op_attention(qb.cuda(), B, N, H, impl=impl).cpu().double()
         err = (out_b - ref_b).abs().max().item()
         assert err < 3e-2, (impl, err)
@@ -135,8 +136,9 @@ def test_attention_softmax_rescale_branch():
     assert (out - ref).abs().max().item() < 5e-5
     qb = qkv.bfloat16()
     ref_b = _attn_ref(qb.float(), B, N, H)
-    out_b = E.op_attention(qb.cuda(), B, N, H, impl=1).cpu().double()
-    assert (out_b - ref_b).abs().max().item() < 5e-2
+    for impl in (1, 2):         # 200 keys: single-pass kernel (no rescale at all) and the online-softmax flash kernel
+        out_b = E.op_attention(qb.cuda(), B, N, H, impl=impl).cpu().double()
+        assert (out_b - ref_b).abs().max().item() < 5e-2, impl
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 768, 768), (64, 2304, 768), (64, 30522, 768), (256, 3072, 768),
