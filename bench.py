@@ -97,7 +97,7 @@ def pmc_traffic(kernel_substr: str):
     if not vals:
         return None
     return {"bytes_per_launch": sum(vals) / len(vals), "source": os.path.relpath(files[-1], ROOT),
-            "note": "2*FETCH_SIZE + WRITE_SIZE, averaged over the gemm_ring kernel variants"}
+            "note": "2*FETCH_SIZE + WRITE_SIZE per dispatch, averaged over the profiled launches of this kernel"}
 
 
 def main():
@@ -215,11 +215,11 @@ def main():
         avg_ms = prof["vit_gemm_ms"] / n
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         result["roofline"] = {
-            "kernel": "gitmi::gemm_ring_kernel / gemm_ring256_kernel <bf16> (the 49 image-encoder GEMM launches)"
+            "kernel": "gitmi::gemm_p8_kernel <bf16> (the 49 image-encoder GEMM launches)"
                       if args.precision == "bf16" else "gitmi::gemm_kernel<f32>",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "traffic_detail": pmc_traffic("gemm_ring"),
+            "traffic_detail": pmc_traffic("gemm_p8"),
             "launches_per_step": prof["vit_gemm_launches"], "avg_launch_ms": round(avg_ms, 4),
             "flops_per_launch": flops_per_launch,
             "method": "HIP events around each launch on the launch stream, eager (no graph) pass after the timed region",
