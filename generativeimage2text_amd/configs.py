@@ -33,6 +33,15 @@ class GitModelConfig:
     def n_tok(self) -> int:
         return (self.image_size // self.patch) ** 2 + 1
 
+    @property
+    def max_image_hw(self):
+        """Largest input the engine is sized for: MinMaxResizeForTest(test_crop_size, test_respect_ratio_max) yields
+        short side <= test_crop_size and long side <= test_respect_ratio_max (inference.py:29-64, 111-117); models
+        without it only see image_size x image_size."""
+        if self.test_respect_ratio_max is None:
+            return None
+        return (int(self.image_size), int(self.test_respect_ratio_max))
+
 
 _ENCODERS = {
     # model.py:64-67 name_map -> CLIP VisualTransformer(input_resolution, patch, width, layers, heads, out)

@@ -76,8 +76,12 @@ struct gitmi_engine {
     std::map<std::string, HostTensor> host_w;
     std::vector<void*> allocs;
 
-    // derived dims
-    int N = 0, g = 0, Kp = 0, Kp_pad = 0;
+    // derived dims: N/gh/gw/H/W describe the CURRENT input resolution (gitmi_set_image_shape); *_nat the stored grid
+    int N = 0, gh = 0, gw = 0, H = 0, W = 0, Kp = 0, Kp_pad = 0;
+    int N_nat = 0, g_nat = 0, Nmax = 0;
+    size_t max_pixels = 0;
+    float* pos_var = nullptr;          // [Nmax, D] positional table resized to the current grid
+    const float* pos_cur = nullptr;    // pos (native grid) or pos_var
 
     // packed weights
     void* conv_w = nullptr;
@@ -130,9 +134,10 @@ struct gitmi_engine {
 
     // hipGraph cache for gitmi_generate
     struct GraphKey {
-        int B, F, P, kind, k, pn, T; double lp;
+        int B, F, P, kind, k, pn, T, H, W; double lp;
         bool operator==(const GraphKey& o) const {
-            return B == o.B && F == o.F && P == o.P && kind == o.kind && k == o.k && pn == o.pn && T == o.T && lp == o.lp;
+            return B == o.B && F == o.F && P == o.P && kind == o.kind && k == o.k && pn == o.pn && T == o.T &&
+                   H == o.H && W == o.W && lp == o.lp;
         }
     };
     bool graph_valid = false;
@@ -210,6 +215,7 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     if (c.vit_width % c.vit_heads || c.vit_width / c.vit_heads != 64) return fail("ViT head_dim must be 64");
     if (c.dec_hidden % c.dec_heads || c.dec_hidden / c.dec_heads != 64) return fail("decoder head_dim must be 64");
     if (c.image_size % c.patch) return fail("image_size must be a multiple of patch");
+    if (c.max_image_pixels < 0 || c.max_image_tokens < 0) return fail("negative image capacity");
     if (c.vit_width > 1024 || c.dec_hidden > 1024) return fail("hidden sizes above 1024 are not supported");
     if (c.vit_width % 64 || c.dec_hidden % 64 || c.dec_ffn % 64) return fail("hidden sizes must be multiples of 64");
     if (c.max_batch < 1 || c.max_beams < 1 || c.max_beams > 8 || c.max_frames < 1 || c.max_text_len < 2)
@@ -223,8 +229,11 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     e->f32 = c.precision == GITMI_PREC_F32;
     e->esz = e->f32 ? 4 : 2;
     e->attn_impl = e->f32 ? 0 : 1;
-    e->g = c.image_size / c.patch;
-    e->N = e->g * e->g + 1;
+    e->g_nat = e->gh = e->gw = c.image_size / c.patch;
+    e->N_nat = e->N = e->g_nat * e->g_nat + 1;
+    e->H = e->W = c.image_size;
+    e->Nmax = std::max(e->N_nat, c.max_image_tokens);
+    e->max_pixels = std::max((size_t)c.image_size * c.image_size, (size_t)c.max_image_pixels);
     e->Kp = 3 * c.patch * c.patch;
     e->Kp_pad = round_up(e->Kp, 64);
     if (const char* env = getenv("GITMI_ATTN_IMPL")) e->attn_impl = e->f32 ? 0 : atoi(env);
@@ -348,12 +357,13 @@ static int alloc_workspaces(gitmi_engine* e) {
     const gitmi_config& c = e->cfg;
     const size_t esz = e->esz;
     const int D = c.vit_width, d = c.dec_hidden;
-    const size_t Mv = (size_t)c.max_batch * c.max_frames * e->N;  // ViT rows: all frames of a call in one pass
-    const size_t Mp = (size_t)c.max_batch * c.max_frames * e->N;  // prefill rows
+    const size_t Mv = (size_t)c.max_batch * c.max_frames * e->Nmax;  // ViT rows: all frames of a call in one pass
+    const size_t Mp = (size_t)c.max_batch * c.max_frames * e->Nmax;  // prefill rows
     const size_t R = (size_t)c.max_batch * c.max_beams;
     const int T = c.max_text_len;
-    RCK(dev_alloc(e, &e->patches, (size_t)c.max_batch * c.max_frames * e->g * e->g * e->Kp_pad * esz));
-    RCK(dev_alloc_t(e, &e->patch_out, (size_t)c.max_batch * c.max_frames * e->g * e->g * D));
+    RCK(dev_alloc(e, &e->patches, (size_t)c.max_batch * c.max_frames * (e->Nmax - 1) * e->Kp_pad * esz));
+    RCK(dev_alloc_t(e, &e->patch_out, (size_t)c.max_batch * c.max_frames * (e->Nmax - 1) * D));
+    RCK(dev_alloc_t(e, &e->pos_var, (size_t)e->Nmax * D));
     RCK(dev_alloc_t(e, &e->v_x, Mv * D));
     RCK(dev_alloc(e, &e->v_h, Mv * D * esz));
     RCK(dev_alloc(e, &e->v_qkv, Mv * 3 * D * esz));
@@ -411,7 +421,7 @@ static int alloc_workspaces(gitmi_engine* e) {
     HIPCK(hipEventCreateWithFlags(&e->fence_out, hipEventDisableTiming));
     e->frame_stage.resize(c.max_frames);
     for (int f = 0; f < c.max_frames; ++f)
-        RCK(dev_alloc_t(e, &e->frame_stage[f], (size_t)c.max_batch * 3 * c.image_size * c.image_size));
+        RCK(dev_alloc_t(e, &e->frame_stage[f], (size_t)c.max_batch * 3 * e->max_pixels));
     return 0;
 }
 
@@ -430,7 +440,8 @@ extern "C" int gitmi_finalize_weights(gitmi_engine* e) {
         RCK(up_mat(e, "image_encoder.conv1.weight", D, e->Kp, e->Kp_pad, &e->conv_w));
     }
     RCK(up_f32(e, "image_encoder.class_embedding", {D}, &e->cls));
-    RCK(up_f32(e, "image_encoder.positional_embedding", {e->N, D}, &e->pos));
+    RCK(up_f32(e, "image_encoder.positional_embedding", {e->N_nat, D}, &e->pos));
+    e->pos_cur = e->pos;
     RCK(up_f32(e, "image_encoder.ln_pre.weight", {D}, &e->lnpre_g));
     RCK(up_f32(e, "image_encoder.ln_pre.bias", {D}, &e->lnpre_b));
     RCK(up_f32(e, "image_encoder.ln_post.weight", {D}, &e->lnpost_g));
@@ -512,10 +523,13 @@ extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
     HIPCK(hipSetDevice(src->device));
     gitmi_engine* e = new gitmi_engine();
     e->cfg = src->cfg; e->device = src->device; e->f32 = src->f32; e->esz = src->esz;
-    e->attn_impl = src->attn_impl; e->N = src->N; e->g = src->g; e->Kp = src->Kp; e->Kp_pad = src->Kp_pad;
+    e->attn_impl = src->attn_impl; e->Kp = src->Kp; e->Kp_pad = src->Kp_pad;
+    // a clone starts at the native resolution (its own gitmi_set_image_shape state and resized table)
+    e->N_nat = e->N = src->N_nat; e->g_nat = e->gh = e->gw = src->g_nat; e->H = e->W = src->cfg.image_size;
+    e->Nmax = src->Nmax; e->max_pixels = src->max_pixels;
     e->use_graph = src->use_graph; e->skinny = src->skinny;
     e->parent = src->parent ? src->parent : src;
-    e->conv_w = src->conv_w; e->cls = src->cls; e->pos = src->pos;
+    e->conv_w = src->conv_w; e->cls = src->cls; e->pos = src->pos; e->pos_cur = src->pos;
     e->lnpre_g = src->lnpre_g; e->lnpre_b = src->lnpre_b; e->lnpost_g = src->lnpost_g; e->lnpost_b = src->lnpost_b;
     e->vit = src->vit; e->temb = src->temb;
     e->vp_w = src->vp_w; e->vp_b = src->vp_b; e->vp_lng = src->vp_lng; e->vp_lnb = src->vp_lnb;
@@ -526,6 +540,30 @@ extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
     HIPCK(hipDeviceSynchronize());
     e->finalized = true;
     *out = e;
+    return 0;
+}
+
+// ---- input resolution (CLIP/model.py:243-251) ---------------------------------------------
+extern "C" int gitmi_set_image_shape(gitmi_engine* e, int H, int W, void* stream) {
+    if (!e) return fail("null engine");
+    if (!e->finalized) return fail("weights not finalized");
+    const gitmi_config& c = e->cfg;
+    if (H < c.patch || W < c.patch) return fail("image %dx%d is smaller than one %d-pixel patch", H, W, c.patch);
+    const int gh = H / c.patch, gw = W / c.patch;
+    if ((size_t)H * W > e->max_pixels)
+        return fail("image %dx%d exceeds the max_image_pixels capacity (%zu)", H, W, e->max_pixels);
+    if (gh * gw + 1 > e->Nmax)
+        return fail("a %dx%d token grid exceeds the max_image_tokens capacity (%d)", gh, gw, e->Nmax);
+    if (H == e->H && W == e->W) return 0;
+    HIPCK(hipSetDevice(e->device));
+    if (gh == e->g_nat && gw == e->g_nat) {
+        e->pos_cur = e->pos;
+    } else {
+        HIPCK(launch_pos_bicubic(e->pos, e->pos_var, e->g_nat, gh, gw, c.vit_width, (hipStream_t)stream));
+        e->pos_cur = e->pos_var;
+    }
+    e->H = H; e->W = W; e->gh = gh; e->gw = gw; e->N = gh * gw + 1;
+    e->have_feats = e->have_prefill = false;
     return 0;
 }
 
@@ -541,13 +579,13 @@ static int encode_frames_impl(gitmi_engine* e, const float* const* frames, int F
     // frame, decoder.py:847; per-image results are identical, the GEMMs just see M = F*B*197 rows)
     const int BI = F_eff * B;                // images in the pass
     const int M = BI * N;
-    const int g2 = e->g * e->g;
+    const int g2 = e->gh * e->gw;
     for (int fr = 0; fr < F_eff; ++fr)
         HIPCK(launch_im2col(frames[fr], (char*)e->patches + (size_t)fr * B * g2 * e->Kp_pad * e->esz, e->f32, B,
-                            c.image_size, c.patch, e->Kp, e->Kp_pad, s));
+                            e->H, e->W, c.patch, e->Kp, e->Kp_pad, s));
     RCK(gemm(e, s, e->patches, e->Kp_pad, e->conv_w, nullptr, nullptr, 0, e->patch_out, D, true, BI * g2, D, e->Kp_pad, 0,
              TAG_GEMM_VIT));
-    HIPCK(launch_vit_assemble_ln(e->patch_out, e->cls, e->pos, e->lnpre_g, e->lnpre_b, 1e-5f, e->v_x, BI, N, D, s));
+    HIPCK(launch_vit_assemble_ln(e->patch_out, e->cls, e->pos_cur, e->lnpre_g, e->lnpre_b, 1e-5f, e->v_x, BI, N, D, s));
     for (int l = 0; l < c.vit_layers; ++l) {
         const VitLayerW& L = e->vit[l];
         HIPCK(launch_layernorm(e->v_x, D, L.ln1g, L.ln1b, 1e-5f, nullptr, e->v_h, D, e->f32, nullptr, 0, M, D, 0, 0, 0, s));
@@ -882,13 +920,13 @@ extern "C" int gitmi_generate(gitmi_engine* e, const float* const* frames, int F
         HIPCK(hipEventRecord(e->fence_in, s));
         HIPCK(hipStreamWaitEvent(x, e->fence_in, 0));
     }
-    const size_t frame_bytes = (size_t)B * 3 * c.image_size * c.image_size * sizeof(float);
+    const size_t frame_bytes = (size_t)B * 3 * e->H * e->W * sizeof(float);
     const int F_eff = c.num_frames > 0 ? std::min(F, c.num_frames) : F;
     for (int f = 0; f < F_eff; ++f)
         HIPCK(hipMemcpyAsync(e->frame_stage[f], frames[f], frame_bytes, hipMemcpyDeviceToDevice, x));
     gitmi_engine::GraphKey key{};
     key.B = B; key.F = F_eff; key.P = P; key.kind = sp->kind; key.k = sp->beam_size; key.pn = sp->per_node_beam_size;
-    key.T = sp->max_steps; key.lp = sp->length_penalty;
+    key.T = sp->max_steps; key.H = e->H; key.W = e->W; key.lp = sp->length_penalty;
     if (!e->graph_valid || !(key == e->graph_key)) {
         destroy_graph(e);
         std::vector<const float*> fp(F_eff);
@@ -1041,5 +1079,16 @@ extern "C" int gitmi_preprocess_image(const uint8_t* rgb_hwc, int H, int W, int 
     const int nw = W <= H ? crop : (int)((double)crop * W / H);
     if (nw != W && (!tmp || tmp_bytes < (size_t)H * nw * 3)) return fail("preprocess: workspace must hold H * %d * 3 bytes", nw);
     HIPCK(launch_preprocess(rgb_hwc, H, W, crop, tmp, out_chw, (hipStream_t)stream));
+    return 0;
+}
+
+// MinMaxResizeForTest (inference.py:29-64) output: a plain resize to out_h x out_w (no crop) + ToTensor + Normalize.
+// The caller computes (out_h, out_w) with the reference's get_size() rule (generativeimage2text_amd/inference.py).
+extern "C" int gitmi_preprocess_image_to(const uint8_t* rgb_hwc, int H, int W, int out_h, int out_w, uint8_t* tmp,
+                                         size_t tmp_bytes, float* out_chw, void* stream) {
+    if (!rgb_hwc || !out_chw || H < 1 || W < 1 || out_h < 1 || out_w < 1) return fail("preprocess: bad argument");
+    if (out_w != W && (!tmp || tmp_bytes < (size_t)H * out_w * 3))
+        return fail("preprocess: workspace must hold H * %d * 3 bytes", out_w);
+    HIPCK(launch_resize_crop_norm(rgb_hwc, H, W, out_h, out_w, 0, 0, out_h, out_w, tmp, out_chw, (hipStream_t)stream));
     return 0;
 }

@@ -86,21 +86,68 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-// patches[(b*g*g + gy*g + gx), c*p*p + ky*p + kx] = img[b, c, gy*p + ky, gx*p + kx]; zero pad to Kpad
+// patches[(b*gh*gw + gy*gw + gx), c*p*p + ky*p + kx] = img[b, c, gy*p + ky, gx*p + kx]; zero pad to Kpad.
+// img is [B, C, H, W]; gh = H / p, gw = W / p (floor): like the stride-p convolution of CLIP/model.py:242 the
+// H % p bottom rows and W % p right columns are never read.
 template <typename TOut>
-__global__ void im2col_kernel(const float* __restrict__ img, TOut* __restrict__ out, int B, int C, int HW,
-                              int p, int g, int K, int Kpad) {
-    const size_t total = (size_t)B * g * g * Kpad;
+__global__ void im2col_kernel(const float* __restrict__ img, TOut* __restrict__ out, int B, int C, int H, int W,
+                              int p, int gh, int gw, int K, int Kpad) {
+    const size_t total = (size_t)B * gh * gw * Kpad;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(i % Kpad);
         const size_t prow = i / Kpad;
         float val = 0.f;
         if (k < K) {
             const int kx = k % p, ky = (k / p) % p, c = k / (p * p);
-            const int gx = (int)(prow % g), gy = (int)((prow / g) % g), b = (int)(prow / ((size_t)g * g));
-            val = img[(((size_t)b * C + c) * HW + gy * p + ky) * HW + gx * p + kx];
+            const int gx = (int)(prow % gw), gy = (int)((prow / gw) % gh), b = (int)(prow / ((size_t)gh * gw));
+            val = img[(((size_t)b * C + c) * H + gy * p + ky) * W + gx * p + kx];
         }
         st<TOut>(out + i, val);
+    }
+}
+
+// Positional embedding for a gh x gw token grid from the stored g x g one (CLIP/model.py:243-251:
+// F.interpolate(mode='bicubic', align_corners=False)): source coordinate (o + 0.5) * in/out - 0.5, cubic
+// convolution taps (A = -0.75) at floor-1 .. floor+2 with border-clamped indices, x first, then y; the class
+// row 0 is copied.  pos [g*g + 1, D] -> out [gh*gw + 1, D].  One thread per output element.
+__device__ __forceinline__ void cubic_taps(float t, float (&w)[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.0f, x3 = 2.0f - t, u = 1.0f - t;
+    w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    w[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+    w[2] = ((A + 2.0f) * u - (A + 3.0f)) * u * u + 1.0f;
+    w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+__global__ void pos_bicubic_kernel(const float* __restrict__ pos, float* __restrict__ out, int g, int gh, int gw, int D) {
+    const size_t total = ((size_t)gh * gw + 1) * D;
+    const float sy = (float)g / (float)gh, sx = (float)g / (float)gw;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const int n = (int)(i / D);
+        if (n == 0) { out[i] = pos[c]; continue; }
+        const int oy = (n - 1) / gw, ox = (n - 1) % gw;
+        const float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+        const float y0f = floorf(fy), x0f = floorf(fx);
+        float wy[4], wx[4];
+        cubic_taps(fy - y0f, wy);
+        cubic_taps(fx - x0f, wx);
+        const int y0 = (int)y0f, x0 = (int)x0f;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            int yy = y0 - 1 + a;
+            yy = yy < 0 ? 0 : (yy > g - 1 ? g - 1 : yy);
+            float row = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                int xx = x0 - 1 + b;
+                xx = xx < 0 ? 0 : (xx > g - 1 ? g - 1 : xx);
+                row += wx[b] * pos[((size_t)1 + (size_t)yy * g + xx) * D + c];
+            }
+            acc += wy[a] * row;
+        }
+        out[i] = acc;
     }
 }
 
@@ -240,16 +287,22 @@ hipError_t launch_layernorm(const float* x, int ldx, const float* gamma, const f
     return hipGetLastError();
 }
 
-hipError_t launch_im2col(const float* img, void* out, bool out_f32, int B, int HW, int p, int K, int Kpad,
+hipError_t launch_im2col(const float* img, void* out, bool out_f32, int B, int H, int W, int p, int K, int Kpad,
                          hipStream_t s) {
-    const int g = HW / p;
-    const size_t total = (size_t)B * g * g * Kpad;
+    const int gh = H / p, gw = W / p;
+    const size_t total = (size_t)B * gh * gw * Kpad;
     if (out_f32)
         hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, img, (float*)out, B,
-                           3, HW, p, g, K, Kpad);
+                           3, H, W, p, gh, gw, K, Kpad);
     else
         hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, img, (bf16_t*)out,
-                           B, 3, HW, p, g, K, Kpad);
+                           B, 3, H, W, p, gh, gw, K, Kpad);
+    return hipGetLastError();
+}
+
+hipError_t launch_pos_bicubic(const float* pos, float* out, int g, int gh, int gw, int D, hipStream_t s) {
+    const size_t total = ((size_t)gh * gw + 1) * D;
+    hipLaunchKernelGGL(pos_bicubic_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, pos, out, g, gh, gw, D);
     return hipGetLastError();
 }
 

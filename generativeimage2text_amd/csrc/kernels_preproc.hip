@@ -50,14 +50,14 @@ __global__ void resize_h_kernel(const uint8_t* __restrict__ in, uint8_t* __restr
     o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
 }
 
-// in: [H_in, W, 3] (after the horizontal pass) -> out fp32 [3, crop, crop] for the centre crop (top, left)
+// in: [H_in, W, 3] (after the horizontal pass) -> out fp32 [3, ch, cw] for the crop window at (top, left)
 __global__ void resize_v_crop_norm_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int H_in, int W,
-                                          int crop, int top, int left, const int* __restrict__ kk,
+                                          int ch, int cw, int top, int left, const int* __restrict__ kk,
                                           const int* __restrict__ bounds, int ksize, int identity_v, float m0, float m1,
                                           float m2, float d0, float d1, float d2) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
-    if (x >= crop) return;
+    if (x >= cw) return;
     const int yo = y + top, xi = x + left;
     int p0, p1, p2;
     if (identity_v) {                               // Pillow skips a pass whose size does not change
@@ -76,7 +76,7 @@ __global__ void resize_v_crop_norm_kernel(const uint8_t* __restrict__ in, float*
         }
         p0 = clip8(s0); p1 = clip8(s1); p2 = clip8(s2);
     }
-    const size_t plane = (size_t)crop * crop, o = (size_t)y * crop + x;
+    const size_t plane = (size_t)ch * cw, o = (size_t)y * cw + x;
     out[o] = ((float)p0 / 255.0f - m0) / d0;
     out[plane + o] = ((float)p1 / 255.0f - m1) / d1;
     out[2 * plane + o] = ((float)p2 / 255.0f - m2) / d2;
@@ -144,22 +144,17 @@ hipError_t get_coeffs(int in_size, int out_size, Coeffs* out) {
 
 }  // namespace
 
-// rgb: uint8 [H, W, 3] on the device; tmp: uint8 workspace of at least H * W_out * 3 bytes; out: fp32 [3, crop, crop]
-hipError_t launch_preprocess(const uint8_t* rgb, int H, int W, int crop, uint8_t* tmp, float* out, hipStream_t s) {
-    // torchvision Resize(int): shorter side -> crop, the other int(crop * long / short)
-    int nw, nh;
-    if (W <= H) { nw = crop; nh = (int)((double)crop * H / W); }
-    else { nw = (int)((double)crop * W / H); nh = crop; }
-    // CenterCrop offsets: int(round((size - crop) / 2.0)) with Python's round-half-even
-    auto pyround = [](double v) { return (int)std::nearbyint(v); };
-    const int left = pyround((nw - crop) / 2.0), top = pyround((nh - crop) / 2.0);
+// Pillow resize of rgb uint8 [H, W, 3] to nh x nw (BICUBIC), crop window (top, left, ch, cw) of the result,
+// ToTensor + Normalize -> out fp32 [3, ch, cw].  tmp: uint8 workspace of at least H * nw * 3 bytes (unused if nw == W).
+hipError_t launch_resize_crop_norm(const uint8_t* rgb, int H, int W, int nh, int nw, int top, int left, int ch, int cw,
+                                   uint8_t* tmp, float* out, hipStream_t s) {
     const uint8_t* hsrc = rgb;
     if (nw != W) {
-        Coeffs ch;
-        hipError_t e = get_coeffs(W, nw, &ch);
+        Coeffs chz;
+        hipError_t e = get_coeffs(W, nw, &chz);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(resize_h_kernel, dim3((nw + 127) / 128, H), dim3(128), 0, s, rgb, tmp, H, W, nw, ch.kk, ch.bounds,
-                           ch.ksize);
+        hipLaunchKernelGGL(resize_h_kernel, dim3((nw + 127) / 128, H), dim3(128), 0, s, rgb, tmp, H, W, nw, chz.kk, chz.bounds,
+                           chz.ksize);
         hsrc = tmp;
     }
     Coeffs cv;
@@ -168,10 +163,22 @@ hipError_t launch_preprocess(const uint8_t* rgb, int H, int W, int crop, uint8_t
         hipError_t e = get_coeffs(H, nh, &cv);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(resize_v_crop_norm_kernel, dim3((crop + 127) / 128, crop), dim3(128), 0, s, hsrc, out, H, nw, crop, top,
+    hipLaunchKernelGGL(resize_v_crop_norm_kernel, dim3((cw + 127) / 128, ch), dim3(128), 0, s, hsrc, out, H, nw, ch, cw, top,
                        left, cv.kk, cv.bounds, cv.ksize, identity_v, 0.48145466f, 0.4578275f, 0.40821073f, 0.26862954f,
                        0.26130258f, 0.27577711f);
     return hipGetLastError();
+}
+
+// Resize(crop, BICUBIC) -> CenterCrop(crop) -> ToTensor -> Normalize (inference.py:118-131)
+hipError_t launch_preprocess(const uint8_t* rgb, int H, int W, int crop, uint8_t* tmp, float* out, hipStream_t s) {
+    // torchvision Resize(int): shorter side -> crop, the other int(crop * long / short)
+    int nw, nh;
+    if (W <= H) { nw = crop; nh = (int)((double)crop * H / W); }
+    else { nw = (int)((double)crop * W / H); nh = crop; }
+    // CenterCrop offsets: int(round((size - crop) / 2.0)) with Python's round-half-even
+    auto pyround = [](double v) { return (int)std::nearbyint(v); };
+    const int left = pyround((nw - crop) / 2.0), top = pyround((nh - crop) / 2.0);
+    return launch_resize_crop_norm(rgb, H, W, nh, nw, top, left, crop, crop, tmp, out, s);
 }
 
 }  // namespace gitmi

@@ -44,8 +44,9 @@ hipError_t launch_splitk_ln(const float* partial, int S, const float* bias, cons
 hipError_t launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps,
                             const float* add_after, void* y_t, int ld_t, bool t_is_f32, float* y_f, int ld_f,
                             int rows, int D, int map_n_in, int map_n_out, int map_off, hipStream_t s);
-hipError_t launch_im2col(const float* img, void* out, bool out_f32, int B, int HW, int p, int K, int Kpad,
+hipError_t launch_im2col(const float* img, void* out, bool out_f32, int B, int H, int W, int p, int K, int Kpad,
                          hipStream_t s);
+hipError_t launch_pos_bicubic(const float* pos, float* out, int g, int gh, int gw, int D, hipStream_t s);
 hipError_t launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* gamma,
                                   const float* beta, float eps, float* X, int B, int N, int D, hipStream_t s);
 hipError_t launch_embed_ln(const int* ids, int ld_ids, int pos, const float* words, const float* positions,
@@ -106,5 +107,7 @@ hipError_t launch_load_ids(const long long* tokens, int R, int t, int* ids, int*
 
 // GPU image transform (Pillow-exact bicubic resize + centre crop + CLIP normalisation)
 hipError_t launch_preprocess(const unsigned char* rgb, int H, int W, int crop, unsigned char* tmp, float* out, hipStream_t s);
+hipError_t launch_resize_crop_norm(const uint8_t* rgb, int H, int W, int nh, int nw, int top, int left, int ch, int cw,
+                                   uint8_t* tmp, float* out, hipStream_t s);
 
 }  // namespace gitmi

@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_search_finish", "gitmi_profile_enable", "gitmi_profile_read", "gitmi_set_graph",
     "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_gemm_skinny",
     "gitmi_op_gemm_splitk_ln", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
+    "gitmi_set_image_shape", "gitmi_preprocess_image_to",
 ]
 
 
@@ -34,7 +35,7 @@ class GitmiConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "image_size", "patch", "vit_width", "vit_layers", "vit_heads", "dec_hidden", "dec_layers",
         "dec_heads", "dec_ffn", "vocab", "max_pos", "num_frames", "sos", "eos", "precision",
-        "max_batch", "max_beams", "max_frames", "max_text_len")]
+        "max_batch", "max_beams", "max_frames", "max_text_len", "max_image_pixels", "max_image_tokens")]
 
 
 class GitmiSearch(C.Structure):
@@ -96,12 +97,14 @@ def load_library() -> C.CDLL:
     lib.gitmi_debug_set_gemm_impl.argtypes = [i32]
     lib.gitmi_clone.argtypes = [vp, C.POINTER(vp)]
     lib.gitmi_preprocess_image.argtypes = [vp, i32, i32, i32, vp, C.c_size_t, vp, vp]
+    lib.gitmi_preprocess_image_to.argtypes = [vp, i32, i32, i32, i32, vp, C.c_size_t, vp, vp]
+    lib.gitmi_set_image_shape.argtypes = [vp, i32, i32, vp]
     lib.gitmi_op_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_gemm_splitk_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, i32, vp, vp, i32, i32, i32, vp]
     for name in EXPORTED_SYMBOLS:
         if name not in ("gitmi_last_error", "gitmi_destroy"):
             getattr(lib, name).restype = C.c_int
-    if lib.gitmi_abi_version() != 1:
+    if lib.gitmi_abi_version() != 2:
         raise GitmiError("libgitmi.so ABI version mismatch")
     _lib = lib
     return lib
@@ -128,7 +131,10 @@ class Engine:
     """One GIT engine on one GPU.  Mirrors what `get_git_model(...).cuda()` holds in the reference."""
 
     def __init__(self, model_cfg, precision: str = "bf16", max_batch: int = 64, max_beams: int = 4,
-                 max_frames: int = 1, max_text_len: int = 40, device: Optional[int] = None):
+                 max_frames: int = 1, max_text_len: int = 40, device: Optional[int] = None,
+                 max_image_hw: Optional[Tuple[int, int]] = None):
+        """max_image_hw: largest (H, W) input the engine must accept when images are not all image_size x image_size
+        (MinMaxResizeForTest models); default: the model config's max_image_hw, else the native square."""
         if not torch.cuda.is_available():
             raise GitmiError("no GPU visible: the GIT engine runs on MI355X (gfx950) only, there is no CPU fallback")
         self.lib = load_library()
@@ -142,8 +148,15 @@ class Engine:
         c.precision = {"bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32}[precision]
         c.max_batch, c.max_beams = int(max_batch), int(max_beams)
         c.max_frames, c.max_text_len = int(max_frames), int(max_text_len)
+        if max_image_hw is None:
+            max_image_hw = getattr(model_cfg, "max_image_hw", None)
+        if max_image_hw is not None:
+            mh, mw = int(max_image_hw[0]), int(max_image_hw[1])
+            c.max_image_pixels = mh * mw
+            c.max_image_tokens = (mh // c.patch) * (mw // c.patch) + 1
         self.c = c
-        self.n_tok = (c.image_size // c.patch) ** 2 + 1
+        self.n_tok = (c.image_size // c.patch) ** 2 + 1          # tokens per frame at the CURRENT input resolution
+        self._hw = (int(c.image_size), int(c.image_size))
         self._h = C.c_void_p()
         _ck(self.lib.gitmi_create(C.byref(c), self.device, C.byref(self._h)))
         self._finalized = False
@@ -156,7 +169,8 @@ class Engine:
         for keeping several batches in flight on different streams.  Keep `self` alive while it is used."""
         other = object.__new__(Engine)
         other.lib, other.device, other.cfg, other.precision, other.c = self.lib, self.device, self.cfg, self.precision, self.c
-        other.n_tok = self.n_tok
+        other.n_tok = (self.c.image_size // self.c.patch) ** 2 + 1
+        other._hw = (int(self.c.image_size), int(self.c.image_size))
         other._h = C.c_void_p()
         _ck(self.lib.gitmi_clone(self._h, C.byref(other._h)))
         other._finalized, other._cur_B, other._cur_F = True, 0, 0
@@ -189,11 +203,20 @@ class Engine:
         self._finalized = True
 
     # -- phases --------------------------------------------------------------------------------
+    def set_image_shape(self, H: int, W: int) -> None:
+        """Input resolution of the following calls (CLIP/model.py:243-251: token grid (H//patch) x (W//patch),
+        positional table resized on the device).  Called automatically from the frames' shape."""
+        if (H, W) != self._hw:
+            _ck(self.lib.gitmi_set_image_shape(self._h, int(H), int(W), _stream()))
+            self._hw = (int(H), int(W))
+            self.n_tok = (H // self.c.patch) * (W // self.c.patch) + 1
+
     def _frames_arg(self, frames: Sequence[torch.Tensor]) -> Tuple[C.Array, List[torch.Tensor], int]:
         keep = [f.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous() for f in frames]
-        B = keep[0].shape[0]
+        B, _, H, W = keep[0].shape
         for f in keep:
-            assert f.shape == (B, 3, self.c.image_size, self.c.image_size), f"frame shape {tuple(f.shape)}"
+            assert f.shape == (B, 3, H, W), f"frame shape {tuple(f.shape)}: all frames of a call share one resolution"
+        self.set_image_shape(H, W)
         arr = (C.c_void_p * len(keep))(*[f.data_ptr() for f in keep])
         return arr, keep, B
 
@@ -375,4 +398,18 @@ def preprocess_image(rgb_hwc: torch.Tensor, crop: int = 224) -> torch.Tensor:
     tmp = torch.empty(H * nw * 3, dtype=torch.uint8, device=rgb_hwc.device)
     out = torch.empty(3, crop, crop, dtype=torch.float32, device=rgb_hwc.device)
     _ck(lib.gitmi_preprocess_image(rgb_hwc.data_ptr(), H, W, crop, tmp.data_ptr(), tmp.numel(), out.data_ptr(), _stream()))
+    return out
+
+
+def preprocess_image_to(rgb_hwc: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+    """uint8 [H,W,3] device tensor -> fp32 [3,out_h,out_w]: Pillow-exact bicubic resize to (out_h, out_w), ToTensor,
+    Normalize -- the MinMaxResizeForTest branch of the reference transform (inference.py:113-116)."""
+    lib = load_library()
+    assert rgb_hwc.is_cuda and rgb_hwc.dtype == torch.uint8 and rgb_hwc.dim() == 3 and rgb_hwc.shape[2] == 3
+    rgb_hwc = rgb_hwc.contiguous()
+    H, W = int(rgb_hwc.shape[0]), int(rgb_hwc.shape[1])
+    tmp = torch.empty(H * out_w * 3, dtype=torch.uint8, device=rgb_hwc.device)
+    out = torch.empty(3, out_h, out_w, dtype=torch.float32, device=rgb_hwc.device)
+    _ck(lib.gitmi_preprocess_image_to(rgb_hwc.data_ptr(), H, W, int(out_h), int(out_w), tmp.data_ptr(), tmp.numel(),
+                                      out.data_ptr(), _stream()))
     return out

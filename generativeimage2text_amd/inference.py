@@ -6,7 +6,8 @@ Differences forced by the environment, not by design:
     Resize/CenterCrop on PIL images call PIL themselves), checkpoints are read with torch.load.
   * the WordPiece vocabulary is looked up offline (HF cache, $GIT_VOCAB or aux_data/vocab.txt);
     without one the tasks still run and report token ids instead of text.
-  * images are batched (the reference runs batch 1, one host sync per image) and ranks return
+  * images are batched (the reference runs batch 1, one host sync per image; models with test_respect_ratio_max
+    keep batch 1 because every image has its own resolution) and ranks return
     their results through one RCCL gather instead of the shared-filesystem poll of
     inference.py:214-225; shard files `{out}.{rank}.{world}.tsv` are still written.
 """
@@ -115,12 +116,61 @@ def gpu_image_transform(img, crop_size: int = 224) -> torch.Tensor:
     return preprocess_image(torch.from_numpy(arr.copy()).cuda(non_blocking=True), crop_size)
 
 
+class MinMaxResizeForTest(object):
+    """inference.py:29-64: keep the aspect ratio, short side -> min_size unless that would push the long side over
+    max_size (then the long side -> max_size).  get_size() returns (height, width)."""
+
+    def __init__(self, min_size, max_size):
+        self.min_size = min_size
+        self.max_size = max_size
+
+    def get_size(self, image_size):
+        w, h = image_size
+        size = self.min_size
+        lo, hi = float(min(w, h)), float(max(w, h))
+        if hi / lo * size > self.max_size:
+            size = int(round(self.max_size * lo / hi))
+        if (w <= h and w == size) or (h <= w and h == size):
+            return (h, w)
+        if w < h:
+            return (int(size * h / w), size)
+        return (size, int(size * w / h))
+
+    def __repr__(self):
+        return "MinMaxResizeForTest({}, {})".format(self.min_size, self.max_size)
+
+    def __call__(self, img):
+        from PIL import Image
+        oh, ow = self.get_size(img.size)
+        return img.resize((ow, oh), Image.BICUBIC)          # torchvision F.resize(img, (h, w)) on a PIL image
+
+
+def minmax_image_transform(img, min_size: int, max_size: int) -> torch.Tensor:
+    """MinMaxResizeForTest -> ToTensor -> Normalize (inference.py:113-116, 123-131); no crop, no RGB conversion step
+    of its own (load_image_by_pil already returns RGB)."""
+    img = MinMaxResizeForTest(min_size, max_size)(img)
+    x = torch.from_numpy(np.asarray(img.convert("RGB"), dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+    mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
+    std = torch.tensor(CLIP_STD).view(3, 1, 1)
+    return (x - mean) / std
+
+
+def gpu_minmax_image_transform(img, min_size: int, max_size: int) -> torch.Tensor:
+    """The same on the GPU: Pillow-exact resize to get_size() + normalise (gitmi_preprocess_image_to)."""
+    from .engine import preprocess_image_to
+    oh, ow = MinMaxResizeForTest(min_size, max_size).get_size(img.size)
+    arr = np.asarray(img.convert("RGB"), dtype=np.uint8)
+    return preprocess_image_to(torch.from_numpy(arr.copy()).cuda(non_blocking=True), oh, ow)
+
+
 def get_image_transform(param: dict, gpu: bool = False):
-    if "test_respect_ratio_max" in param:
-        raise NotImplementedError(
-            "aspect-preserving resize (MinMaxResizeForTest, inference.py:29-64) needs the variable-resolution "
-            "ViT path, which is a 'next' row (SURVEY.md 8f-3)")
+    """inference.py:111-132."""
     crop = param.get("test_crop_size", 224)
+    if "test_respect_ratio_max" in param:
+        mx = param["test_respect_ratio_max"]
+        if gpu:
+            return lambda im: gpu_minmax_image_transform(im, crop, mx)
+        return lambda im: minmax_image_transform(im, crop, mx)
     if gpu:
         return lambda im: gpu_image_transform(im, crop)
     return lambda im: image_transform(im, crop)
@@ -200,6 +250,8 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
     tokenizer = get_tokenizer()
     torch.cuda.set_device(get_mpi_local_rank())                             # inference.py:152
     is_vqa = question_tsv is not None
+    if "test_respect_ratio_max" in param:
+        batch_size = 1            # aspect-preserving resize: every image has its own resolution (as in the reference)
     model = build_model(model_name, tokenizer, checkpoint, max_batch=1 if is_vqa else batch_size, precision=precision)
     transforms = get_image_transform(param, gpu=True)
     rank, world = get_mpi_rank(), get_mpi_size()

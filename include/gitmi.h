@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GITMI_ABI_VERSION 1
+#define GITMI_ABI_VERSION 2
 
 /* compute precision of GEMM/attention operands (accumulation, LayerNorm statistics,
  * softmax, residual stream and logits are fp32 in both modes) */
@@ -68,6 +68,10 @@ typedef struct gitmi_config {
     int32_t max_beams;      /* capacity: beam_size                                    */
     int32_t max_frames;     /* capacity: frames per sample (>=1)                      */
     int32_t max_text_len;   /* capacity: prefix + generated tokens (KV-cache length)  */
+    int32_t max_image_pixels; /* capacity: H*W of an input frame; 0 = image_size^2. Models with
+                               * test_respect_ratio_max (MinMaxResizeForTest, inference.py:29-64):
+                               * test_crop_size * test_respect_ratio_max               */
+    int32_t max_image_tokens; /* capacity: (H/patch)*(W/patch)+1 per frame; 0 = native grid */
 } gitmi_config;
 
 /* Replaces the constructor arguments of the two search classes
@@ -117,9 +121,17 @@ int  gitmi_finalize_weights(gitmi_engine* e);
  * `src` must outlive the clone; destroy clones with gitmi_destroy. */
 int  gitmi_clone(gitmi_engine* src, gitmi_engine** out);
 
+/* ---- input resolution of the following encode/generate calls (default: image_size x image_size).
+ * Replaces the run-time branch of VisualTransformer.forward for inputs that are not the native
+ * resolution (CLIP/model.py:243-251): the token grid becomes (H / patch) x (W / patch) -- the stride-patch
+ * convolution ignores the H % patch / W % patch remainder -- and the positional table is resized to it with
+ * torch's bicubic (align_corners=False) kernel, class row kept.  H*W and the token count must fit the
+ * max_image_pixels / max_image_tokens capacities given at gitmi_create(). */
+int  gitmi_set_image_shape(gitmi_engine* e, int H, int W, void* stream);
+
 /* ---- image encoder: replaces model.image_encoder(x) + the multi-frame branch of
  * CaptioningModel.forward_one (CLIP/model.py:240-274, decoder.py:845-857).
- * frames: F device pointers to fp32 [B,3,H,W] (H=W=image_size).  The visual features
+ * frames: F device pointers to fp32 [B,3,H,W] (H, W as set by gitmi_set_image_shape).  The visual features
  * [B, F*N, vit_width] stay resident in the engine; feats_out (optional, fp32) receives a copy. */
 int  gitmi_encode_frames(gitmi_engine* e, const float* const* frames, int F, int B,
                          float* feats_out, void* stream);
@@ -207,6 +219,11 @@ int  gitmi_op_attn_decode(const void* qkv, const void* img_k, const void* img_v,
  * the device (a decoded image); tmp: device workspace of >= H * W_resized * 3 bytes; out_chw: fp32 [3,crop,crop]. */
 int  gitmi_preprocess_image(const uint8_t* rgb_hwc, int H, int W, int crop, uint8_t* tmp, size_t tmp_bytes,
                             float* out_chw, void* stream);
+/* same arithmetic for MinMaxResizeForTest (inference.py:29-64, the test_respect_ratio_max models): resize to
+ * out_h x out_w (the caller applies get_size()), no crop, ToTensor, Normalize -> fp32 [3, out_h, out_w].
+ * tmp: uint8 workspace of H * out_w * 3 bytes. */
+int  gitmi_preprocess_image_to(const uint8_t* rgb_hwc, int H, int W, int out_h, int out_w, uint8_t* tmp,
+                               size_t tmp_bytes, float* out_chw, void* stream);
 
 /* kernel selection for A/B measurements: -1 auto (default), 0 first-generation GEMM only,
  * 1 force the direct-to-LDS GEMM wherever its constraints hold */

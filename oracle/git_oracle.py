@@ -76,6 +76,8 @@ CONFIGS: Dict[str, GitConfig] = {
     "GIT_LARGE": GitConfig(name="GIT_LARGE", patch=14, vit_width=1024, vit_layers=24, vit_heads=16),
     # aux_data/models/GIT_BASE_VATEX/parameter.yaml: num_image_with_embedding: 6
     "GIT_BASE_VATEX": GitConfig(name="GIT_BASE_VATEX", num_frames=6),
+    # aux_data/models/GIT_BASE_VQAv2/parameter.yaml: test_crop_size 480 (native grid 30x30), inputs up to 640 long
+    "GIT_BASE_VQAv2": GitConfig(name="GIT_BASE_VQAv2", image_size=480),
     # reduced shapes for fast CPU tests (same structure, head_dim stays 64)
     "TINY": GitConfig(name="TINY", image_size=64, patch=16, vit_width=128, vit_layers=2, vit_heads=2,
                       dec_hidden=128, dec_layers=2, dec_heads=2, dec_ffn=512, vocab=1000, max_pos=64),
@@ -169,10 +171,13 @@ def make_weights(cfg: GitConfig, seed: int = 1234, tie_output: bool = True,
     return w
 
 
-def make_images(cfg: GitConfig, batch: int, frames: int = 1, seed: int = 0) -> List[Tensor]:
-    """Synthetic post-Normalize images, one [B,3,H,W] tensor per frame."""
+def make_images(cfg: GitConfig, batch: int, frames: int = 1, seed: int = 0,
+                hw: Optional[Tuple[int, int]] = None) -> List[Tensor]:
+    """Synthetic post-Normalize images, one [B,3,H,W] tensor per frame.  hw: non-native
+    resolution (the MinMaxResizeForTest models)."""
     g = torch.Generator().manual_seed(seed)
-    return [torch.randn(batch, 3, cfg.image_size, cfg.image_size, generator=g) for _ in range(frames)]
+    H, W = hw if hw is not None else (cfg.image_size, cfg.image_size)
+    return [torch.randn(batch, 3, H, W, generator=g) for _ in range(frames)]
 
 
 # ----------------------------------------------------------------------------
@@ -202,17 +207,61 @@ def _merge_heads(x: Tensor) -> Tensor:                      # [B,H,N,hd] -> [B,N
 # ----------------------------------------------------------------------------
 # image encoder  (layers/CLIP/model.py)
 # ----------------------------------------------------------------------------
+def _cubic_weights(t: Tensor, A: float = -0.75) -> Tensor:
+    """Cubic-convolution coefficients for taps at offsets -1, 0, +1, +2 (ATen UpSample.h
+    get_cubic_upsample_coefficients; Keys kernel with A = -0.75).  t in [0,1) -> [..., 4]."""
+    def near(x):   # |x| <= 1
+        return ((A + 2.0) * x - (A + 3.0)) * x * x + 1.0
+
+    def far(x):    # 1 < |x| < 2
+        return ((A * x - 5.0 * A) * x + 8.0 * A) * x - 4.0 * A
+    return torch.stack([far(t + 1.0), near(t), near(1.0 - t), far(2.0 - t)], dim=-1)
+
+
+def bicubic_resize_grid(grid: Tensor, out_h: int, out_w: int) -> Tensor:
+    """torch.nn.functional.interpolate(mode='bicubic', align_corners=False, size=...) restated for a
+    [gh, gw, D] grid (what CLIP/model.py:243-251 applies to the positional embedding when the input is
+    not the native resolution): source coordinate (o + 0.5) * in/out - 0.5 (NOT clamped for cubic),
+    4x4 taps with border-clamped indices, rows first then columns.  -> [out_h, out_w, D]"""
+    gh, gw, _ = grid.shape
+
+    def axis(n_in, n_out):
+        src = (torch.arange(n_out, dtype=torch.float32) + 0.5) * (float(n_in) / float(n_out)) - 0.5
+        i0 = torch.floor(src)
+        wts = _cubic_weights(src - i0)                                           # [n_out, 4]
+        idx = (i0.long()[:, None] + torch.arange(-1, 3)[None, :]).clamp(0, n_in - 1)   # [n_out, 4]
+        return idx, wts
+    iy, wy = axis(gh, out_h)
+    ix, wx = axis(gw, out_w)
+    rows = grid[iy]                                              # [out_h, 4, gw, D]
+    cols = rows[:, :, ix]                                        # [out_h, 4, out_w, 4, D]
+    horiz = (cols * wx[None, None, :, :, None]).sum(dim=3)       # interpolate along x for each tap row
+    return (horiz * wy[:, :, None, None]).sum(dim=1)             # then along y
+
+
+def vit_positional(cfg: GitConfig, w: Weights, gh: int, gw: int) -> Tensor:
+    """Positional embedding for a gh x gw token grid: the stored table at the native grid, otherwise its
+    bicubic resize with the class row kept (CLIP/model.py:243-251)."""
+    pos = w["image_encoder.positional_embedding"]
+    g = cfg.grid
+    if (gh, gw) == (g, g):
+        return pos
+    body = bicubic_resize_grid(pos[1:].reshape(g, g, -1), gh, gw).reshape(gh * gw, -1)
+    return torch.cat([pos[:1], body], dim=0)
+
+
 def vit_stem(cfg: GitConfig, w: Weights, images: Tensor) -> Tensor:
-    """CLIP/model.py:241-257: patchify-conv (no bias), class token, positional add, ln_pre."""
+    """CLIP/model.py:241-257: patchify-conv (no bias), class token, positional add, ln_pre.  Any H, W >= patch:
+    the stride-p convolution drops the H % p / W % p remainder rows and columns."""
     b = images.shape[0]
-    p, g, D = cfg.patch, cfg.grid, cfg.vit_width
-    assert images.shape[2] == cfg.image_size and images.shape[3] == cfg.image_size, \
-        "oracle covers the native grid only (positional interpolation is a 'next' row)"
+    p, D = cfg.patch, cfg.vit_width
+    gh, gw = images.shape[2] // p, images.shape[3] // p
+    images = images[:, :, : gh * p, : gw * p]
     # conv k=s=p == per-patch dot product; K index = c*p*p + ky*p + kx (row-major patches)
-    patches = images.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b, g * g, 3 * p * p)
+    patches = images.reshape(b, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(b, gh * gw, 3 * p * p)
     x = patches @ w["image_encoder.conv1.weight"].reshape(D, 3 * p * p).t()
     cls = w["image_encoder.class_embedding"].expand(b, 1, D)
-    x = torch.cat([cls, x], dim=1) + w["image_encoder.positional_embedding"]
+    x = torch.cat([cls, x], dim=1) + vit_positional(cfg, w, gh, gw)
     return _layer_norm(x, w["image_encoder.ln_pre.weight"], w["image_encoder.ln_pre.bias"], 1e-5)
 
 

@@ -96,14 +96,23 @@ CASES = {
     "base_prefix_beam4": ("GIT_BASE", dict(seed=1236, eos_bias=0.2), 1, 1, O.BEAM4, [101, 2054, 2003, 2023, 1029]),
     "large_greedy": ("GIT_LARGE", dict(seed=1237), 1, 1, O.GREEDY, None),
     "vatex_greedy": ("GIT_BASE_VATEX", dict(seed=1238), 1, 6, O.SearchConfig("greedy", 8, 1, 1), None),
+    # non-native input resolution (MinMaxResizeForTest models): run-time bicubic resize of the positional grid,
+    # H, W not multiples of the patch (the stride-p convolution drops the remainder), up- and down-scaling
+    "tiny_varres_up": ("TINY", dict(seed=31, eos_bias=1.0), 2, 1, O.GREEDY, None, (90, 120)),
+    "tiny_varres_down_beam4": ("TINY", dict(seed=32), 2, 1, O.BEAM4, None, (48, 70)),
+    "tiny_varres_prefix": ("TINY", dict(seed=33, eos_bias=1.0), 1, 1, O.BEAM4, [101, 9, 77, 5], (80, 112)),
+    "tinyl_varres": ("TINY_L", dict(seed=34, eos_bias=1.0), 2, 1, O.GREEDY, None, (70, 100)),
+    "vqa_base_480x640": ("GIT_BASE_VQAv2", dict(seed=1239, eos_bias=0.3), 1, 1, O.SearchConfig("beam", 12, 4, 2, 0.6),
+                         [101, 2054, 3609, 2003, 1996, 4937, 1029], (480, 640)),
 }
 
 
 def run_case(name: str):
-    cfg_name, wkw, B, F, search, prefix = CASES[name]
+    cfg_name, wkw, B, F, search, prefix = CASES[name][:6]
+    hw = CASES[name][6] if len(CASES[name]) > 6 else None
     cfg = O.CONFIGS[cfg_name]
     w = O.make_weights(cfg, **wkw)
-    frames = O.make_images(cfg, B, F, seed=hash(name) % 1000 if False else sum(map(ord, name)))
+    frames = O.make_images(cfg, B, F, seed=sum(map(ord, name)), hw=hw)
     tie = wkw.get("tie_output", True)
     model = build_reference(cfg, w, search, tie)
     batch = {"image": frames if F > 1 else frames[0]}
@@ -154,6 +163,7 @@ def run_case(name: str):
     np.savez_compressed(
         os.path.join(GOLD, name + ".npz"),
         config=cfg_name, weights_kw=repr(wkw), batch=B, frames=F, image_seed=sum(map(ord, name)),
+        hw=np.array(hw if hw is not None else [], dtype=np.int64),
         search=repr(dataclass_tuple(search)), prefix=np.array(prefix if prefix is not None else [], dtype=np.int64),
         predictions=ref["predictions"].numpy(), logprobs=ref["logprobs"].numpy(),
         # features: full for tiny, strided sample for big models
@@ -164,6 +174,35 @@ def run_case(name: str):
         tf_argmax=ref_tf.argmax(-1).numpy(),
         tf_top2_margin=(ref_tf.topk(2).values[:, 0] - ref_tf.topk(2).values[:, 1]).numpy(),
     )
+
+
+def write_minmax_fixture():
+    """Outputs of the reference's MinMaxResizeForTest.get_size (inference.py:29-64) for a spread of image sizes."""
+    import_reference()
+    sys.modules.setdefault("azfuse", types.ModuleType("azfuse"))
+    if not hasattr(sys.modules["azfuse"], "File"):
+        sys.modules["azfuse"].File = object
+    try:
+        from generativeimage2text.inference import MinMaxResizeForTest
+    except Exception as exc:          # the module imports torchvision / azfuse at the top: restate the import surface
+        import importlib.util
+        import re as _re
+        src = open(os.path.join(REF, "generativeimage2text", "inference.py")).read()
+        m = _re.search(r"class MinMaxResizeForTest\(object\):.*?(?=\n\ndef |\nclass |\Z)", src, _re.S)
+        ns = {}
+        exec(compile(m.group(0), "inference.py:MinMaxResizeForTest", "exec"), ns)      # run the reference class itself
+        MinMaxResizeForTest = ns["MinMaxResizeForTest"]
+        print("  (reference inference.py not importable here: %s; executed its MinMaxResizeForTest class)" % type(exc).__name__)
+    rng = np.random.RandomState(7)
+    wh = [(640, 480), (480, 640), (480, 480), (1706, 1279), (500, 333), (333, 500), (1000, 200), (200, 1000),
+          (481, 640), (640, 481), (480, 481), (2, 1), (4032, 3024), (641, 480), (700, 525), (420, 560), (560, 420)]
+    wh += [(int(a), int(b)) for a, b in rng.randint(16, 3000, size=(200, 2))]
+    cfgs = [(480, 640), (420, 560)]
+    outs = [[MinMaxResizeForTest(*c).get_size(s_) for s_ in wh] for c in cfgs]
+    np.savez_compressed(os.path.join(GOLD, "minmax_sizes.npz"), wh=np.array(wh, dtype=np.int64),
+                        cfg_a=np.array(cfgs[0]), out_a=np.array(outs[0], dtype=np.int64),
+                        cfg_b=np.array(cfgs[1]), out_b=np.array(outs[1], dtype=np.int64))
+    print("[minmax_sizes] %d sizes x %d configs" % (len(wh), len(cfgs)))
 
 
 def dataclass_tuple(s: O.SearchConfig):
@@ -240,6 +279,8 @@ def main():
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
+    if args.only in (None, "minmax"):
+        write_minmax_fixture()
     if args.only in (None, "scripted"):
         run_scripted()
     for name in CASES:

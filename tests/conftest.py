@@ -39,6 +39,7 @@ def golden_case(name):
     kind, max_steps, k, pn, lp = eval(str(g["search"]), {"__builtins__": {}}, {})
     search = O.SearchConfig(kind, max_steps, k, pn, lp)
     w = O.make_weights(cfg, **wkw)
-    frames = O.make_images(cfg, int(g["batch"]), int(g["frames"]), seed=int(g["image_seed"]))
+    hw = tuple(int(v) for v in g["hw"]) if "hw" in g and g["hw"].size else None      # non-native resolution cases
+    frames = O.make_images(cfg, int(g["batch"]), int(g["frames"]), seed=int(g["image_seed"]), hw=hw)
     prefix = torch.tensor(g["prefix"], dtype=torch.long)[None] if g["prefix"].size else None
     return g, cfg, w, frames, search, prefix

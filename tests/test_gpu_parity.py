@@ -18,14 +18,16 @@ pytestmark = pytest.mark.gpu
 
 TINY_CASES = ["tiny_greedy", "tiny_greedy_untied", "tiny_beam4", "tiny_beam4_noeos", "tiny_beam3_pn3",
               "tiny_ar_beam3", "tiny_prefix_greedy", "tiny_prefix_beam4", "tiny_video_greedy",
-              "tiny_video_beam4", "tinyl_greedy"]
-BIG_CASES = ["base_greedy", "base_greedy_eos", "base_beam4", "base_prefix_beam4", "large_greedy", "vatex_greedy"]
+              "tiny_video_beam4", "tinyl_greedy",
+              "tiny_varres_up", "tiny_varres_down_beam4", "tiny_varres_prefix", "tinyl_varres"]
+BIG_CASES = ["base_greedy", "base_greedy_eos", "base_beam4", "base_prefix_beam4", "large_greedy", "vatex_greedy",
+             "vqa_base_480x640"]
 
 
-def make_engine(cfg, w, precision, B, search, frames=1, T=None):
+def make_engine(cfg, w, precision, B, search, frames=1, T=None, max_image_hw=None):
     from generativeimage2text_amd.engine import Engine
     eng = Engine(cfg, precision=precision, max_batch=B, max_beams=max(1, search.beam_size), max_frames=frames,
-                 max_text_len=T or search.max_steps)
+                 max_text_len=T or search.max_steps, max_image_hw=max_image_hw)
     eng.load_state_dict(w)
     return eng
 
@@ -53,7 +55,9 @@ def format_like_reference(search, tokens, logprobs, info, prefix):
 def run_case(name, precision):
     g, cfg, w, frames, search, prefix = golden_case(name)
     B, F = frames[0].shape[0], len(frames)
-    eng = make_engine(cfg, w, precision, B, search, frames=F)
+    hw = tuple(frames[0].shape[2:])
+    eng = make_engine(cfg, w, precision, B, search, frames=F,
+                      max_image_hw=hw if hw != (cfg.image_size, cfg.image_size) else None)
     dev_frames = [f.cuda() for f in frames]
     feats = eng.encode(dev_frames).cpu()
     logits = eng.step_logits(torch.from_numpy(g["tf_tokens"])).cpu()

@@ -25,11 +25,11 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(engine.EXPORTED_SYMBOLS) == declared
-    assert lib.gitmi_abi_version() == 1
+    assert lib.gitmi_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
-    assert engine.C.sizeof(engine.GitmiConfig) == 19 * 4
+    assert engine.C.sizeof(engine.GitmiConfig) == 21 * 4
     assert engine.C.sizeof(engine.GitmiSearch) == 24          # 4 x int32 + double
     assert engine.GitmiSearch.length_penalty.offset == 16
 
@@ -46,7 +46,9 @@ def test_model_param_table():
     c = configs.config_for_model("GIT_BASE_VATEX")
     assert c.num_frames == 6 and c.n_tok == 197
     c = configs.config_for_model("GIT_BASE_VQAv2")
-    assert c.image_size == 480 and c.test_respect_ratio_max == 640
+    assert c.image_size == 480 and c.test_respect_ratio_max == 640 and c.max_image_hw == (480, 640) and c.n_tok == 901
+    assert configs.config_for_model("GIT_LARGE_TEXTVQA").max_image_hw == (420, 560)
+    assert configs.config_for_model("GIT_BASE").max_image_hw is None
     with pytest.raises(KeyError):
         configs.config_for_model("nope")
 
@@ -117,3 +119,31 @@ def test_prefix_ids_and_id_tokenizer():
     ids = inference._prefix_ids(tok, long)
     assert len(ids) == 39 and ids[0] == 101 and ids[-1] == 1099          # keeps the LAST 38 (inference.py:99-100)
     assert tok.decode([101, 7, 8, 102, 102]) == "7 8"
+
+
+def test_minmax_resize_sizes_match_reference():
+    """MinMaxResizeForTest.get_size against outputs of the reference class (tests/golden/minmax_sizes.npz, written by
+    oracle/make_golden.py from inference.py:29-64) -- incl. the early-return and the truncation/rounding cases."""
+    from conftest import load_golden
+    g = load_golden("minmax_sizes")
+    for (mn, mx), wh, ref in ((tuple(g["cfg_a"]), g["wh"], g["out_a"]), (tuple(g["cfg_b"]), g["wh"], g["out_b"])):
+        t = inference.MinMaxResizeForTest(int(mn), int(mx))
+        for (w, h), (oh, ow) in zip(wh.tolist(), ref.tolist()):
+            assert t.get_size((w, h)) == (oh, ow), (mn, mx, w, h)
+
+
+def test_minmax_transform_cpu_shape():
+    from PIL import Image
+    rng = np.random.RandomState(1)
+    img = Image.fromarray(rng.randint(0, 255, (300, 500, 3), dtype=np.uint8))
+    x = inference.get_image_transform({"test_crop_size": 480, "test_respect_ratio_max": 640})(img)
+    assert x.shape == (3, 384, 640)          # long side capped at 640, short = round(640 * 300 / 500)
+
+
+def test_every_entry_point_has_ctypes_prototypes():
+    # a missing argtypes list makes ctypes pass 64-bit pointers as C ints (truncated): every bound symbol must declare them
+    lib = engine.load_library()
+    for name in engine.EXPORTED_SYMBOLS:
+        if name in ("gitmi_abi_version", "gitmi_last_error"):
+            continue
+        assert getattr(lib, name).argtypes is not None, name

@@ -42,3 +42,32 @@ def test_gpu_transform_smooth_image_and_repeat():
     for _ in range(2):
         got = E.preprocess_image(torch.from_numpy(img).cuda(), 224).cpu()
         assert torch.equal(got, ref)
+
+
+MINMAX_SIZES = [(480, 640), (1279, 1706), (333, 500), (500, 333), (200, 1000), (700, 525), (97, 61)]
+
+
+@pytest.mark.parametrize("h,w", MINMAX_SIZES)
+def test_oracle_minmax_resize_is_pillow_exact(h, w):
+    """the resize of MinMaxResizeForTest (inference.py:29-64) through the numpy restatement of Pillow's resampler"""
+    from generativeimage2text_amd.inference import MinMaxResizeForTest
+    rng = np.random.RandomState(h * 13 + w)
+    img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+    t = MinMaxResizeForTest(480, 640)
+    oh, ow = t.get_size((w, h))
+    ref = np.asarray(t(Image.fromarray(img)))
+    assert ref.shape == (oh, ow, 3)
+    assert np.array_equal(resize_bicubic_u8(img, oh, ow), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w", MINMAX_SIZES)
+@pytest.mark.parametrize("mn,mx", [(480, 640), (420, 560)])
+def test_gpu_minmax_transform_bit_exact(h, w, mn, mx):
+    from generativeimage2text_amd import inference as I
+    rng = np.random.RandomState(h * 19 + w)
+    img = Image.fromarray(rng.randint(0, 256, (h, w, 3), dtype=np.uint8))
+    ref = I.minmax_image_transform(img, mn, mx)                             # PIL + torch, as the reference does it
+    got = I.gpu_minmax_image_transform(img, mn, mx).cpu()
+    assert got.shape == ref.shape
+    assert torch.equal(got, ref), (got - ref).abs().max()
