@@ -371,6 +371,50 @@ def test_task_function_single_tsv(tmp_path, monkeypatch):
         assert json.loads(r[1])[0]["caption"] == I.IdTokenizer().decode(pred)
 
 
+def test_task_function_vqa_tsv_variable_resolution(tmp_path, monkeypatch):
+    """test_git_inference_single_tsv with a question TSV on a test_respect_ratio_max model (the VQAv2/TextVQA
+    geometry, scaled down to crop 160 / max 224 so that the CPU oracle stays cheap): every image keeps its aspect ratio
+    (MinMaxResizeForTest on the GPU), the engine follows the resolution image by image (positional grid resized at run
+    time), one row `key \t {"answer", "question_id"}` per question."""
+    import base64, dataclasses, io, json
+    from PIL import Image
+    from oracle import git_oracle as O
+    from generativeimage2text_amd import configs, inference as I, tsv_io
+    from generativeimage2text_amd.model import GeneratorWithBeamSearch
+    monkeypatch.setitem(configs.MODEL_PARAMS, "GIT_BASE_VQAv2", {"test_crop_size": 160, "test_respect_ratio_max": 224})
+    monkeypatch.setitem(I.MODEL_PARAMS, "GIT_BASE_VQAv2", {"test_crop_size": 160, "test_respect_ratio_max": 224})
+    cfg = dataclasses.replace(O.CONFIGS["GIT_BASE"], name="vqa_small", image_size=160)
+    w = O.make_weights(cfg, seed=1241, tie_output=False, eos_bias=0.3)
+    rng = np.random.RandomState(6)
+    sizes = [(300, 400), (500, 260), (333, 333)]                     # (h, w): landscape, portrait beyond the ratio cap, square
+    questions = [[("2054 2003 2023", 11)], [("2129 2116", 12), ("2054 3609", 13)], [("2003 2009 1037 4937", 14)]]
+    img_rows, q_rows, want = [], [], []
+    for i, ((h, wd), qs) in enumerate(zip(sizes, questions)):
+        im = Image.fromarray(rng.randint(0, 255, (h, wd, 3), dtype=np.uint8))
+        buf = io.BytesIO()
+        im.save(buf, format="PNG")
+        img_rows.append(["img%d" % i, base64.b64encode(buf.getvalue()).decode()])
+        q_rows.append(["img%d" % i, json.dumps([{"question": q, "question_id": qid} for q, qid in qs])])
+        x = I.minmax_image_transform(im.convert("RGB"), 160, 224)[None]
+        assert x.shape[2] != x.shape[3] or (h, wd) == (333, 333)
+        for q, qid in qs:
+            ids = [101] + [int(t) for t in q.split()]
+            with torch.no_grad():
+                ref = O.caption(cfg, w, [x], O.SearchConfig("beam", 14, 4, 2, 0.6), prefix=torch.tensor([ids]), cached=True)
+            want.append(("img%d" % i, qid, I.IdTokenizer().decode(ref["predictions"][0].tolist())))
+    tsv_io.tsv_writer(img_rows, str(tmp_path / "img.tsv"))
+    tsv_io.tsv_writer(q_rows, str(tmp_path / "q.tsv"))
+    monkeypatch.setattr(I, "get_tokenizer", lambda: I.IdTokenizer())
+    real_build = I.build_model
+    monkeypatch.setattr(I, "build_model", lambda name, tok, c, **kw: real_build(
+        name, tok, c, decoder=GeneratorWithBeamSearch(eos_index=102, max_steps=14, beam_size=4, length_penalty=0.6), **kw))
+    out = str(tmp_path / "out.tsv")
+    I.test_git_inference_single_tsv(str(tmp_path / "img.tsv"), "GIT_BASE_VQAv2", str(tmp_path / "q.tsv"), out, checkpoint=w,
+                                    precision="f32")
+    got = [(r[0], json.loads(r[1])["question_id"], json.loads(r[1])["answer"]) for r in tsv_io.tsv_reader(out)]
+    assert got == want, (got, want)
+
+
 @pytest.mark.parametrize("kind", ["greedy", "beam"])
 def test_long_step_budget_polling_path(kind):
     """The shipped step budget is max_steps=1024 (model.py:37): far beyond 32 steps the engine launches eagerly
