@@ -273,14 +273,10 @@ hipError_t launch_gemm(const GemmArgs& g_in, bool in_f32, bool out_f32, hipStrea
     GemmArgs g = g_in;
     g.dbg = g_gemm_dbg;
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
-    // impl: -1 auto | 0 first generation | 1 direct-to-LDS 128x128 | 2 256x128 3-stage ring
+    // impl: -1 auto | 0 register-staged (also fp32, odd shapes) | 1 direct-to-LDS 128x128 | 2 256x128 3-stage ring |
+    //       6 256x256x32 4-stage ring | 9 256x256x64 half-tile pipeline (kernels_gemm10.hip)
     if (g_gemm_impl != 0 && gemm_dlds_supported(g, in_f32, out_f32)) {
-        if (g_gemm_impl == 3) return launch_gemm_pring(g, out_f32, s);
-        if (g_gemm_impl == 4) return launch_gemm_ring32(g, out_f32, s);
-        if (g_gemm_impl == 5) return launch_gemm_ring32w(g, out_f32, s);
         if (g_gemm_impl == 6) return launch_gemm_ring256(g, out_f32, s);
-        if (g_gemm_impl == 7) return launch_gemm_ring2p(g, out_f32, s);
-        if (g_gemm_impl == 8 && g.K >= 128) return launch_gemm_pring2(g, out_f32, s);
         if (g_gemm_impl == 9 && gemm_p8_supports(g)) return launch_gemm_p8(g, out_f32, s);
         // auto: narrow outputs (N <= 1024: out-proj, c_proj, patch embed) have too few 256x128 tiles per CU and
         // run faster on the 256x256 4-stage ring; wide outputs on the 256x128 3-stage ring (measured, profiles/)

@@ -2,18 +2,10 @@
 //
 //   C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) (+ residual[M,N])      K % 32 == 0, N % 8 == 0
 //
-// Measured on the 256x128 variants (kernels_gemm3/5/6.hip): every tile/wave arrangement saturates at the same
-// ~11-12 TB/s of L2->LDS operand feed (1.0 PFLOP/s at 87 FLOP per fed byte).  A 256x256 tile needs 131 FLOP per
-// fed byte, i.e. a third less operand traffic per FLOP; 4 stages of 32 KiB keep three K steps in flight.
-// (derived from kernels_gemm5.hip: 4 waves per workgroup, each owning 128x64 = 8x4 MFMA tiles, so a K step
-// needs 12 ds_read_b128 per 32 MFMAs instead of 8 per 16, and the two co-resident workgroups of a CU --
-// one wave each per SIMD -- run decoupled: one computes while the other waits on its barrier.)
-// kernels_gemm3.hip keeps one 144-KiB workgroup per CU, so a tile's ramp-up (two stages of HBM
-// latency) and its epilogue are fully exposed -- with K = 768 they cost as much as the 12-step main
-// loop.  Here a K step is 32 deep: a stage is 24 KiB, the 3-stage ring 72 KiB, and two workgroups
-// (16 waves) share a CU: while one sits in its prologue, epilogue, barrier or counted wait the other
-// one feeds the MFMA pipe.  Per step and wave: 3 global_load_lds_dwordx4, 8 ds_read_b128, 16 MFMAs,
-// `s_waitcnt vmcnt(3)` + raw s_barrier.
+// A 256x256 tile needs 128 FLOP per operand byte fed from L2 (the 256x128 ring of kernels_gemm3.hip: 85), which is
+// what bounds these kernels.  BK = 32 keeps four 32-KiB stages (three K steps in flight) inside 128 KiB.  Per K step
+// and wave: 4 global_load_lds_dwordx4, 12 ds_read_b128, 32 MFMAs, a counted s_waitcnt vmcnt + raw s_barrier.
+// Now the fallback for narrow outputs when the half-tile pipeline of kernels_gemm10.hip does not apply.
 //   * LDS image: 64-byte rows, four per 256-byte bank row; 16-byte chunk c of row r lives at
 //         r*64 + (c ^ ((-(r>>2)) & 3))*16
 //     so that the 16 rows of a ds_read_b128 lane group hit 16 distinct bank slots; applied on the

@@ -19,12 +19,7 @@ hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t
 bool gemm_dlds_supported(const GemmArgs& g, bool in_f32, bool out_f32);
 hipError_t launch_gemm_dlds(GemmArgs g, bool out_f32, hipStream_t s);
 hipError_t launch_gemm_ring(GemmArgs g, bool out_f32, hipStream_t s);   // 256x128 tile, 3-stage ring
-hipError_t launch_gemm_pring(GemmArgs g, bool out_f32, hipStream_t s);  // persistent ring (one workgroup per CU)
-hipError_t launch_gemm_ring32(GemmArgs g, bool out_f32, hipStream_t s); // 256x128x32, 72 KiB ring, 2 workgroups/CU
-hipError_t launch_gemm_ring32w(GemmArgs g, bool out_f32, hipStream_t s); // 256x128x32, 4 waves of 128x64, 2 workgroups/CU
 hipError_t launch_gemm_ring256(GemmArgs g, bool out_f32, hipStream_t s); // 256x256x32, 8 waves of 128x64, 4-stage ring
-hipError_t launch_gemm_ring2p(GemmArgs g, bool out_f32, hipStream_t s); // ring with phase-staggered wave groups
-hipError_t launch_gemm_pring2(GemmArgs g, bool out_f32, hipStream_t s); // persistent ring, nested tile/K loops
 hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s);     // 256x256x64, half-tile pipeline, staggered wave groups
 bool gemm_p8_supports(const GemmArgs& g);
 void set_gemm_impl(int impl);   // -1 auto, 0 first-generation kernel only, 1 force direct-to-LDS kernel

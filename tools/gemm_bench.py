@@ -29,7 +29,7 @@ def bench(fn, reps=20):
 
 
 def main():
-    impls = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["2", "3"])]
+    impls = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["2", "6", "9"])]
     g = torch.Generator().manual_seed(0)
     for name, M, N, K, odt, act, use_res in SHAPES:
         A = (torch.randn(M, K, generator=g)).bfloat16().cuda()
