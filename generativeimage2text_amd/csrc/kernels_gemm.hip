@@ -281,11 +281,12 @@ hipError_t launch_gemm(const GemmArgs& g_in, bool in_f32, bool out_f32, hipStrea
         // auto: narrow outputs (N <= 1024: out-proj, c_proj, patch embed) have too few 256x128 tiles per CU and
         // run faster on the 256x256 4-stage ring; wide outputs on the 256x128 3-stage ring (measured, profiles/)
         if (g_gemm_impl == -1 && g.M > 512 && gemm_p8_supports(g)) {
-            // 256x256 half-tile pipeline vs 256x128 ring: a p8 tile does twice the work in ~1.5x the time;
-            // take it when its (one workgroup per CU) round count wins
+            // 256x256 (or 192x256) half-tile pipeline vs 256x128 ring: a p8 tile does twice the work in ~1.5x the
+            // time; take it when its (one workgroup per CU) round count wins.  Units: ring round = 8/3, p8 round = 4|3
             const long tm = (g.M + 255) / 256;
-            const long r_p8 = (tm * (g.N / 256) + 255) / 256, r_ring = (tm * ((g.N + 127) / 128) + 255) / 256;
-            if (3 * r_p8 < 2 * r_ring) return launch_gemm_p8(g, out_f32, s);
+            const long r_ring = (tm * ((g.N + 127) / 128) + 255) / 256;
+            const int c_p8 = gemm_p8_cost(g, 96) < gemm_p8_cost(g, 128) ? gemm_p8_cost(g, 96) : gemm_p8_cost(g, 128);
+            if (3 * c_p8 < 8 * r_ring) return launch_gemm_p8(g, out_f32, s);
         }
         if (g_gemm_impl == -1 && g.M > 512 && g.N <= 1024 && g.N % 256 == 0) return launch_gemm_ring256(g, out_f32, s);
         if (g_gemm_impl == 2 || (g_gemm_impl == -1 && g.M > 512)) return launch_gemm_ring(g, out_f32, s);

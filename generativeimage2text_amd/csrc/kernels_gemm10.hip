@@ -33,7 +33,7 @@ namespace gitmi {
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int BN = 256, BK = 64;                    // BM = 2 * MH, MH = 128 (256x256 tile) or 96 (192x256)
 constexpr int HALF_BYTES = 128 * BK * 2;             // 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES;            // 64 KiB: A0 A1 B0 B1
 constexpr int LDS_BYTES = 2 * BUF_BYTES;             // 128 KiB
@@ -57,8 +57,13 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 }
 
 // DBG (measurement builds only): 1 no global stores / residual reads, 2 no epilogue, 4 no ds_reads / MFMAs, 8 no loads
-template <typename TOut, int ACT, int DBG = 0>
+// MH = rows of an activation half tile: 128 -> 256x256 tile; 96 -> 192x256 tile (3 instead of 4 row fragments per
+// quadrant), used when it fills more CUs in a single round (N = 768: 198 instead of 150 workgroups).  The A slots keep
+// their 16 KiB; with MH = 96 the last four 1-KiB pieces of a slot are loaded (clamped rows) but never read, so every
+// wave still issues two loads per half tile and the vmcnt arithmetic is unchanged.
+template <typename TOut, int ACT, int DBG = 0, int MH = 128>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
+    constexpr int BM = 2 * MH, MI = MH / 32;            // row fragments of a 64/48-row quadrant
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x;
@@ -99,12 +104,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int rr = h * 128 + (wave * 2 + q) * 8 + 2 * Rl + (hi ^ q);
+            const int rr = h * MH + (wave * 2 + q) * 8 + 2 * Rl + (hi ^ q);
             const int ch = lo ^ (q * 4 + Rl);
             int m = m0 + rr;
             m = m < g.M ? m : g.M - 1;
             a_off[h][q] = ((uint32_t)m * (uint32_t)g.lda + ch * 8) * 2u;
-            w_off[h][q] = ((uint32_t)(n0 + rr) * (uint32_t)g.K + ch * 8) * 2u;
+            const int rn = h * 128 + (wave * 2 + q) * 8 + 2 * Rl + (hi ^ q);
+            w_off[h][q] = ((uint32_t)(n0 + rn) * (uint32_t)g.K + ch * 8) * 2u;
         }
     // half tile `half` (0/1) of operand `isw` for K tile kt -> slot of buffer kt & 1
     auto issue = [&](int isw, int half, int kt) {
@@ -122,10 +128,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     const int x7 = (l15 >> 1) & 7;
     const int ch0 = ((0 * 4 + lg) ^ x7) * 16;
     const int ch1 = ((1 * 4 + lg) ^ x7) * 16;
-    const int a_rd = grp * 64 * 128 + rowpart;                     // + half*HALF_BYTES + i*2048 + ch
+    const int a_rd = grp * (MH / 2) * 128 + rowpart;                     // + half*HALF_BYTES + i*2048 + ch
     const int w_rd = SLOT_B0 + wc * 32 * 128 + rowpart;            // + half*HALF_BYTES + j*2048 + ch
 
-    f32x4_t acc[2][2][2][4];   // [qm][qn][j: n-frag][i: m-frag]
+    f32x4_t acc[2][2][2][MI];  // [qm][qn][j: n-frag][i: m-frag]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -133,14 +139,14 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[a][b][j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < MI; ++i) acc[a][b][j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    bf16x8_t af[4][2], wf0[2][2], wf1[2][2];
+    bf16x8_t af[MI][2], wf0[2][2], wf1[2][2];
 
     auto read_a = [&](const unsigned char* sb, int half) {
         if constexpr (DBG & 4) return;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
             af[i][0] = *reinterpret_cast<const bf16x8_t*>(sb + a_rd + half * HALF_BYTES + i * 2048 + ch0);
             af[i][1] = *reinterpret_cast<const bf16x8_t*>(sb + a_rd + half * HALF_BYTES + i * 2048 + ch1);
         }
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
             wf[j][1] = *reinterpret_cast<const bf16x8_t*>(sb + w_rd + half * HALF_BYTES + j * 2048 + ch1);
         }
     };
-    auto mma = [&](f32x4_t (&c)[2][4], const bf16x8_t (&wf)[2][2]) {
+    auto mma = [&](f32x4_t (&c)[2][MI], const bf16x8_t (&wf)[2][2]) {
         if constexpr (DBG & 4) return;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
                     c[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], af[i][kk], c[j][i], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
@@ -208,13 +214,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     ktile(std::integral_constant<int, 2>{}, nk - 1);
     if (grp == 0) P8_BARRIER();
 
-    // ---- epilogue through LDS: slab = 128 rows (qm) x WCOL columns ---------------------------------
+    // ---- epilogue through LDS: slab = MH rows (qm) x WCOL columns ---------------------------------
     constexpr int NQN = sizeof(TOut) == 2 ? 2 : 1;                 // weight halves per slab
     constexpr int WCOL = 128 * NQN;
     constexpr int EPC = 16 / (int)sizeof(TOut);                    // elements per 16-byte chunk
     constexpr int EPS = WCOL + EPC;                                // padded row stride (elements)
     constexpr int CPR = WCOL / EPC;                                // chunks per row
-    static_assert(128 * EPS * sizeof(TOut) <= LDS_BYTES, "epilogue slab does not fit");
+    static_assert(MH * EPS * sizeof(TOut) <= LDS_BYTES && (MH * CPR) % 512 == 0, "epilogue slab does not fit");
     TOut* ep = reinterpret_cast<TOut*>(smem);
     TOut* __restrict__ C = reinterpret_cast<TOut*>(g.C);
 
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) sum += acc[a][b][j][i][0] + acc[a][b][j][i][1] + acc[a][b][j][i][2] + acc[a][b][j][i][3];
+                    for (int i = 0; i < MI; ++i) sum += acc[a][b][j][i][0] + acc[a][b][j][i][1] + acc[a][b][j][i][2] + acc[a][b][j][i][3];
         if (sum == 12345.678f) C[0] = (TOut)0;
         return;
     }
@@ -250,11 +256,11 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                 for (int j = 0; j < 2; ++j) {
                     const int nl = u * 128 + wc * 32 + j * 16 + lg * 4;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < MI; ++i) {
                         float v[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = apply_act_t<ACT>(acc[qm][qn][j][i][r] + bias4[qn][j][r]);
-                        TOut* p = ep + (grp * 64 + i * 16 + l15) * EPS + nl;
+                        TOut* p = ep + (grp * (MH / 2) + i * 16 + l15) * EPS + nl;
                         if constexpr (sizeof(TOut) == 4) {
                             *reinterpret_cast<f32x4_t*>(p) = f32x4_t{v[0], v[1], v[2], v[3]};
                         } else {
@@ -268,10 +274,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
             }
             __syncthreads();
 #pragma unroll 4
-            for (int q = 0; q < 128 * CPR / 512; ++q) {
+            for (int q = 0; q < MH * CPR / 512; ++q) {
                 const int chunk = tid + q * 512;
                 const int row = chunk / CPR, cc = chunk % CPR;
-                const int m = m0 + qm * 128 + row;
+                const int m = m0 + qm * MH + row;
                 const int n = n0 + s * WCOL + cc * EPC;
                 if (m < g.M && !(DBG & 1)) {
                     if constexpr (sizeof(TOut) == 4) {
@@ -308,24 +314,26 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 
 }  // namespace
 
-template <typename TOut>
+template <typename TOut, int MH>
 static void launch_p8_t(const GemmArgs& g, hipStream_t s) {
     if (g.dbg) {      // measurement builds (tools/gemm_dbg.py); act is ignored
-        switch (g.dbg) {
-            case 1: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 1>), dim3(g.nwg), dim3(512), 0, s, g); return;
-            case 2: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 2>), dim3(g.nwg), dim3(512), 0, s, g); return;
-            case 6: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 6>), dim3(g.nwg), dim3(512), 0, s, g); return;
-            case 10: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 10>), dim3(g.nwg), dim3(512), 0, s, g); return;
-            default: break;
+        if constexpr (MH == 128) {
+            switch (g.dbg) {
+                case 1: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 1>), dim3(g.nwg), dim3(512), 0, s, g); return;
+                case 2: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 2>), dim3(g.nwg), dim3(512), 0, s, g); return;
+                case 6: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 6>), dim3(g.nwg), dim3(512), 0, s, g); return;
+                case 10: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 10>), dim3(g.nwg), dim3(512), 0, s, g); return;
+                default: break;
+            }
         }
     }
     switch (g.act) {
         case GITMI_ACT_QUICKGELU:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_QUICKGELU>), dim3(g.nwg), dim3(512), 0, s, g); break;
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_QUICKGELU, 0, MH>), dim3(g.nwg), dim3(512), 0, s, g); break;
         case GITMI_ACT_GELU_ERF:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_GELU_ERF>), dim3(g.nwg), dim3(512), 0, s, g); break;
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_GELU_ERF, 0, MH>), dim3(g.nwg), dim3(512), 0, s, g); break;
         default:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_NONE>), dim3(g.nwg), dim3(512), 0, s, g); break;
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_NONE, 0, MH>), dim3(g.nwg), dim3(512), 0, s, g); break;
     }
 }
 
@@ -334,27 +342,57 @@ bool gemm_p8_supports(const GemmArgs& g) {
            (double)g.M * g.lda * 2.0 < 4.0e9 && (double)g.N * g.K * 2.0 < 4.0e9;
 }
 
-hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s) {
-    const int tiles_m = (g.M + BM - 1) / BM;
-    g.tiles_n = g.N / BN;
-    // N groups: smallest power of two that brings an XCD's share of W under ~2.5 MB (it stays L2 resident while
-    // activation panels stream through)
-    int ng = 1;
-    const double wbytes = (double)g.N * g.K * 2.0;
-    while (ng < 8 && wbytes / ng > 2.5e6 && ng * 2 <= g.tiles_n) ng *= 2;
-    g.ng = ng;
-    const int mg = 8 / ng;
-    int max_cnt = 0;
-    for (int x = 0; x < 8; ++x) {
-        const int gn = x % ng, gm = x / ng;
-        const int nn = (gn + 1) * g.tiles_n / ng - gn * g.tiles_n / ng;
-        const int tg = tiles_m * nn;
-        const int cnt = (gm + 1) * tg / mg - gm * tg / mg;
-        max_cnt = cnt > max_cnt ? cnt : max_cnt;
+// Partition of the tile grid over the 8 XCDs for tile height 2*mh: the N tiles are cut into ng groups, the 8/ng XCDs
+// of a group share its (M-major, N-fastest) tile list in equal chunks.  Returns the rounds an XCD's 32 CUs need (one
+// workgroup per CU) for the best ng: fewest rounds first (33 tiles on one XCD cost a whole extra round), then the
+// fewest distinct operand panels among the 32 tiles an XCD runs concurrently -- ceil(32/nn) activation panels + nn
+// weight panels for a group nn tiles wide -- i.e. the best L2 sharing (8192^3: ng = 8 -> 12 panels, 1.49 PFLOP/s;
+// ng = 1 -> 33 panels, 1.05 PFLOP/s).
+static int p8_plan(const GemmArgs& g, int mh, int* ng_out, int* max_cnt_out) {
+    const int tiles_m = (g.M + 2 * mh - 1) / (2 * mh), tiles_n = g.N / BN;
+    int best_ng = 1, best_rounds = 1 << 30, best_cnt = 0, best_panels = 1 << 30;
+    for (int ng = 1; ng <= 8 && ng <= tiles_n; ng *= 2) {
+        const int mg = 8 / ng;
+        int max_cnt = 0, max_nn = 0;
+        for (int x = 0; x < 8; ++x) {
+            const int gn = x % ng, gm = x / ng;
+            const int nn = (gn + 1) * tiles_n / ng - gn * tiles_n / ng;
+            const int tg = tiles_m * nn;
+            const int cnt = (gm + 1) * tg / mg - gm * tg / mg;
+            max_cnt = cnt > max_cnt ? cnt : max_cnt;
+            max_nn = nn > max_nn ? nn : max_nn;
+        }
+        const int rounds = (max_cnt + 31) / 32;
+        const int panels = (32 + max_nn - 1) / max_nn + (max_nn < 32 ? max_nn : 32);
+        if (rounds < best_rounds || (rounds == best_rounds && panels < best_panels)) {
+            best_ng = ng; best_rounds = rounds; best_cnt = max_cnt; best_panels = panels;
+        }
     }
+    if (ng_out) *ng_out = best_ng;
+    if (max_cnt_out) *max_cnt_out = best_cnt;
+    return best_rounds;
+}
+
+// rounds x relative tile time (4 units for the 256-row tile, 3 for the 192-row one)
+int gemm_p8_cost(const GemmArgs& g, int mh) { return p8_plan(g, mh, nullptr, nullptr) * (mh / 32); }
+
+hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s) {
+    // the 192-row tile when it fills a partial round better (N = 768 at M = 12608: 198 workgroups instead of 150);
+    // dbg 64 / 128 force the 192- / 256-row tile (tests, A/B)
+    int mh = gemm_p8_cost(g, 96) < gemm_p8_cost(g, 128) ? 96 : 128;
+    if (g.dbg & 64) { mh = 96; g.dbg &= ~64; }
+    if (g.dbg & 128) { mh = 128; g.dbg &= ~128; }
+    g.tiles_n = g.N / BN;
+    int max_cnt = 0;
+    p8_plan(g, mh, &g.ng, &max_cnt);
     g.nwg = 8 * max_cnt;
-    if (out_f32) launch_p8_t<float>(g, s);
-    else launch_p8_t<bf16_t>(g, s);
+    if (mh == 96) {
+        if (out_f32) launch_p8_t<float, 96>(g, s);
+        else launch_p8_t<bf16_t, 96>(g, s);
+    } else {
+        if (out_f32) launch_p8_t<float, 128>(g, s);
+        else launch_p8_t<bf16_t, 128>(g, s);
+    }
     return hipGetLastError();
 }
 

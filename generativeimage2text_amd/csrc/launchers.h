@@ -22,6 +22,7 @@ hipError_t launch_gemm_ring(GemmArgs g, bool out_f32, hipStream_t s);   // 256x1
 hipError_t launch_gemm_ring256(GemmArgs g, bool out_f32, hipStream_t s); // 256x256x32, 8 waves of 128x64, 4-stage ring
 hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s);     // 256x256x64, half-tile pipeline, staggered wave groups
 bool gemm_p8_supports(const GemmArgs& g);
+int gemm_p8_cost(const GemmArgs& g, int mh);   // rounds x relative tile time of the 256-row (mh=128) / 192-row (96) tile
 void set_gemm_impl(int impl);   // -1 auto, 0 first-generation kernel only, 1 force direct-to-LDS kernel
 
 // weight-streaming GEMM for decode (bf16 operands): C or fp32 partial slabs [S][M][N]

@@ -42,7 +42,8 @@ def test_gemm_bf16(M, N, K, act):
 
 @pytest.mark.parametrize("M,N,K", [(1000, 512, 128), (777, 256, 192), (2100, 768, 768), (515, 1024, 3072)])
 @pytest.mark.parametrize("act", [0, 1, 2])
-def test_gemm_bf16_p8_variant(M, N, K, act):
+@pytest.mark.parametrize("tile", [9 | (128 << 8), 9 | (64 << 8)])          # forced 256x256 / 192x256 tile
+def test_gemm_bf16_p8_variant(M, N, K, act, tile):
     """The 256x256 half-tile pipeline kernel (kernels_gemm10.hip), forced: shortest K (2 and 3 K tiles), ragged M,
     every epilogue; it must also equal the 256x128 ring kernel bit for bit (same K order)."""
     from generativeimage2text_amd import engine as E
@@ -52,7 +53,7 @@ def test_gemm_bf16_p8_variant(M, N, K, act):
     res = _rand(M, N, seed=14)
     ref = _act(A.double() @ W.double().t() + bias.double(), act)
     try:
-        E.set_gemm_impl(9)
+        E.set_gemm_impl(tile)
         out = E.op_gemm(A.cuda(), W.cuda(), bias.cuda(), res.cuda(), act, torch.float32).cpu()
         out_b = E.op_gemm(A.cuda(), W.cuda(), bias.cuda(), None, act, torch.bfloat16).cpu()
         out_br = E.op_gemm(A.cuda(), W.cuda(), None, res.cuda(), act, torch.bfloat16).cpu()
