@@ -417,8 +417,6 @@ static int alloc_workspaces(gitmi_engine* e) {
     RCK(dev_alloc_t(e, &e->out_lp, (size_t)c.max_batch));
     RCK(dev_alloc_t(e, &e->out_info, 4));
     HIPCK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
-    HIPCK(hipEventCreateWithFlags(&e->fence_in, hipEventDisableTiming));
-    HIPCK(hipEventCreateWithFlags(&e->fence_out, hipEventDisableTiming));
     e->frame_stage.resize(c.max_frames);
     for (int f = 0; f < c.max_frames; ++f)
         RCK(dev_alloc_t(e, &e->frame_stage[f], (size_t)c.max_batch * 3 * e->max_pixels));
@@ -852,12 +850,16 @@ extern "C" int gitmi_search_finish(gitmi_engine* e, int64_t* tokens_out, float* 
 }
 
 // ---- the whole hot path ------------------------------------------------------------------
-static int generate_body(gitmi_engine* e, const float* const* frames, int F, int B, const long long* start_dev, int P,
-                         const gitmi_search* sp, long long* tokens_out, float* logprob_out, int32_t* info_out,
-                         hipStream_t s, bool allow_poll) {
-    SpanGuard total(e, s, 99, 0);
+// image encoder + decoder prefill over the image tokens
+static int generate_encode(gitmi_engine* e, const float* const* frames, int F, int B, hipStream_t s) {
     RCK(encode_frames_impl(e, frames, F, B, nullptr, s));
     RCK(prefill_impl(e, s));
+    return 0;
+}
+
+// search over the text positions (teacher-forced prefix, then decode steps) + result formatting
+static int generate_decode(gitmi_engine* e, int B, const long long* start_dev, int P, const gitmi_search* sp,
+                           long long* tokens_out, float* logprob_out, int32_t* info_out, hipStream_t s, bool allow_poll) {
     RCK(search_begin_impl(e, sp, B, start_dev, P, e->cfg.vocab, s));
     const int T = sp->max_steps;
     const SearchState& st = e->ss;
@@ -888,6 +890,14 @@ static int generate_body(gitmi_engine* e, const float* const* frames, int F, int
                       e->cfg.dec_hidden * e->esz;
     e->last_decode_step_bytes = e->dec_weight_bytes + kv;
     return 0;
+}
+
+static int generate_body(gitmi_engine* e, const float* const* frames, int F, int B, const long long* start_dev, int P,
+                         const gitmi_search* sp, long long* tokens_out, float* logprob_out, int32_t* info_out,
+                         hipStream_t s, bool allow_poll) {
+    SpanGuard total(e, s, 99, 0);
+    RCK(generate_encode(e, frames, F, B, s));
+    return generate_decode(e, B, start_dev, P, sp, tokens_out, logprob_out, info_out, s, allow_poll);
 }
 
 extern "C" int gitmi_generate(gitmi_engine* e, const float* const* frames, int F, int B, const int64_t* prefix, int P,

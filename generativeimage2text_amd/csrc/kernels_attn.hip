@@ -500,7 +500,9 @@ template <> struct Raw8<float> {
 // the 8 groups of a wave are merged with shuffles and the 4 waves through a 1-KB-per-beam LDS exchange.
 // All global loads (q, image K/V of the first 256 keys, text K/V through the beam indirection) are issued
 // before the first use; the kernel is a single memory round trip + ~1 us of arithmetic.
-template <typename T, int KB>
+// PF / TI: image keys per 8-lane group per chunk / text items per group whose loads are issued up front (8 / 5: one
+// memory round trip for 197 image keys and short texts, 144 VGPRs at one beam; 4 / 1 would need 76)
+template <typename T, int KB, int PF = 8, int TI = 5>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     __shared__ float part[4][KB][HD + 2];      // per wave and beam: o[64], m, l
 
@@ -517,8 +519,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     const int row0 = b * k;
     const int grp = tid >> 3, sub = tid & 7;    // 32 groups of 8 lanes; a group reads one 64-dim row at a time
     const int wave = tid >> 6;
-    constexpr int PF = 8;                       // image keys per group per chunk (256 keys per chunk)
-    constexpr int TI = 5;                       // text (beam, position) items per group held in registers
 
     const T* kbase = IMGK + ((size_t)b * H + h) * a.N_img * HD + sub * 8;   // head-major: contiguous per (b, h)
     const T* vbase = IMGV + ((size_t)b * H + h) * a.N_img * HD + sub * 8;
