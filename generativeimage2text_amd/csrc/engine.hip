@@ -417,6 +417,8 @@ static int alloc_workspaces(gitmi_engine* e) {
     RCK(dev_alloc_t(e, &e->out_lp, (size_t)c.max_batch));
     RCK(dev_alloc_t(e, &e->out_info, 4));
     HIPCK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&e->fence_in, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&e->fence_out, hipEventDisableTiming));
     e->frame_stage.resize(c.max_frames);
     for (int f = 0; f < c.max_frames; ++f)
         RCK(dev_alloc_t(e, &e->frame_stage[f], (size_t)c.max_batch * 3 * e->max_pixels));
