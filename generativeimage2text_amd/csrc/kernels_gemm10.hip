@@ -93,6 +93,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
+    const char* __restrict__ Ab = reinterpret_cast<const char*>(g.A);
+    const char* __restrict__ Wb = reinterpret_cast<const char*>(g.W);
 
     // ---- staging sources.  A wave instruction fills 1 KiB = 4 bank rows = 8 tile rows; this wave owns
     // pieces P = 2*wave + q (q = 0,1) of every half tile.  lane -> bank row Rl, half hi, slot lo.
@@ -110,25 +112,15 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
             const int rn = h * 128 + (wave * 2 + q) * 8 + 2 * Rl + (hi ^ q);
             w_off[h][q] = ((uint32_t)(n0 + rn) * (uint32_t)g.K + ch * 8) * 2u;
         }
-    // half tile `half` (0/1) of operand `isw` for K tile kt -> slot of buffer kt & 1.  Buffer loads with an LDS
-    // destination: the per-lane part of the address is a 32-bit VGPR offset, the K advance an SGPR offset and the base a
-    // scalar resource -- eight 64-bit per-lane pointers would cost 8 more VGPRs (226 -> 218: the kernel then fits the
-    // 224-register allocation that leaves 64 VGPRs per SIMD to a workgroup of another stream).
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, 0x7fffffff, 0x00020000);
+    // half tile `half` (0/1) of operand `isw` for K tile kt -> slot of buffer kt & 1
     auto issue = [&](int isw, int half, int kt) {
         if constexpr (DBG & 8) return;
+        const char* src = (isw ? Wb : Ab) + (size_t)kt * (BK * 2);
         unsigned char* dst = smem + (kt & 1) * BUF_BYTES + (isw ? SLOT_B0 : SLOT_A0) + half * HALF_BYTES + wave * 2048;
         const uint32_t o0 = isw ? w_off[half][0] : a_off[half][0];
         const uint32_t o1 = isw ? w_off[half][1] : a_off[half][1];
-        const int koff = kt * (BK * 2);
-        if (isw) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void_t*)(dst), 16, o0, koff, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void_t*)(dst + 1024), 16, o1, koff, 0, 0);
-        } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void_t*)(dst), 16, o0, koff, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_void_t*)(dst + 1024), 16, o1, koff, 0, 0);
-        }
+        __builtin_amdgcn_global_load_lds((const void*)(src + o0), (lds_void_t*)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(src + o1), (lds_void_t*)(dst + 1024), 16, 0, 0);
     };
 
     // ---- fragment addressing (bank-conflict free image, kernels_gemm3.hip) ---------------------------
@@ -180,34 +172,33 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // K tile t.  The last two tiles issue fewer prefetches (the stream of half tiles ends with A1(nk-1)), so their waits
-    // count down 8 -> 4 -> 2 -> 0; `rem` = nk - 1 - t is wave-uniform and the branches are scalar.  (One loop body for
-    // all tiles: peeled copies of the 64-MFMA body made the register allocator shuffle the accumulators.)
-    auto ktile = [&](int t, int rem) {
+    // MODE 0: steady state (t <= nk-3)   MODE 1: t == nk-2   MODE 2: t == nk-1
+    auto ktile = [&](auto mode_c, int t) {
+        constexpr int MODE = decltype(mode_c)::value;
         const unsigned char* sb = smem + (t & 1) * BUF_BYTES;
         // ---- P1
         read_w(sb, 0, wf0);
         __builtin_amdgcn_sched_barrier(0);
         read_a(sb, 0);
-        if (rem >= 1) { issue(1, 1, t + 1); wait_vm<8>(); } else { wait_vm<2>(); }
+        if constexpr (MODE <= 1) { issue(1, 1, t + 1); wait_vm<8>(); } else { wait_vm<2>(); }
         P8_BARRIER();
         mma(acc[0][0], wf0);
         P8_BARRIER();
         // ---- P2
         read_w(sb, 1, wf1);
-        if (rem >= 1) { issue(0, 1, t + 1); wait_vm<8>(); } else { wait_vm<0>(); }
+        if constexpr (MODE <= 1) { issue(0, 1, t + 1); wait_vm<8>(); } else { wait_vm<0>(); }
         P8_BARRIER();
         mma(acc[0][1], wf1);
         P8_BARRIER();
         // ---- P3
         read_a(sb, 1);
-        if (rem >= 2) { issue(0, 0, t + 2); wait_vm<8>(); }
+        if constexpr (MODE == 0) { issue(0, 0, t + 2); wait_vm<8>(); }
         P8_BARRIER();
         mma(acc[1][1], wf1);
         P8_BARRIER();
         // ---- P4
-        if (rem >= 2) { issue(1, 0, t + 2); wait_vm<8>(); }
-        else if (rem == 1) { wait_vm<4>(); }
+        if constexpr (MODE == 0) { issue(1, 0, t + 2); wait_vm<8>(); }
+        else if constexpr (MODE == 1) { wait_vm<4>(); }
         P8_BARRIER();
         mma(acc[1][0], wf0);
         P8_BARRIER();
@@ -218,7 +209,9 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     wait_vm<8>();                                                  // A0(0), B0(0) of this wave have landed
     P8_BARRIER();
     if (grp == 1) P8_BARRIER();                                    // group 1 runs one barrier behind
-    for (int t = 0; t < nk; ++t) ktile(t, nk - 1 - t);
+    for (int t = 0; t < nk - 2; ++t) ktile(std::integral_constant<int, 0>{}, t);
+    ktile(std::integral_constant<int, 1>{}, nk - 2);
+    ktile(std::integral_constant<int, 2>{}, nk - 1);
     if (grp == 0) P8_BARRIER();
 
     // ---- epilogue through LDS: slab = MH rows (qm) x WCOL columns ---------------------------------
@@ -244,6 +237,14 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         if (sum == 12345.678f) C[0] = (TOut)0;
         return;
     }
+    f32x4_t bias4[2][2];
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            bias4[qn][j] = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + n0 + qn * 128 + wc * 32 + j * 16 + lg * 4)
+                                  : f32x4_t{0.f, 0.f, 0.f, 0.f};
+
 #pragma unroll
     for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
@@ -254,15 +255,11 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int nl = u * 128 + wc * 32 + j * 16 + lg * 4;
-                    // (re-read per slab: 16 live bias registers next to 128 accumulators would push the kernel over
-                    // the 224-VGPR allocation)
-                    const f32x4_t b4 = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + n0 + qn * 128 + wc * 32 + j * 16 + lg * 4)
-                                              : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
                         float v[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = apply_act_t<ACT>(acc[qm][qn][j][i][r] + b4[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = apply_act_t<ACT>(acc[qm][qn][j][i][r] + bias4[qn][j][r]);
                         TOut* p = ep + (grp * (MH / 2) + i * 16 + l15) * EPS + nl;
                         if constexpr (sizeof(TOut) == 4) {
                             *reinterpret_cast<f32x4_t*>(p) = f32x4_t{v[0], v[1], v[2], v[3]};
@@ -276,7 +273,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                 }
             }
             __syncthreads();
-#pragma unroll 2
+#pragma unroll 4
             for (int q = 0; q < MH * CPR / 512; ++q) {
                 const int chunk = tid + q * 512;
                 const int row = chunk / CPR, cc = chunk % CPR;
@@ -342,7 +339,7 @@ static void launch_p8_t(const GemmArgs& g, hipStream_t s) {
 
 bool gemm_p8_supports(const GemmArgs& g) {
     return g.K % BK == 0 && g.K >= 2 * BK && g.N % BN == 0 &&
-           (double)g.M * g.lda * 2.0 < 2.0e9 && (double)g.N * g.K * 2.0 < 2.0e9;    // 32-bit buffer offsets
+           (double)g.M * g.lda * 2.0 < 4.0e9 && (double)g.N * g.K * 2.0 < 4.0e9;
 }
 
 // Partition of the tile grid over the 8 XCDs for tile height 2*mh: the N tiles are cut into ng groups, the 8/ng XCDs
