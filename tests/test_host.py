@@ -147,3 +147,16 @@ def test_every_entry_point_has_ctypes_prototypes():
         if name in ("gitmi_abi_version", "gitmi_last_error"):
             continue
         assert getattr(lib, name).argtypes is not None, name
+
+
+def test_config_struct_fields_agree_across_header_binding_and_integration_doc():
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "gitmi.h")).read()
+    body = hdr[hdr.index("typedef struct gitmi_config {"):hdr.index("} gitmi_config;")]
+    header_fields = re.findall(r"int32_t\s+(\w+);", body)
+    assert header_fields == [n for n, _ in engine.GitmiConfig._fields_]
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class Cfg(C.Structure):"):doc.index("class Search(C.Structure):")]
+    doc_fields = " ".join(re.findall(r'"([^"]+)"', stub)).split()
+    assert doc_fields == header_fields
