@@ -520,8 +520,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
     const int grp = tid >> 3, sub = tid & 7;    // 32 groups of 8 lanes; a group reads one 64-dim row at a time
     const int wave = tid >> 6;
 
-    const T* kbase = IMGK + ((size_t)b * H + h) * a.N_img * HD + sub * 8;   // head-major: contiguous per (b, h)
-    const T* vbase = IMGV + ((size_t)b * H + h) * a.N_img * HD + sub * 8;
+    const int bi = a.img_of ? a.img_of[b] : b;                             // sentence -> image (several questions per image)
+    const T* kbase = IMGK + ((size_t)bi * H + h) * a.N_img * HD + sub * 8;  // head-major: contiguous per (image, h)
+    const T* vbase = IMGV + ((size_t)bi * H + h) * a.N_img * HD + sub * 8;
     const int nt = a.pos + 1;
 
     // ---- issue every load up front -------------------------------------------------------------------
@@ -531,7 +532,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
         const int it = grp + 32 * u;
         t_j[u] = it < k * nt ? it / nt : -1;
         t_s[u] = it < k * nt ? it % nt : 0;
-        t_row[u] = (t_j[u] >= 0 && t_s[u] != a.pos) ? a.kv_src[(size_t)(row0 + t_j[u]) * a.ld_src + t_s[u]] : 0;
+        // one beam: histories are never re-ordered, the cache row is the row itself (no dependent index load)
+        if constexpr (KB == 1) t_row[u] = row0;
+        else t_row[u] = (t_j[u] >= 0 && t_s[u] != a.pos) ? a.kv_src[(size_t)(row0 + t_j[u]) * a.ld_src + t_s[u]] : 0;
     }
     Raw8<T> qr[KB];
 #pragma unroll
@@ -672,7 +675,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
             ld8(QKV + (size_t)(row0 + j) * ld3 + a.d + h * HD + sub * 8, kv);
             ld8(QKV + (size_t)(row0 + j) * ld3 + 2 * a.d + h * HD + sub * 8, vv);
         } else {
-            const int srow = a.kv_src[(size_t)(row0 + j) * a.ld_src + sidx];
+            const int srow = KB == 1 ? row0 : a.kv_src[(size_t)(row0 + j) * a.ld_src + sidx];
             ld8(TK + ((size_t)srow * a.T_max + sidx) * a.d + h * HD + sub * 8, kv);
             ld8(TV + ((size_t)srow * a.T_max + sidx) * a.d + h * HD + sub * 8, vv);
         }

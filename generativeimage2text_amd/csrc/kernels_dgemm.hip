@@ -1,0 +1,449 @@
+// Decode-step GEMM family (bf16, gfx950): the 5-launches-per-layer chain of the KV-cached decode step.
+//
+// A decode step multiplies R = B*beams rows (64..256) by every decoder matrix once.  Each launch is a short
+// dependent stage (one HBM round trip + a few hundred MFMAs), so what matters is the NUMBER of stages and that no
+// stage does redundant row work.  Round 1 ran 7 launches per layer (QKV, attention, out-proj split-K, sum+LayerNorm,
+// FFN1, FFN2 split-K, sum+LayerNorm); the two LayerNorm launches are gone here:
+//
+//   * the N = 768 GEMMs (BertSelfOutput / BertOutput dense, modeling_bert.py:171-178, 243-250) write the PRE-LayerNorm
+//     sum x = A W^T + bias + residual (fp32 + a bf16 copy) and, per 16-column strip, the row partials (sum x, sum x^2)
+//     of their own columns -- no split-K slabs, no LayerNorm launch;
+//   * the next GEMM (QKV / FFN1 / vocabulary head) consumes bf16(x) directly as its MFMA operand with the LayerNorm
+//     FOLDED into weights and epilogue:
+//         LN(x) W^T + b  =  rstd * ( x (W . gamma)^T  -  mean * colsum(W . gamma) )  +  ( beta W^T + b )
+//     (W' = bf16(W . gamma), colsum over the bf16-rounded W', the constant in fp32 -- all prepared at weight
+//     finalisation).  mean / rstd of a row come from the 48 strip partials (fixed summation order);
+//   * the residual of a post-norm layer is the NORMALISED hidden state: the N = 768 epilogue rebuilds it on the fly
+//     from the previous raw x and its strip partials, so the normalised tensor is never materialised either.
+//
+// Kernel shape (all variants): a workgroup owns 16*MT rows x one 16-column strip, the K range is split over its NW
+// waves, MFMA fragments come straight from global memory (weights are read once, activations from L2; no LDS staging,
+// all loads of a chunk in flight before the first MFMA), partial accumulators are exchanged through LDS and summed
+// in a FIXED order -- deterministic, batch-invariant (a row's result does not depend on which rows share its tile).
+//
+// The vocabulary head (`vocab_topm_kernel`) keeps its 64-row activation fragments in registers and sweeps 128
+// columns per workgroup (weights double-buffered), applies the no-repeat rule (decoder.py:330), and keeps a running
+// per-row top-M and log-sum-exp in registers: logits never reach HBM (decoder.py:1054, 1169-1175 fused); what is
+// written is one sorted candidate list + (max, sum-exp) per (row, workgroup), merged by the search kernel.
+#include "gitmi_common.h"
+#include "launchers.h"
+#include <type_traits>
+
+namespace gitmi {
+
+// ---- row statistics from strip partials --------------------------------------------------------------
+// stats[strip][row] = (sum, sum of squares) over the strip's 16 columns.  The 4 lanes that share a row (lane>>4 = 0..3)
+// each take strips lg, lg+4, ... and combine with two shuffles; every lane ends with (mean, rstd) of its row.
+constexpr int STRIP_SLOTS = 16;          // per lane: up to 64 strips = 1024 columns
+
+struct RowStatLoads {
+    float2 v[STRIP_SLOTS];
+};
+__device__ __forceinline__ void stats_issue(RowStatLoads& L, const float2* __restrict__ stats, int strips, int M,
+                                            int row, int lg) {
+#pragma unroll
+    for (int u = 0; u < STRIP_SLOTS; ++u) {
+        const int sidx = lg + 4 * u;
+        L.v[u] = sidx < strips ? stats[(size_t)sidx * M + row] : float2{0.f, 0.f};
+    }
+}
+__device__ __forceinline__ void stats_finish(const RowStatLoads& L, float inv_d, float eps, float& mean, float& rstd) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int u = 0; u < STRIP_SLOTS; ++u) { s += L.v[u].x; q += L.v[u].y; }
+    s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+    s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+    mean = s * inv_d;
+    const float var = fmaxf(q * inv_d - mean * mean, 0.f);
+    rstd = rsqrtf(var + eps);
+}
+
+enum { DEPI_BF16 = 0, DEPI_RES = 1 };
+
+// grid = (ceil(N/16), ceil(M/(16*MT))); block = 64*NW
+template <int MT, int NW, int EPI>
+__global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs g) {
+    __shared__ __attribute__((aligned(16))) f32x4_t red[NW][MT][64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MT);
+
+    const bf16_t* __restrict__ X = g.A;
+    const bf16_t* __restrict__ W = g.W;
+
+    // the tile this wave finishes (if any) and the row/columns this lane finishes in it
+    const bool finisher = wave < MT;
+    const int fi = wave;                                  // m-tile finished by this wave
+    const int fm_raw = m0 + fi * 16 + l15;
+    const int fm = fm_raw < g.M ? fm_raw : g.M - 1;
+    const int fn = n0 + lg * 4;
+
+    // ---- early, latency-hiding loads of everything the epilogue needs ------------------------------------
+    RowStatLoads sl;
+    bool have_stats = false;
+    float4 ep_a = {0.f, 0.f, 0.f, 0.f}, ep_b = ep_a, ep_c = ep_a, ep_d = ep_a;
+    auto ld4 = [&](const float* p, int n) {
+        float4 r;
+        r.x = p[n < g.N ? n : g.N - 1];
+        r.y = p[n + 1 < g.N ? n + 1 : g.N - 1];
+        r.z = p[n + 2 < g.N ? n + 2 : g.N - 1];
+        r.w = p[n + 3 < g.N ? n + 3 : g.N - 1];
+        return r;
+    };
+    if (finisher) {
+        ep_a = ld4(g.bias, fn);
+        if constexpr (EPI == DEPI_BF16) {
+            if (g.stats_in) {
+                stats_issue(sl, g.stats_in, g.strips_in, g.M, fm, lg);
+                have_stats = true;
+                ep_b = ld4(g.colsum, fn);
+            }
+        } else {
+            // residual source (always 16-byte aligned: N % 16 == 0 for this epilogue)
+            ep_b = *reinterpret_cast<const float4*>(g.res_x + (size_t)fm * g.N + fn);
+            if (g.res_stats) {
+                stats_issue(sl, g.res_stats, g.res_strips, g.M, fm, lg);
+                have_stats = true;
+                ep_c = *reinterpret_cast<const float4*>(g.res_gamma + fn);
+                ep_d = *reinterpret_cast<const float4*>(g.res_beta + fn);
+            }
+        }
+    }
+
+    // ---- K range of this wave, operand pointers ----------------------------------------------------------
+    const int ksteps = g.K >> 5;
+    const int per = (ksteps + NW - 1) / NW;
+    const int kb = wave * per;
+    const int ke = min(kb + per, ksteps);
+
+    int wn = n0 + l15;
+    wn = wn < g.N ? wn : g.N - 1;
+    const bf16_t* wp = W + (size_t)wn * g.K + lg * 8;
+    const bf16_t* xp[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = m0 + i * 16 + l15;
+        m = m < g.M ? m : g.M - 1;
+        xp[i] = X + (size_t)m * g.lda + lg * 8;
+    }
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto chunk = [&](auto UC, int k0) {
+        constexpr int U = decltype(UC)::value;
+        bf16x8_t wf[U], xf[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)(k0 + u) * 32));
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xf[u][i] = *reinterpret_cast<const bf16x8_t*>(xp[i] + (size_t)(k0 + u) * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[u][i], acc[i], 0, 0, 0);
+    };
+    constexpr int UBIG = MT >= 4 ? 6 : 12;       // <= 30 sixteen-byte loads in flight per lane
+    int k = kb;
+    for (; k + UBIG <= ke; k += UBIG) chunk(std::integral_constant<int, UBIG>{}, k);
+    for (; k + 2 <= ke; k += 2) chunk(std::integral_constant<int, 2>{}, k);
+    for (; k < ke; ++k) chunk(std::integral_constant<int, 1>{}, k);
+
+    // ---- cross-wave reduction: every wave publishes all its tiles; wave i sums tile i over the writers 0..NW-1 --
+#pragma unroll
+    for (int i = 0; i < MT; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    if (!finisher) return;
+    f32x4_t tot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const f32x4_t t = red[w][fi][lane];
+        tot[0] += t[0]; tot[1] += t[1]; tot[2] += t[2]; tot[3] += t[3];
+    }
+    float v[4] = {tot[0], tot[1], tot[2], tot[3]};
+    const float biasv[4] = {ep_a.x, ep_a.y, ep_a.z, ep_a.w};
+
+    if constexpr (EPI == DEPI_BF16) {
+        if (have_stats) {
+            float mean, rstd;
+            stats_finish(sl, g.inv_d, g.eps_in, mean, rstd);
+            const float cs[4] = {ep_b.x, ep_b.y, ep_b.z, ep_b.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * cs[r]) + biasv[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += biasv[r];
+        }
+        if (g.act != GITMI_ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], g.act);
+        }
+        if (fm_raw >= g.M || fn >= g.N) return;
+        bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (size_t)fm * g.ldc + fn;
+        if (fn + 3 < g.N && (g.ldc & 3) == 0) {
+            uint2 t;
+            t.x = pack2bf(v[0], v[1]);
+            t.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(cp) = t;
+        } else {
+            for (int r = 0; r < 4; ++r)
+                if (fn + r < g.N) cp[r] = f2bf(v[r]);
+        }
+    } else {
+        // x = A W^T + bias + residual, residual = LayerNorm_prev(x_prev) rebuilt from its strip partials
+        float res[4] = {ep_b.x, ep_b.y, ep_b.z, ep_b.w};
+        if (have_stats) {
+            float mean, rstd;
+            stats_finish(sl, g.res_inv_d, g.res_eps, mean, rstd);
+            const float gm[4] = {ep_c.x, ep_c.y, ep_c.z, ep_c.w}, bt[4] = {ep_d.x, ep_d.y, ep_d.z, ep_d.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) res[r] = (res[r] - mean) * rstd * gm[r] + bt[r];
+        }
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] += biasv[r] + res[r];
+            s += v[r];
+            q += v[r] * v[r];
+        }
+        s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+        s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+        if (fm_raw >= g.M) return;
+        *reinterpret_cast<f32x4_t*>(g.x_out + (size_t)fm * g.N + fn) = f32x4_t{v[0], v[1], v[2], v[3]};
+        uint2 t;
+        t.x = pack2bf(v[0], v[1]);
+        t.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(g.xb_out + (size_t)fm * g.N + fn) = t;
+        if (lg == 0) g.stats_out[(size_t)blockIdx.x * g.M + fm] = float2{s, q};
+    }
+}
+
+// ---- vocabulary head + running top-M / log-sum-exp ---------------------------------------------------------
+// grid = (ceil(V / cols_per_wg), ceil(M/(16*MT))); block = 256 (K split over 4 waves, K <= 768)
+constexpr int VKS = 6;      // k-steps of 32 per wave held in registers
+
+template <int MT, int MTOP>
+__global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
+    __shared__ __attribute__((aligned(16))) f32x4_t red[2][4][MT][64];     // double-buffered exchange: one barrier per strip
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int m0 = blockIdx.y * (16 * MT);
+    const int c0 = blockIdx.x * g.cols_per_wg;
+    const int ncols = max(0, min(g.cols_per_wg, g.N - c0));
+    const int nstrips = (ncols + 15) / 16;
+
+    const bool finisher = wave < MT;
+    const int fm_raw = m0 + wave * 16 + l15;
+    const int fm = fm_raw < g.M ? fm_raw : g.M - 1;
+
+    RowStatLoads sl;
+    const bool fold = g.stats_in != nullptr;
+    int last_tok = -1;
+    if (finisher) {
+        if (fold) stats_issue(sl, g.stats_in, g.strips_in, g.M, fm, lg);
+        if (g.ids) {
+            const int sent = fm / g.beams;
+            const bool suppress = g.suppress_kind && g.cur_len > g.plen[sent];      // decoder.py:330 (not on a sentence's first step)
+            if (suppress) last_tok = g.ids[(size_t)fm * g.ld_ids + g.cur_len - 1];
+        }
+    }
+
+    // ---- activation fragments of this wave's K range: loaded once, kept for every strip ------------------
+    const int ksteps = g.K >> 5;
+    const int per = (ksteps + 3) / 4;
+    const int kb = wave * per;
+    const int ks = max(0, min(kb + per, ksteps) - kb);        // <= VKS (checked by the launcher)
+    bf16x8_t xf[VKS][MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = m0 + i * 16 + l15;
+        m = m < g.M ? m : g.M - 1;
+        const bf16_t* xp = g.A + (size_t)m * g.lda + lg * 8 + (size_t)kb * 32;
+#pragma unroll
+        for (int u = 0; u < VKS; ++u) {
+            if (u < ks) xf[u][i] = *reinterpret_cast<const bf16x8_t*>(xp + (size_t)u * 32);
+            else xf[u][i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    auto load_w = [&](bf16x8_t (&wf)[VKS], int strip) {
+        int n = c0 + strip * 16 + l15;
+        n = n < g.N ? n : g.N - 1;
+        const bf16_t* wp = g.W + (size_t)n * g.K + lg * 8 + (size_t)kb * 32;
+#pragma unroll
+        for (int u = 0; u < VKS; ++u) {
+            if (u < ks) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)u * 32));
+            else wf[u] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+
+    // running per-lane state of the finisher: sorted top-MTOP of its 4 columns per strip, online log-sum-exp
+    float tv[MTOP];
+    int ti[MTOP];
+#pragma unroll
+    for (int j = 0; j < MTOP; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+    float mx = -INFINITY, sm = 0.f;
+    float mean = 0.f, rstd = 1.f;
+
+    bf16x8_t wa[VKS], wb[VKS];
+    if (nstrips > 0) load_w(wa, 0);
+
+    auto do_strip = [&](bf16x8_t (&wcur)[VKS], bf16x8_t (&wnext)[VKS], int strip) {
+        if (strip + 1 < nstrips) load_w(wnext, strip + 1);          // prefetch: in flight during this strip's MFMAs
+        f32x4_t acc[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < VKS; ++u)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur[u], xf[u][i], acc[i], 0, 0, 0);
+        const int buf = strip & 1;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) red[buf][wave][i][lane] = acc[i];
+        __syncthreads();
+        if (finisher) {
+            f32x4_t tot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f32x4_t t = red[buf][w][wave][lane];
+                tot[0] += t[0]; tot[1] += t[1]; tot[2] += t[2]; tot[3] += t[3];
+            }
+            const int n = c0 + strip * 16 + lg * 4;
+            float v[4] = {tot[0], tot[1], tot[2], tot[3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = n + r < g.N ? n + r : g.N - 1;
+                const float b = g.bias[nn];
+                if (fold) v[r] = rstd * (v[r] - mean * g.colsum[nn]) + b;
+                else v[r] += b;
+            }
+            if (g.logits_out && fm_raw < g.M) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < g.N) g.logits_out[(size_t)fm * g.ld_logits + n + r] = v[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = v[r];
+                const int idx = n + r;
+                if (idx >= g.N) continue;
+                if (idx == last_tok) x = -10000.f;
+                if (x > mx) { sm = sm * fast_exp(mx - x) + 1.f; mx = x; }
+                else sm += fast_exp(x - mx);
+                if (x > tv[MTOP - 1]) {
+                    tv[MTOP - 1] = x; ti[MTOP - 1] = idx;
+#pragma unroll
+                    for (int j = MTOP - 1; j > 0; --j) {
+                        if (tv[j] > tv[j - 1]) {
+                            const float a = tv[j]; tv[j] = tv[j - 1]; tv[j - 1] = a;
+                            const int c = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = c;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    if (finisher && fold) stats_finish(sl, g.inv_d, g.eps_in, mean, rstd);
+    for (int strip = 0; strip < nstrips; strip += 2) {
+        do_strip(wa, wb, strip);
+        if (strip + 1 < nstrips) do_strip(wb, wa, strip + 1);
+    }
+    if (!finisher) return;
+
+    // ---- merge the 4 lanes of a row (equal lane & 15): log-sum-exp, then MTOP rounds of 4-way arg-max ------
+    float bm = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    float part = mx == -INFINITY ? 0.f : sm * fast_exp(mx - bm);
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    const size_t slot = (size_t)fm * gridDim.x + blockIdx.x;
+    const bool writer = lg == 0 && fm_raw < g.M;
+    if (writer) g.part_lse[slot] = float2{bm, part};
+#pragma unroll
+    for (int round = 0; round < MTOP; ++round) {
+        float v = tv[0];
+        int id = ti[0];
+        int who = lg;
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            const float ov = __shfl_xor(v, o, 64);
+            const int oi = __shfl_xor(id, o, 64);
+            const int ow = __shfl_xor(who, o, 64);
+            if (ov > v || (ov == v && oi < id)) { v = ov; id = oi; who = ow; }
+        }
+        if (writer) {
+            g.part_val[slot * MTOP + round] = v;
+            g.part_idx[slot * MTOP + round] = id;
+        }
+        if (who == lg) {                                   // pop the winner's head (static shifts: no dynamic register index)
+#pragma unroll
+            for (int j = 0; j + 1 < MTOP; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
+            tv[MTOP - 1] = -INFINITY; ti[MTOP - 1] = 0x7fffffff;
+        }
+    }
+}
+
+// ---- host launchers ------------------------------------------------------------------
+template <int EPI>
+static hipError_t launch_dgemm_t(const DGemmArgs& g, hipStream_t s) {
+    // rows per workgroup: all of a <=64-row batch share one pass over the weight strip when the strip count alone
+    // fills the chip (N >= 2304); the N = 768 GEMMs use 16-row blocks so that 48 strips x R/16 workgroups do
+    const bool wide = g.N >= 1536;
+    const int big_k = g.K >= 2048;
+    if (EPI == DEPI_RES || !wide) {
+        dim3 grid((g.N + 15) / 16, (g.M + 15) / 16);
+        if (big_k) hipLaunchKernelGGL((dgemm_kernel<1, 8, EPI>), grid, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((dgemm_kernel<1, 4, EPI>), grid, dim3(256), 0, s, g);
+    } else if (g.M <= 16) {
+        hipLaunchKernelGGL((dgemm_kernel<1, 4, EPI>), dim3((g.N + 15) / 16, 1), dim3(256), 0, s, g);
+    } else if (g.M <= 32) {
+        hipLaunchKernelGGL((dgemm_kernel<2, 4, EPI>), dim3((g.N + 15) / 16, 1), dim3(256), 0, s, g);
+    } else {
+        hipLaunchKernelGGL((dgemm_kernel<4, 4, EPI>), dim3((g.N + 15) / 16, (g.M + 63) / 64), dim3(256), 0, s, g);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_dgemm(const DGemmArgs& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (g.K % 32 != 0 || !g.bias) return hipErrorInvalidValue;
+    if (g.stats_in && (!g.colsum || g.strips_in > 4 * STRIP_SLOTS)) return hipErrorInvalidValue;
+    if (g.x_out) {
+        if ((g.N & 15) || !g.xb_out || !g.stats_out || !g.res_x) return hipErrorInvalidValue;
+        if (g.res_stats && (g.res_strips > 4 * STRIP_SLOTS || !g.res_gamma || !g.res_beta)) return hipErrorInvalidValue;
+        return launch_dgemm_t<DEPI_RES>(g, s);
+    }
+    if (!g.C) return hipErrorInvalidValue;
+    return launch_dgemm_t<DEPI_BF16>(g, s);
+}
+
+int vocab_parts(int V, int cols_per_wg) { return (V + cols_per_wg - 1) / cols_per_wg; }
+int vocab_mtop_slots(int mtop) { return mtop <= 1 ? 1 : mtop <= 2 ? 2 : mtop <= 4 ? 4 : mtop <= 8 ? 8 : 16; }
+
+template <int MTOP>
+static hipError_t launch_vocab_m(const VocabArgs& g, hipStream_t s) {
+    const int nwg = vocab_parts(g.N, g.cols_per_wg);
+    if (g.M <= 16) hipLaunchKernelGGL((vocab_topm_kernel<1, MTOP>), dim3(nwg, 1), dim3(256), 0, s, g);
+    else if (g.M <= 32) hipLaunchKernelGGL((vocab_topm_kernel<2, MTOP>), dim3(nwg, 1), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((vocab_topm_kernel<4, MTOP>), dim3(nwg, (g.M + 63) / 64), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_vocab_topm(const VocabArgs& g, int mtop, hipStream_t s) {
+    if (g.M <= 0) return hipSuccess;
+    if (g.K % 32 != 0 || (g.K >> 5) > 4 * VKS || g.cols_per_wg % 16 != 0 || mtop < 1 || mtop > 16)
+        return hipErrorInvalidValue;
+    if (g.stats_in && (!g.colsum || g.strips_in > 4 * STRIP_SLOTS)) return hipErrorInvalidValue;
+    if (mtop <= 1) return launch_vocab_m<1>(g, s);
+    if (mtop <= 2) return launch_vocab_m<2>(g, s);
+    if (mtop <= 4) return launch_vocab_m<4>(g, s);
+    if (mtop <= 8) return launch_vocab_m<8>(g, s);
+    return launch_vocab_m<16>(g, s);
+}
+
+}  // namespace gitmi

@@ -265,6 +265,10 @@ __global__ void copy_f32_kernel(const float* __restrict__ src, int lds, float* _
     }
 }
 
+__global__ void fill_i32_kernel(int* __restrict__ dst, int value, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = value;
+}
+
 // ---- host launchers ------------------------------------------------------------------
 static inline int grid_for(size_t total, int block) {
     size_t g = (total + block - 1) / block;
@@ -338,6 +342,12 @@ hipError_t launch_convert_pad(const float* src, void* dst, bool dst_f32, size_t 
     else
         hipLaunchKernelGGL(convert_pad_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, src,
                            (bf16_t*)dst, rows, K, Kpad);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_i32(int* dst, int value, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for((size_t)n, 256)), dim3(256), 0, s, dst, value, n);
     return hipGetLastError();
 }
 

@@ -1,19 +1,24 @@
 // Device-side search: the whole bookkeeping of AutoRegressiveBeamSearch.search
 // (decoder.py:224-440) and GeneratorWithBeamSearch.search + BeamHypotheses
-// (decoder.py:1083-1341) runs in two small kernels per decode step, so the decode loop has
-// no host<->device synchronisation at all (the reference does ~10^3 .item() syncs per step
-// at B=64, k=4).
+// (decoder.py:1083-1341) runs on the device, so the decode loop has no host<->device
+// synchronisation at all (the reference does ~10^3 .item() syncs per step at B=64, k=4).
 //
-//   row_topm   : per row r of the beam batch: optional "no immediate repeat" (-10000 on the
-//                last token's logit, decoder.py:330), optional forced-EOS rows
-//                (decoder.py:347-351), log-softmax (online max / sum-exp) and the M best
-//                (log-prob, token) pairs, sorted.  One block per row, one pass over the logits.
-//   s1_advance : AutoRegressiveBeamSearch step for every image (top-k over k*per_node
-//                candidates, beam gather) + "all beams ended" detection.
-//   s2_advance : GeneratorWithBeamSearch step for every image: merge the k sorted candidate
-//                lists into the top-2k of the flattened [k*V] axis, then the per-sentence loop
-//                of decoder.py:1184-1222 (is_done, hypotheses, next beam, padding rule).
-//   finish     : select outputs.
+//   row_topm     : (fp32 parity path / caller-supplied logits) per row: optional "no immediate repeat"
+//                  (-10000 on the last token's logit, decoder.py:330), online max / sum-exp and the M best
+//                  (logit, token) pairs, sorted -- written in the same "partial list" format the fused
+//                  vocabulary head of the bf16 path emits (kernels_dgemm.hip), with one part per row.
+//   search_step  : ONE workgroup per sentence and step: merges the row's partial candidate lists into the top-M
+//                  log-probabilities (log-softmax = logit - logsumexp), then runs the step of the sentence's
+//                  search class, re-orders the beam histories, and finally embeds the k chosen tokens
+//                  (word + position + LayerNorm, decoder.py:65-78) for the next decode step -- selection,
+//                  beam bookkeeping and the next step's embedding are one launch.
+//                    AUTOREGRESSIVE: decoder.py:257-298 (first step), 313-417
+//                    GENERATOR     : decoder.py:1169-1232 + BeamHypotheses 1292-1341 (n_hyp = 1)
+//   finish       : select outputs.
+//
+// Sentences may carry their own prefix (VQA questions of different lengths in one batch; the reference runs them
+// one at a time, decoder.py:984-989): while cur_len < plen[b] the step simply appends the given token.  All
+// sentences sit at the same text position in every step, so no padding or position shifting is involved.
 //
 // Beams are re-ordered by index only: ids are gathered, and kv_src[row][pos] (the cache row
 // that holds the K/V of text position pos for this row's history) is gathered with them.
@@ -26,8 +31,9 @@ namespace gitmi {
 template <int MMAX, int NT>
 __global__ __launch_bounds__(NT) void row_topm_kernel(const float* __restrict__ logits, int ldl, int V,
                                                        const int* __restrict__ ids, int ld_ids, int cur_len,
-                                                       int eos, int suppress_last, int force_eos, int M,
-                                                       float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+                                                       const int* __restrict__ plen, int beams, int suppress_kind,
+                                                       float* __restrict__ part_val, int* __restrict__ part_idx,
+                                                       float2* __restrict__ part_lse) {
     constexpr int NW = NT / 64;
     __shared__ float s_val[NT * MMAX];
     __shared__ int s_idx[NT * MMAX];
@@ -37,18 +43,10 @@ __global__ __launch_bounds__(NT) void row_topm_kernel(const float* __restrict__ 
 
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* x = logits + (size_t)r * ldl;
-    const int last = ids[(size_t)r * ld_ids + cur_len - 1];
-    float* cv = cand_val + (size_t)r * M;
-    int* ci = cand_idx + (size_t)r * M;
-
-    if (force_eos && last == eos) {
-        // one-hot distribution on EOS (decoder.py:300-310, 347-351): log-prob 0, everything else -inf
-        if (tid < M) {
-            cv[tid] = tid == 0 ? 0.f : -INFINITY;
-            ci[tid] = tid == 0 ? eos : (tid - 1 < eos ? tid - 1 : tid);
-        }
-        return;
-    }
+    const bool suppress = suppress_kind && cur_len > plen[r / beams];
+    const int last = suppress ? ids[(size_t)r * ld_ids + cur_len - 1] : -1;
+    float* cv = part_val + (size_t)r * MMAX;
+    int* ci = part_idx + (size_t)r * MMAX;
 
     float tv[MMAX];
     int ti[MMAX];
@@ -56,7 +54,7 @@ __global__ __launch_bounds__(NT) void row_topm_kernel(const float* __restrict__ 
     for (int j = 0; j < MMAX; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
     float mx = -INFINITY, sm = 0.f;
     auto feed = [&](float v, int i) {
-        if (suppress_last && i == last) v = -10000.f;
+        if (i == last) v = -10000.f;
         // online log-sum-exp
         if (v > mx) { sm = sm * __expf(mx - v) + 1.f; mx = v; }
         else sm += __expf(v - mx);
@@ -94,7 +92,7 @@ __global__ __launch_bounds__(NT) void row_topm_kernel(const float* __restrict__ 
     } else {
         for (int i = tid; i < V; i += NT) feed(x[i], i);
     }
-    // block log-sum-exp
+    // block max / sum-exp
     float bmx = wave_max(mx);
     if (lane == 0) s_red[wave] = bmx;
     __syncthreads();
@@ -110,12 +108,12 @@ __global__ __launch_bounds__(NT) void row_topm_kernel(const float* __restrict__ 
     float tot = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) tot += s_red[NW + w];
-    const float lse = bmx + logf(tot);
+    if (tid == 0) part_lse[r] = float2{bmx, tot};
     __syncthreads();
 
-    // M rounds of block arg-max over the heads of the 256 sorted per-thread lists
+    // MMAX rounds of block arg-max over the heads of the per-thread sorted lists
     int head = 0;
-    for (int round = 0; round < M; ++round) {
+    for (int round = 0; round < MMAX; ++round) {
         float v = head < MMAX ? s_val[tid * MMAX + head] : -INFINITY;
         int id = head < MMAX ? s_idx[tid * MMAX + head] : 0x7fffffff;
         int who = tid;
@@ -133,8 +131,8 @@ __global__ __launch_bounds__(NT) void row_topm_kernel(const float* __restrict__ 
 #pragma unroll
             for (int w = 1; w < NW; ++w)
                 if (s_red[w] > bv || (s_red[w] == bv && s_redi[w] < bi)) { bv = s_red[w]; bi = s_redi[w]; bw = s_redi[NW + w]; }
-            cv[round] = bv - lse;
-            ci[round] = bi == 0x7fffffff ? 0 : bi;
+            cv[round] = bv;
+            ci[round] = bi;
             s_owner = bw;
         }
         __syncthreads();
@@ -144,217 +142,335 @@ __global__ __launch_bounds__(NT) void row_topm_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
-// AutoRegressiveBeamSearch.  One thread per image, single block.
-//   first == 1 : decoder.py:257-298 (top-k of beam 0's distribution, all beams share the prefix)
-//   first == 0 : decoder.py:313-417
-// cur_len = number of tokens currently in ids (before appending).
-// ---------------------------------------------------------------------------------------
-__global__ void s1_advance_kernel(SearchState st, int src, int cur_len, int first, int M) {
-    __shared__ int s_all_eos;
-    const int dst = src ^ 1;
-    const int R = st.B * st.k;
-    if (threadIdx.x == 0) s_all_eos = 1;
-    __syncthreads();
-    if (!first) {
-        // decoder.py:319: stop when every beam's last token is EOS (the step is idempotent after that)
-        int ok = 1;
-        for (int r = threadIdx.x; r < R; r += blockDim.x)
-            if (st.ids[src][(size_t)r * st.T + cur_len - 1] != st.eos) ok = 0;
-        if (!ok) s_all_eos = 0;
-        __syncthreads();
-        if (threadIdx.x == 0 && s_all_eos && st.info[0] == 0) st.info[0] = cur_len;
-    }
-    for (int b = threadIdx.x; b < st.B; b += blockDim.x) {
-        const int k = st.k, pn = st.pn;
-        int chosen_src[16];
-        if (first) {
-            const int r0 = b * k;
-            for (int j = 0; j < k; ++j) {
-                const int r = r0 + j;
-                for (int s = 0; s < cur_len; ++s) {
-                    st.ids[dst][(size_t)r * st.T + s] = st.ids[src][(size_t)r0 * st.T + s];
-                    st.kv_src[dst][(size_t)r * st.T + s] = st.kv_src[src][(size_t)r0 * st.T + s];
-                }
-                st.ids[dst][(size_t)r * st.T + cur_len] = st.cand_idx[(size_t)r0 * M + j];
-                st.kv_src[dst][(size_t)r * st.T + cur_len] = r;
-                st.score[dst][r] = st.cand_val[(size_t)r0 * M + j];
-            }
-        } else {
-            // top-k (sorted) of the k*pn summed candidates, ties -> lower candidate index
-            unsigned long long used = 0ull;
-            for (int j = 0; j < k; ++j) {
-                float best = 0.f; int bc = -1;
-                for (int c = 0; c < k * pn; ++c) {
-                    if (used >> c & 1ull) continue;
-                    const int r = b * k + c / pn;
-                    const float v = st.cand_val[(size_t)r * M + c % pn] + st.score[src][r];
-                    if (bc < 0 || v > best) { best = v; bc = c; }
-                }
-                used |= 1ull << bc;
-                const int rs = b * k + bc / pn;
-                const int r = b * k + j;
-                chosen_src[j] = rs;
-                st.score[dst][r] = best;
-                st.ids[dst][(size_t)r * st.T + cur_len] = st.cand_idx[(size_t)rs * M + bc % pn];
-                st.kv_src[dst][(size_t)r * st.T + cur_len] = r;
-            }
-            for (int j = 0; j < k; ++j) {
-                const int r = b * k + j, rs = chosen_src[j];
-                for (int s = 0; s < cur_len; ++s) {
-                    st.ids[dst][(size_t)r * st.T + s] = st.ids[src][(size_t)rs * st.T + s];
-                    st.kv_src[dst][(size_t)r * st.T + s] = st.kv_src[src][(size_t)rs * st.T + s];
-                }
-            }
-        }
-    }
-    if (first && st.k == 1) {
-        // decoder.py:279-291: every first prediction is EOS -> early return
-        __syncthreads();
-        int ok = 1;
-        for (int b = threadIdx.x; b < st.B; b += blockDim.x)
-            if (st.cand_idx[(size_t)b * M] != st.eos) ok = 0;
-        if (!ok) s_all_eos = 0;
-        __syncthreads();
-        if (threadIdx.x == 0 && s_all_eos) st.info[1] = 1;
-    }
-    if (threadIdx.x == 0) st.info[2] += 1;
-}
-
-// ---------------------------------------------------------------------------------------
-// GeneratorWithBeamSearch step (decoder.py:1169-1232) + BeamHypotheses (1292-1341, n_hyp = 1).
-// Host arithmetic of the reference is Python double -> double here.
-// ---------------------------------------------------------------------------------------
+// Host arithmetic of the reference is Python double -> double here (decoder.py:1310-1341).
 __device__ __forceinline__ double length_norm(int len, double alpha) {
     return pow(5.0 + (double)len, alpha) / pow(6.0, alpha);
 }
 
-__global__ void s2_advance_kernel(SearchState st, int src, int cur_len, int M) {
+constexpr int SS_KMAX = 8;        // beams per sentence
+constexpr int SS_CMAX = 16;       // candidates per row (beam_size * per_node_beam_size <= 16)
+
+__device__ __forceinline__ int ids_at(const SearchState& st, int buf, int r, int s) { return st.ids[buf][(size_t)r * st.T + s]; }
+
+// grid = B (one workgroup per sentence), block = 256.  cur_len = tokens currently in ids (before appending).
+template <typename TOut>
+__global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int src, int cur_len, StepCands in,
+                                                          EmbedArgs em) {
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];   // sorted partial lists: [256][slots] values, then indices
+    float* s_hv = reinterpret_cast<float*>(dyn_lds);
+    int* s_hi = reinterpret_cast<int*>(dyn_lds + (size_t)256 * in.slots * sizeof(float));
+    __shared__ float s_red[8];
+    __shared__ int s_redi[8];
+    __shared__ int s_owner;
+    __shared__ float c_val[SS_KMAX][SS_CMAX];  // merged top-M log-probabilities per beam row
+    __shared__ int c_idx[SS_KMAX][SS_CMAX];
+    __shared__ int sel_src[SS_KMAX], sel_word[SS_KMAX];
+    __shared__ float sel_score[SS_KMAX];
+    __shared__ int s_hyp_row;                  // GENERATOR: row whose history becomes the new best hypothesis (-1: none)
+    __shared__ float s_part[8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int k = st.k, pn = st.pn, T = st.T;
     const int dst = src ^ 1;
-    for (int b = threadIdx.x; b < st.B; b += blockDim.x) {
-        const int k = st.k, V = st.V;
-        const int ncand = st.pn * k;              // "2k"
-        // merge: each row's list is sorted by log-prob; adding the row's beam score keeps the order
-        int headp[16];
-        for (int j = 0; j < k; ++j) headp[j] = 0;
-        float n_score[32]; int n_beam[32], n_word[32];
-        for (int c = 0; c < ncand; ++c) {
-            float best = 0.f; int bj = -1; long long bflat = 0;
-            for (int j = 0; j < k; ++j) {
-                if (headp[j] >= M) continue;
-                const int r = b * k + j;
-                const float v = st.cand_val[(size_t)r * M + headp[j]] + st.score[src][r];
-                const long long flat = (long long)j * V + st.cand_idx[(size_t)r * M + headp[j]];
-                if (bj < 0 || v > best || (v == best && flat < bflat)) { best = v; bj = j; bflat = flat; }
-            }
-            n_score[c] = best; n_beam[c] = bj; n_word[c] = st.cand_idx[(size_t)(b * k + bj) * M + headp[bj]];
-            headp[bj]++;
-        }
-        // ---- per-sentence loop ---------------------------------------------------------
-        int is_done = st.done[b];
-        if (!is_done && st.hyp_n[b] >= 1) {
-            // BeamHypotheses.is_done(max next score); self.max_length = max_length - 1
-            is_done = st.hyp_score[b] >= (double)n_score[0] / length_norm(st.T - 1, st.length_penalty);
-        }
-        st.done[b] = is_done;
-        int nb = 0;
-        int sel_src[16], sel_word[16]; float sel_score[16];
-        if (!is_done) {
-            for (int c = 0; c < ncand && nb < k; ++c) {
-                const int word = n_word[c];
-                if (word == st.eos || cur_len + 1 == st.T) {
-                    // hyps.add(input_ids[row, :cur_len], score)
-                    const double sc = (double)n_score[c] / length_norm(cur_len, st.length_penalty);
-                    if (st.hyp_n[b] < 1 || sc > st.hyp_score[b]) {
-                        st.hyp_n[b] = 1;
-                        st.hyp_score[b] = sc;
-                        st.hyp_len[b] = cur_len;
-                        const int r = b * k + n_beam[c];
-                        for (int s = 0; s < cur_len; ++s) st.hyp_tok[(size_t)b * st.T + s] = st.ids[src][(size_t)r * st.T + s];
-                    }
-                } else {
-                    sel_score[nb] = n_score[c]; sel_word[nb] = word; sel_src[nb] = b * k + n_beam[c];
-                    ++nb;
-                }
-            }
-        }
-        if (nb < k) {
-            // done sentence, or every candidate finished (cur_len + 1 == max_length): pad the batch
-            // with (score 0, EOS, global row 0)  -- decoder.py:1189, 1219-1220
-            for (int j = 0; j < k; ++j) { sel_score[j] = 0.f; sel_word[j] = st.eos; sel_src[j] = 0; }
-        }
+    const int P = st.plen[b];
+    const bool forced = cur_len < P;                       // still inside this sentence's prefix
+    const bool first = cur_len == P;                       // first search step of this sentence
+    const int M = st.kind == 0 ? (first ? k : pn) : pn * k;        // candidates needed per row
+
+    if (tid == 0) s_hyp_row = -1;
+
+    // ---- phase A: merged top-M log-probabilities of every beam row of the sentence --------------------------
+    if (!forced) {
         for (int j = 0; j < k; ++j) {
-            const int r = b * k + j, rs = sel_src[j];
-            for (int s = 0; s < cur_len; ++s) {
-                st.ids[dst][(size_t)r * st.T + s] = st.ids[src][(size_t)rs * st.T + s];
-                st.kv_src[dst][(size_t)r * st.T + s] = st.kv_src[src][(size_t)rs * st.T + s];
+            const int r = b * k + j;
+            if (st.kind == 0 && first && j > 0) break;     // the first step expands beam 0 only (decoder.py:257-271)
+            const int last = ids_at(st, src, r, cur_len - 1);
+            if (st.kind == 0 && !first && last == st.eos) {
+                // one-hot distribution on EOS (decoder.py:300-310, 347-351): log-prob 0, everything else -inf
+                if (tid < M) {
+                    c_val[j][tid] = tid == 0 ? 0.f : -INFINITY;
+                    c_idx[j][tid] = tid == 0 ? st.eos : (tid - 1 < st.eos ? tid - 1 : tid);
+                }
+                __syncthreads();
+                continue;
             }
-            st.ids[dst][(size_t)r * st.T + cur_len] = sel_word[j];
-            st.kv_src[dst][(size_t)r * st.T + cur_len] = r;
-            st.score[dst][r] = sel_score[j];
+            // log-sum-exp over the parts (fixed order: part index -> lane/wave tree)
+            float pm = -INFINITY, ps = 0.f;
+            for (int p = tid; p < in.nparts; p += 256) {          // nparts <= 256 (checked by the launcher)
+                const float2 ml = in.part_lse[(size_t)r * in.nparts + p];
+                if (ml.x > pm) { ps = ps * __expf(pm - ml.x) + ml.y; pm = ml.x; }
+                else if (ml.x != -INFINITY) ps += ml.y * __expf(ml.x - pm);
+            }
+            float bm = wave_max(pm);
+            if (lane == 0) s_red[wave] = bm;
+            __syncthreads();
+            bm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+            float part = pm == -INFINITY ? 0.f : ps * __expf(pm - bm);
+            part = wave_sum(part);
+            if (lane == 0) s_red[4 + wave] = part;
+            // heads of this thread's part (parts beyond 256 are folded in by the owning thread below)
+            const int slots = in.slots;
+            for (int q = 0; q < slots; ++q) { s_hv[tid * slots + q] = -INFINITY; s_hi[tid * slots + q] = 0x7fffffff; }
+            if (tid < in.nparts) {
+                const size_t base = ((size_t)r * in.nparts + tid) * slots;
+                for (int q = 0; q < slots; ++q) { s_hv[tid * slots + q] = in.part_val[base + q]; s_hi[tid * slots + q] = in.part_idx[base + q]; }
+            }
+            __syncthreads();
+            const float lse = bm + logf(s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+            int head = 0;
+            for (int round = 0; round < M; ++round) {
+                float v = head < slots ? s_hv[tid * slots + head] : -INFINITY;
+                int id = head < slots ? s_hi[tid * slots + head] : 0x7fffffff;
+                int who = tid;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(v, o, 64);
+                    const int oi = __shfl_xor(id, o, 64);
+                    const int ow = __shfl_xor(who, o, 64);
+                    if (ov > v || (ov == v && oi < id)) { v = ov; id = oi; who = ow; }
+                }
+                if (lane == 0) { s_part[wave] = v; s_redi[wave] = id; s_redi[4 + wave] = who; }
+                __syncthreads();
+                if (tid == 0) {
+                    float bv = s_part[0]; int bi = s_redi[0], bw = s_redi[4];
+#pragma unroll
+                    for (int w = 1; w < 4; ++w)
+                        if (s_part[w] > bv || (s_part[w] == bv && s_redi[w] < bi)) { bv = s_part[w]; bi = s_redi[w]; bw = s_redi[4 + w]; }
+                    c_val[j][round] = bv - lse;
+                    c_idx[j][round] = bi == 0x7fffffff ? 0 : bi;
+                    s_owner = bw;
+                }
+                __syncthreads();
+                if (tid == s_owner) ++head;
+                __syncthreads();
+            }
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int all = 1;
-        for (int b = 0; b < st.B; ++b)
-            if (!st.done[b]) all = 0;
-        st.info[3] = all;          // decoder.py:1251: the host loop may stop polling here
-        st.info[2] += 1;
+
+    // ---- phase B: the search step of this sentence (one thread; k <= 8, <= 16 candidates per row) ---------------
+    if (tid == 0) {
+        if (forced) {
+            const int word = (int)st.start[(size_t)b * st.ld_start + cur_len];
+            for (int j = 0; j < k; ++j) { sel_src[j] = b * k + j; sel_word[j] = word; sel_score[j] = st.score[src][b * k + j]; }
+        } else if (st.kind == 0) {
+            // ---- AutoRegressiveBeamSearch -------------------------------------------------------------------
+            if (!first && st.stop[b] == 0) {
+                // decoder.py:319: the loop stops once every beam's last token is EOS (later steps are idempotent)
+                int all_eos = 1;
+                for (int j = 0; j < k; ++j)
+                    if (ids_at(st, src, b * k + j, cur_len - 1) != st.eos) all_eos = 0;
+                if (all_eos) { st.stop[b] = cur_len; atomicAdd(&st.info[0], 1); }
+            }
+            if (first) {
+                for (int j = 0; j < k; ++j) {
+                    sel_src[j] = b * k; sel_word[j] = c_idx[0][j]; sel_score[j] = c_val[0][j];
+                }
+                // decoder.py:279-291: every first prediction is EOS (k == 1) -> early return
+                if (k == 1) st.early[b] = c_idx[0][0] == st.eos ? 1 : 0;
+            } else {
+                // top-k (sorted) of the k*pn summed candidates, ties -> lower candidate index
+                unsigned long long used = 0ull;
+                for (int j = 0; j < k; ++j) {
+                    float best = 0.f; int bc = -1;
+                    for (int c = 0; c < k * pn; ++c) {
+                        if (used >> c & 1ull) continue;
+                        const float v = c_val[c / pn][c % pn] + st.score[src][b * k + c / pn];
+                        if (bc < 0 || v > best) { best = v; bc = c; }
+                    }
+                    used |= 1ull << bc;
+                    sel_src[j] = b * k + bc / pn; sel_word[j] = c_idx[bc / pn][bc % pn]; sel_score[j] = best;
+                }
+            }
+        } else {
+            // ---- GeneratorWithBeamSearch ----------------------------------------------------------------------
+            const int V = st.V;
+            const int ncand = pn * k;              // "2k"
+            // merge: each row's list is sorted by log-prob; adding the row's beam score keeps the order
+            int headp[SS_KMAX];
+            for (int j = 0; j < k; ++j) headp[j] = 0;
+            float n_score[SS_CMAX * 2]; int n_beam[SS_CMAX * 2], n_word[SS_CMAX * 2];
+            for (int c = 0; c < ncand; ++c) {
+                float best = 0.f; int bj = -1; long long bflat = 0;
+                for (int j = 0; j < k; ++j) {
+                    if (headp[j] >= M) continue;
+                    const float v = c_val[j][headp[j]] + st.score[src][b * k + j];
+                    const long long flat = (long long)j * V + c_idx[j][headp[j]];
+                    if (bj < 0 || v > best || (v == best && flat < bflat)) { best = v; bj = j; bflat = flat; }
+                }
+                n_score[c] = best; n_beam[c] = bj; n_word[c] = c_idx[bj][headp[bj]];
+                headp[bj]++;
+            }
+            int is_done = st.done[b];
+            if (!is_done && st.hyp_n[b] >= 1) {
+                // BeamHypotheses.is_done(max next score); self.max_length = max_length - 1
+                is_done = st.hyp_score[b] >= (double)n_score[0] / length_norm(T - 1, st.length_penalty);
+            }
+            if (is_done && !st.done[b]) atomicAdd(&st.info[0], 1);
+            st.done[b] = is_done;
+            int nb = 0;
+            if (!is_done) {
+                for (int c = 0; c < ncand && nb < k; ++c) {
+                    const int word = n_word[c];
+                    if (word == st.eos || cur_len + 1 == T) {
+                        // hyps.add(input_ids[row, :cur_len], score)
+                        const double sc = (double)n_score[c] / length_norm(cur_len, st.length_penalty);
+                        if (st.hyp_n[b] < 1 || sc > st.hyp_score[b]) {
+                            st.hyp_n[b] = 1;
+                            st.hyp_score[b] = sc;
+                            st.hyp_len[b] = cur_len;
+                            s_hyp_row = b * k + n_beam[c];
+                        }
+                    } else {
+                        sel_score[nb] = n_score[c]; sel_word[nb] = word; sel_src[nb] = b * k + n_beam[c];
+                        ++nb;
+                    }
+                }
+            }
+            if (nb < k) {
+                // done sentence, or every candidate finished (cur_len + 1 == max_length): pad the batch with
+                // (score 0, EOS, row 0 of the call)  -- decoder.py:1189, 1219-1220.  A sentence of a batched ragged call
+                // stands for its own batch-1 reference call, whose row 0 is the sentence's own first row.
+                const int pad_row = st.ragged ? b * k : 0;
+                for (int j = 0; j < k; ++j) { sel_score[j] = 0.f; sel_word[j] = st.eos; sel_src[j] = pad_row; }
+            }
+        }
+        if (b == 0) st.info[2] += 1;
+    }
+    __syncthreads();
+
+    // ---- phase C: histories of the new beams (all threads), new token, scores -------------------------------------
+    if (s_hyp_row >= 0)
+        for (int s = tid; s < cur_len; s += 256) st.hyp_tok[(size_t)b * T + s] = ids_at(st, src, s_hyp_row, s);
+    for (int j = 0; j < k; ++j) {
+        const int r = b * k + j, rs = sel_src[j];
+        for (int s = tid; s < cur_len; s += 256) {
+            st.ids[dst][(size_t)r * T + s] = st.ids[src][(size_t)rs * T + s];
+            st.kv_src[dst][(size_t)r * T + s] = st.kv_src[src][(size_t)rs * T + s];
+        }
+        if (tid == 0) {
+            st.ids[dst][(size_t)r * T + cur_len] = sel_word[j];
+            st.kv_src[dst][(size_t)r * T + cur_len] = r;
+            st.score[dst][r] = sel_score[j];
+        }
+    }
+
+    // ---- phase D: embedding + LayerNorm of the chosen tokens = input of the next decode step -----------------------
+    if (em.words == nullptr || cur_len + 1 >= T) return;
+    const int D = em.D;
+    const int c = tid * 4;
+    const bool on = c < D;
+    for (int j = 0; j < k; ++j) {
+        const int r = b * k + j;
+        int tok = sel_word[j];
+        tok = tok < 0 ? 0 : (tok >= em.vocab ? em.vocab - 1 : tok);
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, g4 = a, b4 = a;
+        if (on) {
+            const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(em.words + (size_t)tok * D + c);
+            const f32x4_t p4 = *reinterpret_cast<const f32x4_t*>(em.positions + (size_t)cur_len * D + c);
+            g4 = *reinterpret_cast<const f32x4_t*>(em.gamma + c);
+            b4 = *reinterpret_cast<const f32x4_t*>(em.beta + c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = w4[q] + p4[q];
+        }
+        __syncthreads();                                   // s_part reuse across rows
+        const float sum = wave_sum(a[0] + a[1] + a[2] + a[3]);
+        if (lane == 0) s_part[wave] = sum;
+        __syncthreads();
+        const float mean = (s_part[0] + s_part[1] + s_part[2] + s_part[3]) / (float)D;
+        float q2 = 0.f;
+        if (on) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float d = a[q] - mean; q2 += d * d; }
+        }
+        q2 = wave_sum(q2);
+        if (lane == 0) s_part[4 + wave] = q2;
+        __syncthreads();
+        const float rstd = rsqrtf((s_part[4] + s_part[5] + s_part[6] + s_part[7]) / (float)D + em.eps);
+        if (on) {
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (a[q] - mean) * rstd * g4[q] + b4[q];
+            *reinterpret_cast<f32x4_t*>(em.h_f + (size_t)r * D + c) = f32x4_t{o[0], o[1], o[2], o[3]};
+            TOut* ht = reinterpret_cast<TOut*>(em.h_t);
+            if constexpr (sizeof(TOut) == 4) {
+                *reinterpret_cast<f32x4_t*>(ht + (size_t)r * D + c) = f32x4_t{o[0], o[1], o[2], o[3]};
+            } else {
+                uint2 t;
+                t.x = pack2bf(o[0], o[1]);
+                t.y = pack2bf(o[2], o[3]);
+                *reinterpret_cast<uint2*>(ht + (size_t)r * D + c) = t;
+            }
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------
-__global__ void search_init_kernel(SearchState st, const long long* __restrict__ start /*[B][P]*/) {
+__global__ void search_init_kernel(SearchState st) {
     const int R = st.B * st.k;
-    for (int r = threadIdx.x; r < R; r += blockDim.x) {
-        const int b = r / st.k, j = r % st.k;
-        for (int s = 0; s < st.T; ++s) {
-            st.ids[0][(size_t)r * st.T + s] = s < st.P ? (int)start[(size_t)b * st.P + s] : st.eos;
-            st.kv_src[0][(size_t)r * st.T + s] = r;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R * st.T; i += gridDim.x * blockDim.x) {
+        const int r = i / st.T, s = i % st.T;
+        const int b = r / st.k;
+        st.ids[0][i] = s < st.plen[b] ? (int)st.start[(size_t)b * st.ld_start + s] : st.eos;
+        st.kv_src[0][i] = r;
+    }
+    if (blockIdx.x == 0) {
+        for (int r = threadIdx.x; r < R; r += blockDim.x) {
+            // decoder.py:1118-1120: only beam 0 is live at the start (GENERATOR); AUTOREGRESSIVE
+            // takes its first step from beam 0 explicitly.
+            st.score[0][r] = (st.kind == 1 && r % st.k > 0) ? -1e9f : 0.f;
         }
-        // decoder.py:1118-1120: only beam 0 is live at the start (GENERATOR); AUTOREGRESSIVE
-        // takes its first step from beam 0 explicitly.
-        st.score[0][r] = (st.kind == 1 && j > 0) ? -1e9f : 0.f;
+        for (int b = threadIdx.x; b < st.B; b += blockDim.x) {
+            st.done[b] = 0; st.hyp_n[b] = 0; st.hyp_score[b] = 0.0; st.hyp_len[b] = 0; st.stop[b] = 0; st.early[b] = 0;
+        }
+        if (threadIdx.x < 4) st.info[threadIdx.x] = 0;
     }
-    for (int b = threadIdx.x; b < st.B; b += blockDim.x) {
-        st.done[b] = 0; st.hyp_n[b] = 0; st.hyp_score[b] = 0.0; st.hyp_len[b] = 0;
-    }
-    if (threadIdx.x < 4) st.info[threadIdx.x] = 0;
 }
 
 // AUTOREGRESSIVE: best beam (index 0), log-prob / num_valid (decoder.py:429-438)
 // GENERATOR     : best hypothesis + EOS, EOS padded; -1e5 when none (decoder.py:1264-1290)
+// sent_out[b] = (length of the sequence the reference returns for this sentence alone, early-return flag)
 __global__ void search_finish_kernel(SearchState st, int cur, int cur_len, long long* __restrict__ tokens_out,
-                                     float* __restrict__ logprob_out, int* __restrict__ info_out) {
+                                     float* __restrict__ logprob_out, int* __restrict__ info_out,
+                                     int* __restrict__ sent_out) {
+    __shared__ int s_max_stop, s_all_stop, s_all_early;
+    if (threadIdx.x == 0) { s_max_stop = 0; s_all_stop = 1; s_all_early = 1; }
+    __syncthreads();
     for (int b = threadIdx.x; b < st.B; b += blockDim.x) {
         long long* out = tokens_out + (size_t)b * st.T;
+        int L = st.T, early = 0;
         if (st.kind == 0) {
             const int r = b * st.k;
-            const int stop = st.info[0];
-            const int L = stop > 0 ? stop : cur_len;          // length the reference returns
+            const int stop = st.stop[b];
+            L = stop > 0 ? stop : cur_len;                      // length the reference returns for this sentence
+            early = st.k == 1 ? st.early[b] : 0;
             int non_eos = 0, any_eos = 0;
             for (int s = 0; s < st.T; ++s) {
                 const int tok = s < L ? st.ids[cur][(size_t)r * st.T + s] : st.eos;
                 out[s] = tok;
                 if (s < L) { if (tok != st.eos) ++non_eos; else any_eos = 1; }
             }
-            if (st.info[1]) {
-                logprob_out[b] = st.score[cur][r];              // early return: raw first log-prob
-            } else {
-                int nv = non_eos + any_eos - st.P;
-                nv = nv < 1 ? 1 : nv;
-                logprob_out[b] = st.score[cur][r] / (float)nv;
-            }
+            int nv = non_eos + any_eos - st.plen[b];
+            nv = nv < 1 ? 1 : nv;
+            logprob_out[b] = st.score[cur][r] / (float)nv;
+            if (sent_out) sent_out[2 * b + 1] = early;
+            if (stop > 0) atomicMax(&s_max_stop, stop); else s_all_stop = 0;
+            if (!early) s_all_early = 0;
         } else {
             const int n = st.hyp_n[b] > 0 ? st.hyp_len[b] : 0;
             for (int s = 0; s < st.T; ++s) out[s] = s < n ? st.hyp_tok[(size_t)b * st.T + s] : st.eos;
             logprob_out[b] = st.hyp_n[b] > 0 ? (float)st.hyp_score[b] : -1e5f;
+            if (sent_out) sent_out[2 * b + 1] = 0;
         }
+        if (sent_out) sent_out[2 * b] = L;
     }
+    __syncthreads();
+    // (decoder.py:279-291, the first-step early return, hands back the raw first log-prob: with the sequence
+    //  [prefix, EOS] num_valid is 1, so the normalised value above is already that number)
     if (threadIdx.x == 0) {
-        const int stop = st.info[0];
-        info_out[0] = st.kind == 0 ? (stop > 0 ? stop : cur_len) : st.T;
-        info_out[1] = st.info[1];
+        info_out[0] = st.kind == 0 ? (s_all_stop ? s_max_stop : cur_len) : st.T;
+        info_out[1] = (st.kind == 0 && st.k == 1) ? s_all_early : 0;
         info_out[2] = st.info[2];
         info_out[3] = 0;
     }
@@ -378,16 +494,20 @@ __global__ void load_ids_kernel(const long long* __restrict__ tokens, int R, int
     }
 }
 
-// start tokens [B,P]: the shared prefix (device pointer) or [CLS] (decoder.py:979-989) -- no host round trip
-__global__ void fill_start_kernel(long long* __restrict__ start, const long long* __restrict__ prefix, int sos, int B,
-                                  int P) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * P; i += gridDim.x * blockDim.x)
-        start[i] = prefix ? prefix[i % P] : (long long)sos;
+// start tokens [B, ld]: row b = its own prefix (prefixes [B, ldp], length plen[b]), or the shared prefix, or [CLS]
+// (decoder.py:979-989) -- no host round trip
+__global__ void fill_start_kernel(long long* __restrict__ start, int ld, const long long* __restrict__ prefix, int ldp,
+                                  int shared, int sos, int B, int P) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * P; i += gridDim.x * blockDim.x) {
+        const int b = i / P, s = i % P;
+        start[(size_t)b * ld + s] = prefix ? prefix[(shared ? 0 : (size_t)b * ldp) + s] : (long long)sos;
+    }
 }
 
 // ---- host launchers ------------------------------------------------------------------
-hipError_t launch_fill_start(long long* start, const long long* prefix, int sos, int B, int P, hipStream_t s) {
-    hipLaunchKernelGGL(fill_start_kernel, dim3(8), dim3(256), 0, s, start, prefix, sos, B, P);
+hipError_t launch_fill_start(long long* start, int ld, const long long* prefix, int ldp, int shared, int sos, int B, int P,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(fill_start_kernel, dim3(8), dim3(256), 0, s, start, ld, prefix, ldp, shared, sos, B, P);
     return hipGetLastError();
 }
 
@@ -396,14 +516,16 @@ hipError_t launch_load_ids(const long long* tokens, int R, int t, int* ids, int*
     return hipGetLastError();
 }
 
-hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, int ld_ids, int cur_len, int eos,
-                           int suppress_last, int force_eos, int M, int R, float* cand_val, int* cand_idx,
-                           hipStream_t s) {
+int row_topm_slots(int M) { return M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : M <= 8 ? 8 : 16; }
+
+hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, int ld_ids, int cur_len,
+                           const int* plen, int beams, int suppress_kind, int M, int R, float* part_val,
+                           int* part_idx, float2* part_lse, hipStream_t s) {
     if (M < 1 || M > 16) return hipErrorInvalidValue;
     // one workgroup per row; more threads per row when the per-thread candidate list is short (LDS: NT*MMAX*8 B)
 #define GITMI_TOPM(MM, NTT)                                                                                         \
-    hipLaunchKernelGGL((row_topm_kernel<MM, NTT>), dim3(R), dim3(NTT), 0, s, logits, ldl, V, ids, ld_ids, cur_len, eos, \
-                       suppress_last, force_eos, M, cand_val, cand_idx)
+    hipLaunchKernelGGL((row_topm_kernel<MM, NTT>), dim3(R), dim3(NTT), 0, s, logits, ldl, V, ids, ld_ids, cur_len, plen, \
+                       beams, suppress_kind, part_val, part_idx, part_lse)
     if (M <= 1) GITMI_TOPM(1, 1024);
     else if (M <= 2) GITMI_TOPM(2, 1024);
     else if (M <= 4) GITMI_TOPM(4, 1024);
@@ -413,22 +535,24 @@ hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, 
     return hipGetLastError();
 }
 
-hipError_t launch_s1_advance(const SearchState& st, int src, int cur_len, int first, int M, hipStream_t s) {
-    hipLaunchKernelGGL(s1_advance_kernel, dim3(1), dim3(256), 0, s, st, src, cur_len, first, M);
+hipError_t launch_search_step(const SearchState& st, int src, int cur_len, const StepCands& in, const EmbedArgs& em,
+                              bool t_is_f32, hipStream_t s) {
+    if (st.k > SS_KMAX || in.slots < 1 || in.slots > SS_CMAX || in.nparts < 1 || in.nparts > 256) return hipErrorInvalidValue;
+    if (st.k * st.pn > SS_CMAX) return hipErrorInvalidValue;
+    if (em.words && (em.D > 1024 || (em.D & 3))) return hipErrorInvalidValue;
+    const size_t lds = (size_t)256 * in.slots * 8;
+    if (t_is_f32) hipLaunchKernelGGL(search_step_kernel<float>, dim3(st.B), dim3(256), lds, s, st, src, cur_len, in, em);
+    else hipLaunchKernelGGL(search_step_kernel<bf16_t>, dim3(st.B), dim3(256), lds, s, st, src, cur_len, in, em);
     return hipGetLastError();
 }
-hipError_t launch_s2_advance(const SearchState& st, int src, int cur_len, int M, hipStream_t s) {
-    hipLaunchKernelGGL(s2_advance_kernel, dim3(1), dim3(256), 0, s, st, src, cur_len, M);
-    return hipGetLastError();
-}
-hipError_t launch_search_init(const SearchState& st, const long long* start_dev, hipStream_t s) {
-    hipLaunchKernelGGL(search_init_kernel, dim3(1), dim3(256), 0, s, st, start_dev);
+hipError_t launch_search_init(const SearchState& st, hipStream_t s) {
+    hipLaunchKernelGGL(search_init_kernel, dim3(16), dim3(256), 0, s, st);
     return hipGetLastError();
 }
 hipError_t launch_search_finish(const SearchState& st, int cur, int cur_len, long long* tokens_out,
-                                float* logprob_out, int* info_out, hipStream_t s) {
+                                float* logprob_out, int* info_out, int* sent_out, hipStream_t s) {
     hipLaunchKernelGGL(search_finish_kernel, dim3(1), dim3(256), 0, s, st, cur, cur_len, tokens_out, logprob_out,
-                       info_out);
+                       info_out, sent_out);
     return hipGetLastError();
 }
 hipError_t launch_search_rows(const SearchState& st, int cur, int cur_len, long long* out, hipStream_t s) {

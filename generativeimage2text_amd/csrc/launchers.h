@@ -25,17 +25,35 @@ bool gemm_p8_supports(const GemmArgs& g);
 int gemm_p8_cost(const GemmArgs& g, int mh);   // rounds x relative tile time of the 256-row (mh=128) / 192-row (96) tile
 void set_gemm_impl(int impl);   // -1 auto, 0 first-generation kernel only, 1 force direct-to-LDS kernel
 
-// weight-streaming GEMM for decode (bf16 operands): C or fp32 partial slabs [S][M][N]
-struct SkinnyArgs {
-    const void* A; const void* W; const float* bias; const float* res; void* C; float* partial;
-    int M, N, K;
-    int lda, ldc, ldr;
-    int act;
-    int S;      // K slices across workgroups (1 = fused epilogue, >1 = partial slabs)
+// ---- decode-step GEMM chain (kernels_dgemm.hip): LayerNorm folded into the consumer, row partials from the producer
+struct DGemmArgs {
+    const unsigned short* A; const unsigned short* W;   // bf16 [M, lda], [N, K]
+    const float* bias;          // [N]  bias, or the folded constant  beta W^T + bias
+    const float* colsum;        // [N]  sum_k bf16(W gamma)[n][k] when the input LayerNorm is folded, else nullptr
+    const float2* stats_in;     // [strips_in][M] (sum, sumsq) strip partials of the folded LayerNorm's input (nullptr: none)
+    int strips_in; float inv_d, eps_in;
+    void* C;                    // bf16 [M, ldc] output of the QKV / FFN1 form
+    // N = 768 form: x_out = A W^T + bias + residual (+ bf16 copy + strip partials of x_out)
+    const float* res_x;         // fp32 [M, N]: the hidden state, or the raw x the residual LayerNorm is rebuilt from
+    const float2* res_stats; int res_strips; const float* res_gamma; const float* res_beta; float res_inv_d, res_eps;
+    float* x_out; unsigned short* xb_out; float2* stats_out;
+    int M, N, K, lda, ldc, act;
 };
-hipError_t launch_skinny_gemm(SkinnyArgs g, bool out_f32, int NT, hipStream_t s);
-hipError_t launch_splitk_ln(const float* partial, int S, const float* bias, const float* res, const float* gamma,
-                            const float* beta, float eps, float* y_f, void* y_t, int rows, int D, hipStream_t s);
+hipError_t launch_dgemm(const DGemmArgs& g, hipStream_t s);
+
+// vocabulary head with the running top-M / log-sum-exp fused: one sorted candidate list per (row, workgroup)
+struct VocabArgs {
+    const unsigned short* A; int lda; const unsigned short* W; const float* bias; const float* colsum;
+    const float2* stats_in; int strips_in; float inv_d, eps_in;
+    int M, N, K, cols_per_wg;
+    // no-immediate-repeat rule (decoder.py:330): rows of AUTOREGRESSIVE sentences past their first search step
+    const int* ids; int ld_ids, cur_len; const int* plen; int beams, suppress_kind;
+    float* part_val; int* part_idx; float2* part_lse;     // [M][gridDim.x][slots], [M][gridDim.x] (max, sum exp)
+    float* logits_out; int ld_logits;                      // optional full logits (teacher-forced parity hook)
+};
+hipError_t launch_vocab_topm(const VocabArgs& g, int mtop, hipStream_t s);
+int vocab_parts(int V, int cols_per_wg);
+int vocab_mtop_slots(int mtop);
 
 hipError_t launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps,
                             const float* add_after, void* y_t, int ld_t, bool t_is_f32, float* y_f, int ld_f,
@@ -51,6 +69,7 @@ hipError_t launch_embed_ln(const int* ids, int ld_ids, int pos, const float* wor
 hipError_t launch_convert_pad(const float* src, void* dst, bool dst_f32, size_t rows, int K, int Kpad,
                               hipStream_t s);
 hipError_t launch_copy_f32(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s);
+hipError_t launch_fill_i32(int* dst, int value, int n, hipStream_t s);
 
 struct AttnFullArgs {
     const void* q; const void* k; const void* v; void* out;
@@ -63,6 +82,7 @@ hipError_t launch_attn_full(const AttnFullArgs& a, int B, bool is_f32, int impl,
 struct AttnDecodeArgs {
     const void* qkv; const void* img_k; const void* img_v; void* txt_k; void* txt_v; void* out;   // img_k/v head-major [B][H][N_img][64]
     const int* kv_src;
+    const int* img_of;   // [B] image whose K/V the sentence attends to (nullptr: sentence b <-> image b)
     int ld_src;
     int d;
     int N_img, T_max, pos, beams;
@@ -75,30 +95,46 @@ hipError_t launch_attn_decode(const AttnDecodeArgs& a, int B, int H, bool is_f32
 hipError_t attn_decode_configure();
 
 struct SearchState {
-    int B, k, pn, P, T, V, eos, kind;
+    int B, k, pn, T, V, eos, kind;      // B sentences of k beams; T = max_steps = row stride of ids / kv_src / hyp_tok
+    int ragged;                         // 1: every sentence stands for its own batch-1 reference call (own prefix)
     double length_penalty;
+    const long long* start;             // [B][ld_start] start tokens of every sentence (its prefix, or [CLS])
+    int ld_start;
+    const int* plen;                    // [B] prefix length of every sentence (>= 1)
     int* ids[2];
     int* kv_src[2];
     float* score[2];
-    float* cand_val;
-    int* cand_idx;
     int* done;
     int* hyp_n;
     double* hyp_score;
     int* hyp_len;
     int* hyp_tok;
-    int* info;
+    int* stop;                          // AUTOREGRESSIVE: cur_len at which every beam of the sentence had ended (0: not yet)
+    int* early;                         // AUTOREGRESSIVE, k == 1: the sentence's first prediction was EOS
+    int* info;                          // [0] sentences ended / done so far, [2] steps run
 };
-hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, int ld_ids, int cur_len, int eos,
-                           int suppress_last, int force_eos, int M, int R, float* cand_val, int* cand_idx,
-                           hipStream_t s);
-hipError_t launch_s1_advance(const SearchState& st, int src, int cur_len, int first, int M, hipStream_t s);
-hipError_t launch_s2_advance(const SearchState& st, int src, int cur_len, int M, hipStream_t s);
-hipError_t launch_search_init(const SearchState& st, const long long* start_dev, hipStream_t s);
+// candidate lists of a step: per row `nparts` sorted lists of `slots` (logit, token) pairs + (max, sum exp) per part
+struct StepCands {
+    const float* part_val; const int* part_idx; const float2* part_lse;
+    int nparts, slots;
+};
+// embedding of the tokens a step appends = input of the next decode step (decoder.py:65-78); words == nullptr: skip
+struct EmbedArgs {
+    const float* words; const float* positions; const float* gamma; const float* beta; float eps;
+    float* h_f; void* h_t; int D, vocab;
+};
+int row_topm_slots(int M);
+hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, int ld_ids, int cur_len,
+                           const int* plen, int beams, int suppress_kind, int M, int R, float* part_val,
+                           int* part_idx, float2* part_lse, hipStream_t s);
+hipError_t launch_search_step(const SearchState& st, int src, int cur_len, const StepCands& in, const EmbedArgs& em,
+                              bool t_is_f32, hipStream_t s);
+hipError_t launch_search_init(const SearchState& st, hipStream_t s);
 hipError_t launch_search_finish(const SearchState& st, int cur, int cur_len, long long* tokens_out,
-                                float* logprob_out, int* info_out, hipStream_t s);
+                                float* logprob_out, int* info_out, int* sent_out, hipStream_t s);
 hipError_t launch_search_rows(const SearchState& st, int cur, int cur_len, long long* out, hipStream_t s);
-hipError_t launch_fill_start(long long* start, const long long* prefix, int sos, int B, int P, hipStream_t s);
+hipError_t launch_fill_start(long long* start, int ld, const long long* prefix, int ldp, int shared, int sos, int B, int P,
+                             hipStream_t s);
 hipError_t launch_load_ids(const long long* tokens, int R, int t, int* ids, int* kv_src, int ld, hipStream_t s);
 
 // GPU image transform (Pillow-exact bicubic resize + centre crop + CLIP normalisation)

@@ -25,9 +25,9 @@ EXPORTED_SYMBOLS = [
     "gitmi_finalize_weights", "gitmi_encode_frames", "gitmi_prefill", "gitmi_step_logits",
     "gitmi_generate", "gitmi_search_begin", "gitmi_search_rows", "gitmi_search_advance",
     "gitmi_search_finish", "gitmi_profile_enable", "gitmi_profile_read", "gitmi_set_graph",
-    "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_gemm_skinny",
-    "gitmi_op_gemm_splitk_ln", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
-    "gitmi_set_image_shape", "gitmi_preprocess_image_to",
+    "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_dgemm", "gitmi_op_dgemm_res",
+    "gitmi_op_vocab_topm", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
+    "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding",
 ]
 
 
@@ -90,21 +90,25 @@ def load_library() -> C.CDLL:
     lib.gitmi_profile_enable.argtypes = [vp, i32]
     lib.gitmi_profile_read.argtypes = [vp, C.POINTER(GitmiProfile)]
     lib.gitmi_set_graph.argtypes = [vp, i32]
+    lib.gitmi_set_temporal_embedding.argtypes = [vp, i32]
     lib.gitmi_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_attention.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
-    lib.gitmi_op_gemm_skinny.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.gitmi_op_dgemm.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, vp, i32, i32, i32, i32, vp]
+    lib.gitmi_op_dgemm_res.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, vp]
+    lib.gitmi_op_vocab_topm.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.gitmi_generate_prefixed.argtypes = [vp, C.POINTER(vp), i32, i32, vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                            i32, C.POINTER(GitmiSearch), vp, vp, vp, vp, vp]
     lib.gitmi_debug_set_gemm_impl.argtypes = [i32]
     lib.gitmi_clone.argtypes = [vp, C.POINTER(vp)]
     lib.gitmi_preprocess_image.argtypes = [vp, i32, i32, i32, vp, C.c_size_t, vp, vp]
     lib.gitmi_preprocess_image_to.argtypes = [vp, i32, i32, i32, i32, vp, C.c_size_t, vp, vp]
     lib.gitmi_set_image_shape.argtypes = [vp, i32, i32, vp]
     lib.gitmi_op_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
-    lib.gitmi_op_gemm_splitk_ln.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, i32, vp, vp, i32, i32, i32, vp]
     for name in EXPORTED_SYMBOLS:
         if name not in ("gitmi_last_error", "gitmi_destroy"):
             getattr(lib, name).restype = C.c_int
-    if lib.gitmi_abi_version() != 2:
+    if lib.gitmi_abi_version() != 3:
         raise GitmiError("libgitmi.so ABI version mismatch")
     _lib = lib
     return lib
@@ -269,6 +273,35 @@ class Engine:
             torch.cuda.current_stream().synchronize()
         return tokens, logprobs, info
 
+    def generate_prefixed(self, frames: Sequence[torch.Tensor], search: GitmiSearch,
+                          prefixes: Sequence[Sequence[int]], image_of: Optional[Sequence[int]] = None, sync: bool = True):
+        """Batched VQA: sentence q starts from its own prefix `prefixes[q]` (token ids incl. [CLS], any lengths) and
+        attends to image `image_of[q]` of the encoded batch (default: sentence q <-> image q).  Every sentence gets
+        exactly what a batch-1 reference call with that image and prefix returns (decoder.py:984-1006).
+        -> (tokens int64 [Q, max_steps], logprobs fp32 [Q], sent int32 [Q, 2] = (returned length, early), info int32 [4])"""
+        arr, keep, B = self._frames_arg(frames)
+        dev = keep[0].device
+        Q = len(prefixes)
+        lens = [len(p) for p in prefixes]
+        ld = max(lens)
+        table = torch.zeros(Q, ld, dtype=torch.int64)
+        for q, p in enumerate(prefixes):
+            table[q, :len(p)] = torch.as_tensor(list(p), dtype=torch.int64)
+        table = table.to(dev)
+        tokens = torch.empty(Q, search.max_steps, device=dev, dtype=torch.int64)
+        logprobs = torch.empty(Q, device=dev, dtype=torch.float32)
+        sent = torch.empty(Q, 2, device=dev, dtype=torch.int32)
+        info = torch.empty(4, device=dev, dtype=torch.int32)
+        lens_c = (C.c_int32 * Q)(*lens)
+        img_c = None if image_of is None else (C.c_int32 * Q)(*[int(i) for i in image_of])
+        _ck(self.lib.gitmi_generate_prefixed(self._h, arr, len(keep), B, table.data_ptr(), ld, lens_c, img_c, Q,
+                                             C.byref(search), tokens.data_ptr(), logprobs.data_ptr(), sent.data_ptr(),
+                                             info.data_ptr(), _stream()))
+        self._cur_B = B
+        if sync:
+            torch.cuda.current_stream().synchronize()
+        return tokens, logprobs, sent, info
+
     # -- search seam ---------------------------------------------------------------------------
     def search_begin(self, search: GitmiSearch, start: torch.Tensor, vocab: int) -> None:
         start = start.to("cpu", torch.int64).contiguous()
@@ -308,6 +341,11 @@ class Engine:
         _ck(self.lib.gitmi_profile_read(self._h, C.byref(p)))
         return p.as_dict()
 
+    def set_temporal_embedding(self, on: bool) -> None:
+        """on (default): frames come as a list -> frame i gets img_temperal_embedding[i]; off: a bare image tensor
+        (decoder.py:845-857 adds the embedding only in the list branch)."""
+        _ck(self.lib.gitmi_set_temporal_embedding(self._h, 1 if on else 0))
+
     def set_graph(self, on: bool) -> None:
         _ck(self.lib.gitmi_set_graph(self._h, 1 if on else 0))
 
@@ -344,31 +382,66 @@ def op_attention(qkv: torch.Tensor, B: int, N: int, H: int, impl: int) -> torch.
     return out
 
 
-def op_gemm_skinny(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                   residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
-                   out_dtype: torch.dtype = torch.float32, NT: int = 1) -> torch.Tensor:
+def strip_stats(x: torch.Tensor) -> torch.Tensor:
+    """Row partials of a [M, N] fp32 tensor per 16-column strip, in the layout the decode-chain kernels exchange:
+    [N/16][M][2] = (sum, sum of squares)."""
+    M, N = x.shape
+    xs = x.float().reshape(M, N // 16, 16)
+    return torch.stack([xs.sum(-1), (xs * xs).sum(-1)], dim=-1).permute(1, 0, 2).contiguous()
+
+
+def op_dgemm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, colsum: Optional[torch.Tensor] = None,
+             stats: Optional[torch.Tensor] = None, eps: float = 1e-12, act: int = ACT_NONE) -> torch.Tensor:
+    """Decode-chain GEMM, QKV / FFN1 form (kernels_dgemm.hip): bf16 A [M,K], W [N,K] -> bf16 [M,N].
+    With `stats` ([K/16][M][2] strip partials of the raw rows behind A) the LayerNorm in front of the GEMM is folded:
+    out = rstd * (A W^T - mean * colsum) + bias."""
     lib = load_library()
-    assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and A.is_contiguous() and W.is_contiguous()
     M, K = A.shape
     N = W.shape[0]
-    out = torch.empty(M, N, device=A.device, dtype=out_dtype)
-    _ck(lib.gitmi_op_gemm_skinny(A.data_ptr(), W.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K,
-                                 _torch_dtype_code(out), act, NT, _stream()))
+    out = torch.empty(M, N, device=A.device, dtype=torch.bfloat16)
+    strips = 0 if stats is None else int(stats.shape[0])
+    _ck(lib.gitmi_op_dgemm(A.data_ptr(), W.data_ptr(), bias.data_ptr(), _ptr(colsum), _ptr(stats), strips, eps,
+                           out.data_ptr(), M, N, K, act, _stream()))
     return out
 
 
-def op_gemm_splitk_ln(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, residual: torch.Tensor,
-                      gamma: torch.Tensor, beta: torch.Tensor, eps: float, S: int):
+def op_dgemm_res(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, res_x: torch.Tensor,
+                 res_stats: Optional[torch.Tensor] = None, res_gamma: Optional[torch.Tensor] = None,
+                 res_beta: Optional[torch.Tensor] = None, res_eps: float = 1e-12):
+    """Decode-chain GEMM, N = hidden form: x = A W^T + bias + residual, where the residual is `res_x` itself or
+    LayerNorm(res_x) rebuilt from its strip partials.  -> (x fp32 [M,N], bf16 copy, strip partials of x)."""
     lib = load_library()
     M, K = A.shape
     N = W.shape[0]
-    ws = torch.empty(S, M, N, device=A.device, dtype=torch.float32)
-    y_f = torch.empty(M, N, device=A.device, dtype=torch.float32)
-    y_t = torch.empty(M, N, device=A.device, dtype=torch.bfloat16)
-    _ck(lib.gitmi_op_gemm_splitk_ln(A.data_ptr(), W.data_ptr(), bias.data_ptr(), residual.data_ptr(), gamma.data_ptr(),
-                                    beta.data_ptr(), eps, ws.data_ptr(), S, y_f.data_ptr(), y_t.data_ptr(), M, N, K,
-                                    _stream()))
-    return y_f, y_t
+    x = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    xb = torch.empty(M, N, device=A.device, dtype=torch.bfloat16)
+    st = torch.empty(N // 16, M, 2, device=A.device, dtype=torch.float32)
+    strips = 0 if res_stats is None else int(res_stats.shape[0])
+    _ck(lib.gitmi_op_dgemm_res(A.data_ptr(), W.data_ptr(), bias.data_ptr(), res_x.data_ptr(), _ptr(res_stats), strips,
+                               _ptr(res_gamma), _ptr(res_beta), res_eps, x.data_ptr(), xb.data_ptr(), st.data_ptr(),
+                               M, N, K, _stream()))
+    return x, xb, st
+
+
+def op_vocab_topm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, mtop: int, cols_per_wg: int = 128,
+                  colsum: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, eps: float = 1e-12,
+                  suppress_tok: Optional[torch.Tensor] = None, want_logits: bool = False):
+    """Vocabulary head with the fused running top-M / log-sum-exp: -> (part_val [M, nparts, slots], part_idx,
+    part_lse [M, nparts, 2] = (max, sum exp), logits [M, V] or None)."""
+    lib = load_library()
+    M, K = A.shape
+    V = W.shape[0]
+    nparts = (V + cols_per_wg - 1) // cols_per_wg
+    slots = 1 if mtop <= 1 else 2 if mtop <= 2 else 4 if mtop <= 4 else 8 if mtop <= 8 else 16
+    pv = torch.empty(M, nparts, slots, device=A.device, dtype=torch.float32)
+    pi = torch.empty(M, nparts, slots, device=A.device, dtype=torch.int32)
+    pl = torch.empty(M, nparts, 2, device=A.device, dtype=torch.float32)
+    lg = torch.empty(M, V, device=A.device, dtype=torch.float32) if want_logits else None
+    strips = 0 if stats is None else int(stats.shape[0])
+    _ck(lib.gitmi_op_vocab_topm(A.data_ptr(), W.data_ptr(), bias.data_ptr(), _ptr(colsum), _ptr(stats), strips, eps,
+                                M, V, K, cols_per_wg, mtop, _ptr(suppress_tok), pv.data_ptr(), pi.data_ptr(),
+                                pl.data_ptr(), _ptr(lg), _stream()))
+    return pv, pi, pl, lg
 
 
 def set_gemm_impl(impl: int) -> None:

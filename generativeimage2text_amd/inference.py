@@ -4,12 +4,15 @@
 Differences forced by the environment, not by design:
   * torchvision / azfuse are not imported: the image transform is restated on PIL (torchvision's
     Resize/CenterCrop on PIL images call PIL themselves), checkpoints are read with torch.load.
-  * the WordPiece vocabulary is looked up offline (HF cache, $GIT_VOCAB or aux_data/vocab.txt);
-    without one the tasks still run and report token ids instead of text.
+  * the WordPiece vocabulary is looked up offline ($GIT_VOCAB or aux_data/vocab.txt, then the HF cache);
+    without one the tasks fail loudly unless GIT_VOCAB=ids asks for raw token ids.
   * images are batched (the reference runs batch 1, one host sync per image; models with test_respect_ratio_max
     keep batch 1 because every image has its own resolution) and ranks return
-    their results through one RCCL gather instead of the shared-filesystem poll of
-    inference.py:214-225; shard files `{out}.{rank}.{world}.tsv` are still written.
+    their results through one RCCL gather (the task forms the process group itself from the launcher's
+    RANK/WORLD_SIZE/MASTER_* variables) and fall back to the shared-filesystem poll + concat of
+    inference.py:214-225 when no group can be formed; shard files `{out}.{rank}.{world}.tsv` are always written.
+  * the task functions default to precision="f32" (token ids bit-identical to the reference's fp32 run);
+    precision="bf16" is the throughput mode that bench.py measures.
 """
 from __future__ import annotations
 
@@ -27,6 +30,8 @@ import torch
 from .configs import MODEL_PARAMS, config_for_model
 from .model import GeneratorWithBeamSearch, CaptioningModel
 from .tsv_io import TSVFile, tsv_writer, concat_tsv_files
+
+MAX_VQA_QUESTIONS = 16      # questions of one image answered in one engine call (batched ragged prefixes)
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)      # inference.py:126-129
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -54,12 +59,15 @@ def shard_range(num_rows: int, rank: int, world: int):
 
 # ---- tokenizer --------------------------------------------------------------------------------
 class IdTokenizer:
-    """Stand-in when no WordPiece vocabulary is available offline: ids in, ids out."""
+    """Explicit opt-in (GIT_VOCAB=ids) for machines without a WordPiece vocabulary: ids in, ids out."""
     cls_token_id, sep_token_id = 101, 102
 
     def __call__(self, text, **kw):
-        ids = [int(x) for x in text.split()] if text.strip() else []
-        return {"input_ids": ids}
+        words = text.split()
+        if not all(w.isdigit() for w in words):
+            raise ValueError("IdTokenizer (GIT_VOCAB=ids) only accepts space-separated token ids, got %r; "
+                             "point GIT_VOCAB at a bert-base-uncased vocab.txt to use text" % text)
+        return {"input_ids": [int(x) for x in words]}
 
     def decode(self, ids, skip_special_tokens=True):
         if skip_special_tokens:
@@ -68,17 +76,22 @@ class IdTokenizer:
 
 
 def get_tokenizer():
-    """BertTokenizer.from_pretrained('bert-base-uncased', do_lower_case=True) (inference.py:72), offline."""
+    """BertTokenizer.from_pretrained('bert-base-uncased', do_lower_case=True) (inference.py:72), offline:
+    $GIT_VOCAB (a vocab.txt path; default aux_data/vocab.txt), else the local HF cache.  Fails loudly when no
+    vocabulary is found; GIT_VOCAB=ids selects the id-passthrough stand-in explicitly."""
     vocab = os.environ.get("GIT_VOCAB", "aux_data/vocab.txt")
-    try:
-        from transformers import BertTokenizer
-        if op.isfile(vocab):
-            return BertTokenizer(vocab, do_lower_case=True)
-        os.environ.setdefault("HF_HUB_OFFLINE", "1")
-        return BertTokenizer.from_pretrained("bert-base-uncased", do_lower_case=True)
-    except Exception as exc:   # no vocabulary on this machine
-        logging.warning("no bert-base-uncased vocabulary available (%s); reporting token ids", type(exc).__name__)
+    if vocab == "ids":
         return IdTokenizer()
+    from transformers import BertTokenizer
+    if op.isfile(vocab):
+        return BertTokenizer(vocab, do_lower_case=True)
+    os.environ.setdefault("HF_HUB_OFFLINE", "1")
+    try:
+        return BertTokenizer.from_pretrained("bert-base-uncased", do_lower_case=True)
+    except Exception as exc:
+        raise FileNotFoundError(
+            f"no bert-base-uncased vocabulary: {vocab} does not exist and the HF cache has none ({type(exc).__name__}). "
+            f"Set GIT_VOCAB=/path/to/vocab.txt, or GIT_VOCAB=ids to work with raw token ids.") from exc
 
 
 # ---- image transform (inference.py:111-132) ------------------------------------------------------
@@ -209,8 +222,9 @@ def _prefix_ids(tokenizer, prefix: str, max_text_len: int = 40) -> List[int]:
 
 
 # ---- tasks --------------------------------------------------------------------------------------
-def test_git_inference_single_image(image_path, model_name, prefix, *, checkpoint=None, precision="bf16"):
-    """inference.py:67-109.  image_path: str or list of str (video frames); logs 'output: <caption>'."""
+def test_git_inference_single_image(image_path, model_name, prefix, *, checkpoint=None, precision="f32"):
+    """inference.py:67-109.  image_path: str or list of str (video frames); logs 'output: <caption>'.
+    precision "f32" (default) = the reference's arithmetic (ids bit-identical); "bf16" = throughput mode."""
     param = MODEL_PARAMS.get(model_name, {})
     tokenizer = get_tokenizer()
     if isinstance(image_path, str):
@@ -229,11 +243,33 @@ def test_git_inference_single_image(image_path, model_name, prefix, *, checkpoin
     test_git_inference_single_image.last_output = cap
 
 
-def _gather_rows(rows: List[list]) -> Optional[List[list]]:
-    """Result gather over RCCL (replaces the file poll of inference.py:214-225). Rank 0 gets all rows."""
+def json_dump(obj) -> str:
+    """common.py:223-226: sorted keys, compact separators -- what the reference writes into every TSV row."""
+    return json.dumps(obj, sort_keys=True, separators=(",", ":"))
+
+
+def ensure_process_group(rank: int, world: int) -> bool:
+    """Form the result-gather group of a multi-rank run when the launcher gave us a rendezvous
+    (torchrun / torch.distributed.run export MASTER_ADDR+MASTER_PORT; so can an mpirun wrapper).
+    RCCL ("nccl") when this rank has a GPU, gloo otherwise (CPU tests).  Returns False when no group
+    can be formed (plain `mpirun -n 8` as in the reference README): the caller then falls back to the
+    reference's shared-filesystem hand-off (inference.py:214-225)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return rows
+    if world <= 1 or not dist.is_available():
+        return False
+    if dist.is_initialized():
+        return True
+    if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:
+        return False
+    backend = "nccl" if torch.cuda.is_available() else "gloo"
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    return True
+
+
+def _gather_rows(rows: List[list]) -> Optional[List[list]]:
+    """Result gather over RCCL (replaces the file poll of inference.py:214-225). Rank 0 gets all rows in
+    rank order.  Only called with an initialised process group."""
+    import torch.distributed as dist
     out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
     dist.gather_object(rows, out, dst=0)
     if dist.get_rank() != 0:
@@ -241,54 +277,108 @@ def _gather_rows(rows: List[list]) -> Optional[List[list]]:
     return [r for part in out for r in part]
 
 
-def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, *, checkpoint=None,
-                                  batch_size=64, precision="bf16"):
-    """inference.py:134-225.  image_tsv rows: key \\t base64(jpeg).  question_tsv (optional) rows:
-    key \\t json list of {'question', 'question_id'}.  Writes out_tsv rows
-    key \\t [{"caption": ...}]   or   key \\t {"answer": ..., "question_id": ...}."""
-    param = MODEL_PARAMS.get(model_name, {})
-    tokenizer = get_tokenizer()
-    torch.cuda.set_device(get_mpi_local_rank())                             # inference.py:152
-    is_vqa = question_tsv is not None
-    if "test_respect_ratio_max" in param:
-        batch_size = 1            # aspect-preserving resize: every image has its own resolution (as in the reference)
-    model = build_model(model_name, tokenizer, checkpoint, max_batch=1 if is_vqa else batch_size, precision=precision)
-    transforms = get_image_transform(param, gpu=True)
-    rank, world = get_mpi_rank(), get_mpi_size()
+def _wait_and_concat_shards(out_tsv: str, world: int, poll_s: float = 0.2, timeout_s: float = 3600.0) -> None:
+    """The reference's hand-off when ranks share nothing but a filesystem (inference.py:214-225): rank 0 waits
+    for every `{out}.{rank}.{world}.tsv` (tsv_writer renames them into place when complete) and concatenates."""
+    import time
+    shards = [f"{out_tsv}.{r}.{world}.tsv" for r in range(world)]
+    t0 = time.time()
+    while True:
+        not_ready = [t for t in shards if not op.isfile(t)]
+        if not not_ready:
+            break
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError("shard files never appeared: " + ",".join(not_ready))
+        logging.info("waiting {}".format(",".join(not_ready)))
+        time.sleep(poll_s)
+    concat_tsv_files(shards, out_tsv)
+
+
+def run_tsv_inference(image_tsv: str, question_tsv: Optional[str], out_tsv: str, *, transform, caption_batch,
+                      answer_questions, batch_size: int, rank: Optional[int] = None, world: Optional[int] = None,
+                      poll_s: float = 0.2) -> None:
+    """Everything of test_git_inference_single_tsv (inference.py:134-225) except the model: shard the rows by
+    rank (:165-169), write this rank's rows, and deliver the complete, ordered `out_tsv` on rank 0 --
+    through ONE RCCL gather when a process group exists or can be formed, else through the reference's
+    shard-file poll + concat.  Rank 0 never writes `out_tsv` from its own rows alone.
+
+      transform(bytes) -> image tensor;  caption_batch(list of images) -> list of caption strings;
+      answer_questions(image, list of question strings) -> list of answer strings.
+    Row formats are the reference's: `key \t json_dump([{"caption": ...}])` (:212) and the ONE-column
+    `json_dump({"answer": ..., "question_id": ...})` (:199) that convert_tsv_to_vqa_json (:227-229) reads."""
+    rank = get_mpi_rank() if rank is None else rank
+    world = get_mpi_size() if world is None else world
     tsv = TSVFile(image_tsv)
     start, end = shard_range(len(tsv), rank, world)
     shard_file = out_tsv if world == 1 else f"{out_tsv}.{rank}.{world}.tsv"    # inference.py:159-164
-    questions = TSVFile(question_tsv) if is_vqa else None
+    questions = TSVFile(question_tsv) if question_tsv else None
     rows: List[list] = []
 
-    def run_batch(keys: Sequence[str], imgs: Sequence[torch.Tensor]):
-        with torch.no_grad():
-            res = model({"image": torch.stack(list(imgs)).cuda()})
-        for key, pred in zip(keys, res["predictions"].tolist()):
-            rows.append([key, json.dumps([{"caption": tokenizer.decode(pred, skip_special_tokens=True)}])])
+    def flush(keys, imgs):
+        for key, cap in zip(keys, caption_batch(imgs)):
+            rows.append([key, json_dump([{"caption": cap}])])
 
     keys, imgs = [], []
     for i in range(start, end):
         key, b64 = tsv[i][0], tsv[i][1]
-        img = transforms(load_image_by_pil(base64.b64decode(b64)))
-        if not is_vqa:
+        img = transform(base64.b64decode(b64))
+        if questions is None:
             keys.append(key)
             imgs.append(img)
             if len(keys) == batch_size:
-                run_batch(keys, imgs)
+                flush(keys, imgs)
                 keys, imgs = [], []
             continue
         qkey, qjson = questions[i][0], questions[i][1]
         assert qkey == key
-        for q in json.loads(qjson):                                          # inference.py:172-199
-            ids = _prefix_ids(tokenizer, q["question"])
-            with torch.no_grad():
-                res = model({"image": img.unsqueeze(0).cuda(), "prefix": torch.tensor(ids).unsqueeze(0).cuda()})
-            ans = tokenizer.decode(res["predictions"][0].tolist(), skip_special_tokens=True)
-            rows.append([key, json.dumps({"answer": ans, "question_id": q["question_id"]})])
+        q_info = json.loads(qjson)                                            # inference.py:172-199
+        answers = answer_questions(img, [q["question"] for q in q_info])
+        for q, ans in zip(q_info, answers):
+            rows.append([json_dump({"answer": ans, "question_id": q["question_id"]})])
     if keys:
-        run_batch(keys, imgs)
+        flush(keys, imgs)
     tsv_writer(rows, shard_file)
-    all_rows = _gather_rows(rows)
-    if world > 1 and rank == 0:
-        tsv_writer(all_rows, out_tsv)
+    if world == 1:
+        return
+    if ensure_process_group(rank, world):
+        all_rows = _gather_rows(rows)
+        if rank == 0:
+            tsv_writer(all_rows, out_tsv)
+    elif rank == 0:
+        _wait_and_concat_shards(out_tsv, world, poll_s=poll_s)
+
+
+def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, *, checkpoint=None,
+                                  batch_size=64, precision="f32"):
+    """inference.py:134-225.  image_tsv rows: key \\t base64(jpeg).  question_tsv (optional) rows:
+    key \\t json list of {'question', 'question_id'}.  Writes out_tsv rows
+    key \\t [{"caption": ...}]   or the one-column   {"answer": ..., "question_id": ...}.
+
+    precision: "f32" (default) reproduces the reference's fp32 token ids bit for bit; "bf16" is the
+    throughput mode (ids may leave the reference's at near-ties, DESIGN.md "parity budget")."""
+    param = MODEL_PARAMS.get(model_name, {})
+    tokenizer = get_tokenizer()
+    torch.cuda.set_device(get_mpi_local_rank())                             # inference.py:152
+    is_vqa = bool(question_tsv)
+    if "test_respect_ratio_max" in param:
+        batch_size = 1            # aspect-preserving resize: every image has its own resolution (as in the reference)
+    model = build_model(model_name, tokenizer, checkpoint, max_batch=MAX_VQA_QUESTIONS if is_vqa else batch_size,
+                        precision=precision)
+    transforms = get_image_transform(param, gpu=True)
+
+    def caption_batch(imgs: Sequence[torch.Tensor]) -> List[str]:
+        with torch.no_grad():
+            res = model({"image": torch.stack(list(imgs)).cuda()})
+        return [tokenizer.decode(pred, skip_special_tokens=True) for pred in res["predictions"].tolist()]
+
+    def answer_questions(img: torch.Tensor, qs: Sequence[str]) -> List[str]:
+        out: List[str] = []
+        for lo in range(0, len(qs), MAX_VQA_QUESTIONS):
+            chunk = [_prefix_ids(tokenizer, q) for q in qs[lo:lo + MAX_VQA_QUESTIONS]]
+            with torch.no_grad():
+                preds = model.answer(img.unsqueeze(0).cuda(), chunk)
+            out += [tokenizer.decode(p, skip_special_tokens=True) for p in preds]
+        return out
+
+    run_tsv_inference(image_tsv, question_tsv, out_tsv, transform=lambda b: transforms(load_image_by_pil(b)),
+                      caption_batch=caption_batch, answer_questions=answer_questions, batch_size=batch_size)

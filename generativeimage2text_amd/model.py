@@ -145,7 +145,9 @@ class CaptioningModel:
         if not self._loaded:
             raise RuntimeError("weights not loaded (call load_state_dict first)")
         image = batch["image"]
-        frames = list(image) if isinstance(image, (list, tuple)) else [image]
+        is_list = isinstance(image, (list, tuple))
+        frames = list(image) if is_list else [image]
+        self.engine.set_temporal_embedding(is_list)                       # decoder.py:845-857: list branch only
         prefix = batch.get("prefix")
         if prefix is not None:
             assert len(prefix) == 1, "not supported"                       # decoder.py:988
@@ -167,6 +169,34 @@ class CaptioningModel:
         return {"predictions": predictions, "logprobs": logprobs}
 
     __call__ = forward
+
+    def answer(self, image: Union[torch.Tensor, Sequence[torch.Tensor]], prefixes: Sequence[Sequence[int]]):
+        """Several questions about ONE image in one engine call (batched ragged prefixes): each prefix is a list of
+        token ids starting with [CLS].  Returns, per question, the list of predicted token ids exactly as
+        ``model({'image': image, 'prefix': [prefix]})['predictions'][0]`` gives them -- the reference loop of
+        inference.py:172-199 without re-encoding the image per question."""
+        if not self._loaded:
+            raise RuntimeError("weights not loaded (call load_state_dict first)")
+        is_list = isinstance(image, (list, tuple))
+        frames = list(image) if is_list else [image]
+        assert frames[0].shape[0] == 1, "answer() takes one image (or one clip)"
+        self.engine.set_temporal_embedding(is_list)
+        Q = len(prefixes)
+        if Q > self.engine.c.max_batch:
+            raise ValueError(f"{Q} questions exceed max_batch={self.engine.c.max_batch}")
+        tokens, logprobs, sent, info = self.engine.generate_prefixed(frames, self._search_struct(), prefixes,
+                                                                     image_of=[0] * Q)
+        tokens, sent = tokens.cpu(), sent.cpu()
+        out = []
+        for q, p in enumerate(prefixes):
+            P = len(p)
+            L, early = int(sent[q, 0]), int(sent[q, 1])
+            if self.decoder.kind == "autoregressive":
+                row = (tokens[q, P:P + 1] if early else tokens[q, :L])[P:]     # decoder.py:279-291, then :1004-1006
+            else:
+                row = tokens[q, P:]
+            out.append(row.tolist())
+        return out
 
 
 def get_git_model(tokenizer, param: Optional[dict], precision: str = "bf16", max_batch: int = 64,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GITMI_ABI_VERSION 2
+#define GITMI_ABI_VERSION 3
 
 /* compute precision of GEMM/attention operands (accumulation, LayerNorm statistics,
  * softmax, residual stream and logits are fp32 in both modes) */
@@ -136,6 +136,10 @@ int  gitmi_set_image_shape(gitmi_engine* e, int H, int W, void* stream);
 int  gitmi_encode_frames(gitmi_engine* e, const float* const* frames, int F, int B,
                          float* feats_out, void* stream);
 
+/* batch['image'] given as a LIST of frames (on = 1, default) or as a bare tensor (on = 0): the reference adds
+ * img_temperal_embedding[i] to frame i only in the list case (decoder.py:845-857). */
+int  gitmi_set_temporal_embedding(gitmi_engine* e, int on);
+
 /* ---- decoder prefill over image tokens (visual_projection + image rows of all layers);
  * builds the per-image K/V cache.  Mathematically the image part of
  * TransformerDecoderTextualHead.forward (decoder.py:521-600), computed once per image. */
@@ -158,10 +162,27 @@ int  gitmi_step_logits(gitmi_engine* e, const int64_t* tokens, int R, int t,
  *   info_out     : int32 [4] = { seq_len, early_all_eos, steps_run, 0 }
  *                  seq_len = length of the tensor the reference returns (AUTOREGRESSIVE stops
  *                  when every beam ended, decoder.py:319; GENERATOR always max_steps);
- *                  early_all_eos=1 is the first-step early return of decoder.py:279-291. */
+ *                  early_all_eos=1 is the first-step early return of decoder.py:279-291;
+ *                  steps_run = text positions appended (max_steps - 1 unless a long-budget call stopped early). */
 int  gitmi_generate(gitmi_engine* e, const float* const* frames, int F, int B,
                     const int64_t* prefix, int P, const gitmi_search* search,
                     int64_t* tokens_out, float* logprob_out, int32_t* info_out, void* stream);
+
+/* ---- batched VQA: Q sentences with their OWN prefixes over B images.  The reference answers one question per
+ * model call (decoder.py:984-989 asserts a single prefix; inference.py:172-199 loops); here the questions of one
+ * image share its encoded K/V and questions of different lengths share every decode step (all sentences sit at the
+ * same text position; a sentence still inside its prefix just appends the given token).  Each sentence gets exactly
+ * what its own batch-1 reference call returns.
+ *   prefixes        : int64 [Q, ld_prefix] DEVICE, row q = its tokens incl. [CLS] (entries past its length ignored)
+ *   prefix_len_host : int32 [Q] HOST, 1 <= len <= ld_prefix
+ *   image_of_host   : int32 [Q] HOST, image index of every sentence, or NULL (Q == B, sentence q <-> image q)
+ *   tokens_out      : int64 [Q, max_steps], logprob_out fp32 [Q] as in gitmi_generate
+ *   sent_out        : int32 [Q, 2] = (length of the sequence returned for this sentence, its early-return flag) or NULL */
+int  gitmi_generate_prefixed(gitmi_engine* e, const float* const* frames, int F, int B,
+                             const int64_t* prefixes, int ld_prefix, const int32_t* prefix_len_host,
+                             const int32_t* image_of_host, int Q, const gitmi_search* search,
+                             int64_t* tokens_out, float* logprob_out, int32_t* sent_out, int32_t* info_out,
+                             void* stream);
 
 /* ---- search with caller-supplied logits: the seam decoder.search(start, step)
  * (decoder.py:224-231, 1083-1092) for scripted-step parity tests of the device search.
@@ -195,16 +216,28 @@ int  gitmi_op_layernorm(const float* x, const float* gamma, const float* beta, f
 int  gitmi_op_attention(const void* qkv, void* out, int B, int N, int H, int dtype, int impl,
                         void* stream);
 
-/* decode-step weight-streaming GEMM (bf16 A,W; M small): same contract as gitmi_op_gemm, dense
- * lda=K, ldc=N.  NT in {1,2}: 16*NT output columns per workgroup. */
-int  gitmi_op_gemm_skinny(const void* A, const void* W, const float* bias, const float* residual,
-                          void* C, int M, int N, int K, int out_dtype, int act, int NT, void* stream);
-/* y = LayerNorm(A W^T + bias + residual): split-K over S workgroup slices into fp32 slabs
- * partial_ws [S,M,N], summed in fixed order with the LayerNorm fused (BertSelfOutput / BertOutput,
- * modeling_bert.py:171-178, 243-250).  Outputs fp32 and bf16 copies.  N <= 1024. */
-int  gitmi_op_gemm_splitk_ln(const void* A, const void* W, const float* bias, const float* residual,
-                             const float* gamma, const float* beta, float eps, float* partial_ws, int S,
-                             float* y_f32, void* y_bf16, int M, int N, int K, void* stream);
+/* decode-step GEMM chain (kernels_dgemm.hip; bf16 A [M,K], W [N,K], K % 32 == 0).  The post-norm BERT layer
+ * (modeling_bert.py:171-178, 243-250) runs WITHOUT LayerNorm launches: the N = hidden GEMMs emit the pre-LayerNorm
+ * sum and per-16-column-strip row partials (sum, sum of squares), the consumer GEMM folds the LayerNorm.
+ * stats layout: fp32 [strips][M][2].
+ *   gitmi_op_dgemm     : C bf16 [M,N] = act( LN_fold(A) W^T + bias ); stats == NULL: plain A W^T + bias.
+ *                        With stats: W must be bf16(W . gamma), bias = beta W^T + b, colsum[n] = sum_k W'[n][k].
+ *   gitmi_op_dgemm_res : x = A W^T + bias + r,  r = res_x (res_stats == NULL) or LayerNorm(res_x; res_gamma, res_beta)
+ *                        rebuilt from res_stats; writes x fp32, its bf16 copy and stats_out [N/16][M][2].  N % 16 == 0. */
+int  gitmi_op_dgemm(const void* A, const void* W, const float* bias, const float* colsum, const float* stats,
+                    int strips, float eps, void* C, int M, int N, int K, int act, void* stream);
+int  gitmi_op_dgemm_res(const void* A, const void* W, const float* bias, const float* res_x, const float* res_stats,
+                        int res_strips, const float* res_gamma, const float* res_beta, float res_eps,
+                        float* x_out, void* xb_out, float* stats_out, int M, int N, int K, void* stream);
+/* vocabulary head with the search's top-M and log-softmax statistics fused (replaces decoder.py:1054 + the
+ * log_softmax/topk of :265-271, 358-366, 1169-1175): one workgroup sweeps cols_per_wg columns for all rows and writes
+ * a sorted list of `slots` = {1,2,4,8,16} >= mtop (logit, token) pairs + (max, sum exp) per (row, workgroup):
+ * part_val/part_idx [M][ceil(V/cols_per_wg)][slots], part_lse [..][2].  suppress_tok int32 [M] (or NULL): that
+ * token's logit counts as -10000 (decoder.py:330).  logits_out fp32 [M,V] optional.  K <= 768. */
+int  gitmi_op_vocab_topm(const void* A, const void* W, const float* bias, const float* colsum, const float* stats,
+                         int strips, float eps, int M, int V, int K, int cols_per_wg, int mtop,
+                         const int* suppress_tok, float* part_val, int* part_idx, float* part_lse,
+                         float* logits_out, void* stream);
 
 /* decode attention for one new text position (unit parity / timing): qkv [R,3d] (R = B*beams), image K/V
  * head-major [B][H][N_img][64], text caches [R][T_max][d] (position `pos` is appended), kv_src int32 [R][T_max],

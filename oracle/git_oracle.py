@@ -96,7 +96,7 @@ CONFIGS: Dict[str, GitConfig] = {
 # token IDs / logits with these weights.
 # ----------------------------------------------------------------------------
 def make_weights(cfg: GitConfig, seed: int = 1234, tie_output: bool = True,
-                 eos_bias: float = 0.0, out_scale: float = 1.0) -> Weights:
+                 eos_bias: float = 0.0, out_scale: float = 1.0, successor: float = 0.0) -> Weights:
     """Deterministic fp32 weights.
 
     Shapes/initial scales follow CLIP/model.py:224-235 (ViT: scale*randn
@@ -104,6 +104,11 @@ def make_weights(cfg: GitConfig, seed: int = 1234, tie_output: bool = True,
     LayerNorm affines and temporal embeddings are perturbed (they are 1/0/0 at
     reference init, which would hide a missing affine or a missing add).
     ``eos_bias`` lifts the EOS logit so that end-of-sentence paths get exercised.
+    ``successor`` (untied output only) adds s * E[perm] to the output matrix, E = word embedding,
+    perm a seeded permutation: the logit of token v then grows with the similarity of the hidden
+    state to the embedding of perm[v], i.e. tokens tend to be followed by "their successor".  Plain
+    random decoders fall into A-B-A-B loops under the no-immediate-repeat rule (decoder.py:330);
+    this keeps 19-step decodes long and diverse without changing any shape or code path.
     """
     g = torch.Generator().manual_seed(seed)
 
@@ -159,6 +164,9 @@ def make_weights(cfg: GitConfig, seed: int = 1234, tie_output: bool = True,
         w["textual.output.weight"] = w["textual.embedding.words.weight"]
     else:
         w["textual.output.weight"] = rn(V, d, std=0.05)
+        if successor != 0.0:
+            perm = torch.randperm(V, generator=torch.Generator().manual_seed(seed + 7919))
+            w["textual.output.weight"] = w["textual.output.weight"] + successor * w["textual.embedding.words.weight"][perm]
     if out_scale != 1.0:
         w["textual.output.weight"] = w["textual.output.weight"] * out_scale
         if tie_output:
@@ -290,10 +298,15 @@ def vit_forward(cfg: GitConfig, w: Weights, images: Tensor) -> Tensor:
     return _layer_norm(x, w["image_encoder.ln_post.weight"], w["image_encoder.ln_post.bias"], 1e-5)
 
 
-def visual_features(cfg: GitConfig, w: Weights, frames: Sequence[Tensor]) -> Tensor:
+def visual_features(cfg: GitConfig, w: Weights, frames: Sequence[Tensor], as_list: bool = True) -> Tensor:
     """CaptioningModel.forward_one image branch (decoder.py:845-857): per-frame encode,
-    + temporal embedding i, concat on the token axis (zip truncates to #embeddings)."""
+    + temporal embedding i, concat on the token axis (zip truncates to #embeddings).
+    as_list=False: batch['image'] was a bare tensor -- image_encoder only, NO temporal embedding even on a
+    video model (the else branch, decoder.py:856-857)."""
     feats = [vit_forward(cfg, w, f) for f in frames]
+    if not as_list:
+        assert len(feats) == 1
+        return feats[0]
     if cfg.num_frames:
         feats = [f + w[f"img_temperal_embedding.{i}"] for i, f in enumerate(feats[: cfg.num_frames])]
     return feats[0] if len(feats) == 1 else torch.cat(feats, dim=1)
@@ -418,8 +431,15 @@ def make_step(cfg: GitConfig, w: Weights, feats: Tensor, cached: bool = False) -
 # ----------------------------------------------------------------------------
 # search strategies
 # ----------------------------------------------------------------------------
+def _adjacent_gap(sorted_scores: Tensor) -> Tensor:
+    """Smallest difference between neighbours of a descending score list [B, n] -> [B]: the amount of
+    logit noise that could change which candidates a top-k keeps, or their order."""
+    return (sorted_scores[:, :-1] - sorted_scores[:, 1:]).min(dim=1).values
+
+
 def search_autoregressive(start: Tensor, step: Callable[[Tensor], Tensor], eos: int, max_steps: int,
-                          beam_size: int = 1, per_node_beam_size: int = 1) -> Tuple[Tensor, Tensor]:
+                          beam_size: int = 1, per_node_beam_size: int = 1,
+                          trace: Optional[List[Tensor]] = None) -> Tuple[Tensor, Tensor]:
     """AutoRegressiveBeamSearch.search with fix_missing_prefix=True, only_return_best=True,
     no sampling (decoder.py:224-440).  Greedy oracle = beam_size=per_node=1.
 
@@ -431,6 +451,8 @@ def search_autoregressive(start: Tensor, step: Callable[[Tensor], Tensor], eos: 
     lp0 = torch.log_softmax(step(start), dim=1)                                 # :257-265
     V = lp0.shape[1]
     last_lp, cls0 = lp0.topk(k)                                                 # :271
+    if trace is not None:       # test diagnostics only: decision margin of this step per image
+        trace.append(_adjacent_gap(lp0.topk(k + 1).values))
     if k == 1 and bool((cls0 == eos).all()):                                    # :279-289
         return cls0, last_lp
     preds = torch.cat([preds, cls0[:, :, None]], dim=-1)                        # :298
@@ -453,6 +475,11 @@ def search_autoregressive(start: Tensor, step: Callable[[Tensor], Tensor], eos: 
         cand_seq = torch.cat([flat[:, None, :].expand(B * k, pn, flat.shape[1]).reshape(B, k * pn, -1),
                               cand_cls[:, :, None]], dim=-1)                    # :399-405
         last_lp, keep = summed.topk(k)                                          # :409
+        if trace is not None:
+            if k == 1 and pn == 1:
+                trace.append(_adjacent_gap(lp.topk(2).values))
+            else:
+                trace.append(_adjacent_gap(summed.topk(min(k + 1, k * pn)).values))
         preds = cand_seq.gather(1, keep[:, :, None].expand(B, k, cand_seq.shape[-1]))
     best = preds[:, 0, :]                                                       # :431
     best_lp = last_lp[:, 0]
@@ -492,7 +519,7 @@ class _Hypotheses:
 
 def search_generator(start: Tensor, step: Callable[[Tensor], Tensor], eos: int, max_steps: int,
                      beam_size: int = 4, per_node_beam_size: int = 2,
-                     length_penalty: float = 0.6) -> Tuple[Tensor, Tensor]:
+                     length_penalty: float = 0.6, trace: Optional[List[Tensor]] = None) -> Tuple[Tensor, Tensor]:
     """GeneratorWithBeamSearch.search, greedy-beam branch, num_keep_best=1
     (decoder.py:1083-1290).  Shipped default: beam 4, per_node 2, length_penalty 0.6.
 
@@ -510,6 +537,9 @@ def search_generator(start: Tensor, step: Callable[[Tensor], Tensor], eos: int, 
         V = lp.shape[-1]
         tot = (lp + beam_scores[:, None]).reshape(B, k * V)
         nxt_s, nxt_i = torch.topk(tot, per_node_beam_size * k, dim=1, largest=True, sorted=True)   # :1175
+        if trace is not None:       # test diagnostics only (live images; finished ones report +inf)
+            gap = _adjacent_gap(torch.topk(tot, per_node_beam_size * k + 1, dim=1).values)
+            trace.append(torch.where(torch.tensor(done), torch.full_like(gap, float("inf")), gap))
         rows: List[Tuple[float, int, int]] = []
         for b in range(B):                                                      # :1184-1222
             done[b] = done[b] or hyps[b].is_done(float(nxt_s[b].max()))
@@ -564,7 +594,7 @@ BEAM4 = SearchConfig("beam", 20, 4, 2, 0.6)                      # model.py:34-4
 
 def caption(cfg: GitConfig, w: Weights, frames: Sequence[Tensor], search: SearchConfig = GREEDY,
             prefix: Optional[Tensor] = None, cached: bool = False,
-            feats: Optional[Tensor] = None) -> Dict[str, Tensor]:
+            feats: Optional[Tensor] = None, trace: Optional[List[Tensor]] = None) -> Dict[str, Tensor]:
     """model({'image': ..., 'prefix': ...}) -> {'predictions','logprobs'} exactly as
     CaptioningModel.infer returns them (prefix stripped, decoder.py:1004-1006)."""
     if feats is None:
@@ -578,10 +608,10 @@ def caption(cfg: GitConfig, w: Weights, frames: Sequence[Tensor], search: Search
     step = make_step(cfg, w, feats, cached=cached)
     if search.kind == "greedy":
         preds, lps = search_autoregressive(start, step, cfg.eos, search.max_steps,
-                                           search.beam_size, search.per_node_beam_size)
+                                           search.beam_size, search.per_node_beam_size, trace=trace)
     else:
         preds, lps = search_generator(start, step, cfg.eos, search.max_steps, search.beam_size,
-                                      search.per_node_beam_size, search.length_penalty)
+                                      search.per_node_beam_size, search.length_penalty, trace=trace)
     if prefix is not None:
         preds = preds[:, start.shape[1]:]
     return {"predictions": preds, "logprobs": lps, "visual_features": feats}

@@ -77,33 +77,40 @@ def build_reference(cfg: O.GitConfig, w: O.Weights, search: O.SearchConfig, tie:
     return model
 
 
+# Untied output weights + the `successor` structure (git_oracle.make_weights) keep 19-step decodes long and diverse;
+# with plain tied random weights most cases collapse to A-B-A-B loops or end at step 1.  The early-exit branches keep
+# their own, explicitly named cases.
+_LONG = dict(tie_output=False, successor=2.0)
 CASES = {
-    # name: (config, weights kw, batch, frames, search, prefix, atol_feat)
-    "tiny_greedy": ("TINY", dict(seed=11, eos_bias=2.5), 3, 1, O.GREEDY, None),
+    # name: (config, weights kw, batch, frames, search, prefix[, (H, W)])
+    "tiny_greedy_early_return": ("TINY", dict(seed=11, eos_bias=2.5), 3, 1, O.GREEDY, None),          # decoder.py:279-291
     "tiny_greedy_untied": ("TINY", dict(seed=12, tie_output=False, eos_bias=1.0), 4, 1, O.GREEDY, None),
-    "tiny_beam4": ("TINY", dict(seed=13, eos_bias=2.0), 3, 1, O.BEAM4, None),
-    "tiny_beam4_noeos": ("TINY", dict(seed=14), 2, 1, O.BEAM4, None),
-    "tiny_beam3_pn3": ("TINY", dict(seed=15, eos_bias=1.5), 2, 1, O.SearchConfig("beam", 12, 3, 3, 1.0), None),
-    "tiny_ar_beam3": ("TINY", dict(seed=16, eos_bias=2.0), 3, 1, O.SearchConfig("greedy", 16, 3, 2), None),
+    "tiny_greedy_long": ("TINY", dict(seed=22, **_LONG), 5, 1, O.GREEDY, None),
+    "tiny_beam4": ("TINY", dict(seed=13, eos_bias=1.5, **_LONG), 3, 1, O.BEAM4, None),
+    "tiny_beam4_noeos": ("TINY", dict(seed=14, **_LONG), 2, 1, O.BEAM4, None),
+    "tiny_beam4_early_done": ("TINY", dict(seed=13, eos_bias=2.0), 3, 1, O.BEAM4, None),             # every sentence done at step 1-2
+    "tiny_beam3_pn3": ("TINY", dict(seed=15, eos_bias=3.0, **_LONG), 2, 1, O.SearchConfig("beam", 12, 3, 3, 1.0), None),
+    "tiny_ar_beam3": ("TINY", dict(seed=16, eos_bias=2.0, **_LONG), 3, 1, O.SearchConfig("greedy", 16, 3, 2), None),
     "tiny_prefix_greedy": ("TINY", dict(seed=17, eos_bias=1.0), 1, 1, O.GREEDY, [101, 7, 44, 512, 9]),
-    "tiny_prefix_beam4": ("TINY", dict(seed=18, eos_bias=1.5), 1, 1, O.BEAM4, [101, 300, 2]),
-    "tiny_video_greedy": ("TINY_VIDEO", dict(seed=19, eos_bias=1.0), 2, 3, O.GREEDY, None),
-    "tiny_video_beam4": ("TINY_VIDEO", dict(seed=20, eos_bias=1.5), 2, 3, O.BEAM4, None),
+    "tiny_prefix_beam4": ("TINY", dict(seed=18, eos_bias=1.5, **_LONG), 1, 1, O.BEAM4, [101, 300, 2]),
+    "tiny_video_greedy": ("TINY_VIDEO", dict(seed=19, **_LONG), 2, 3, O.GREEDY, None),
+    "tiny_video_beam4": ("TINY_VIDEO", dict(seed=20, eos_bias=0.3, **_LONG), 2, 3, O.BEAM4, None),
     "tinyl_greedy": ("TINY_L", dict(seed=21, eos_bias=1.0), 3, 1, O.GREEDY, None),
     "base_greedy": ("GIT_BASE", dict(seed=1234), 2, 1, O.GREEDY, None),
     "base_greedy_eos": ("GIT_BASE", dict(seed=1235, tie_output=False, eos_bias=0.25), 2, 1, O.GREEDY, None),
     "base_beam4": ("GIT_BASE", dict(seed=1234, eos_bias=0.2), 2, 1, O.BEAM4, None),
-    "base_prefix_beam4": ("GIT_BASE", dict(seed=1236, eos_bias=0.2), 1, 1, O.BEAM4, [101, 2054, 2003, 2023, 1029]),
+    "base_prefix_beam4": ("GIT_BASE", dict(seed=1236, tie_output=False, successor=4.0, eos_bias=11.0), 1, 1, O.BEAM4,
+                          [101, 2054, 2003, 2023, 1029]),
     "large_greedy": ("GIT_LARGE", dict(seed=1237), 1, 1, O.GREEDY, None),
     "vatex_greedy": ("GIT_BASE_VATEX", dict(seed=1238), 1, 6, O.SearchConfig("greedy", 8, 1, 1), None),
     # non-native input resolution (MinMaxResizeForTest models): run-time bicubic resize of the positional grid,
     # H, W not multiples of the patch (the stride-p convolution drops the remainder), up- and down-scaling
     "tiny_varres_up": ("TINY", dict(seed=31, eos_bias=1.0), 2, 1, O.GREEDY, None, (90, 120)),
-    "tiny_varres_down_beam4": ("TINY", dict(seed=32), 2, 1, O.BEAM4, None, (48, 70)),
-    "tiny_varres_prefix": ("TINY", dict(seed=33, eos_bias=1.0), 1, 1, O.BEAM4, [101, 9, 77, 5], (80, 112)),
-    "tinyl_varres": ("TINY_L", dict(seed=34, eos_bias=1.0), 2, 1, O.GREEDY, None, (70, 100)),
-    "vqa_base_480x640": ("GIT_BASE_VQAv2", dict(seed=1239, eos_bias=0.3), 1, 1, O.SearchConfig("beam", 12, 4, 2, 0.6),
-                         [101, 2054, 3609, 2003, 1996, 4937, 1029], (480, 640)),
+    "tiny_varres_down_beam4": ("TINY", dict(seed=32, **_LONG), 2, 1, O.BEAM4, None, (48, 70)),
+    "tiny_varres_prefix": ("TINY", dict(seed=33, eos_bias=3.0, **_LONG), 1, 1, O.BEAM4, [101, 9, 77, 5], (80, 112)),
+    "tinyl_varres": ("TINY_L", dict(seed=34, **_LONG), 2, 1, O.GREEDY, None, (70, 100)),
+    "vqa_base_480x640": ("GIT_BASE_VQAv2", dict(seed=1239, tie_output=False, successor=4.0, eos_bias=11.0), 1, 1,
+                         O.SearchConfig("beam", 12, 4, 2, 0.6), [101, 2054, 3609, 2003, 1996, 4937, 1029], (480, 640)),
 }
 
 
@@ -137,7 +144,8 @@ def run_case(name: str):
 
     t0 = time.time()
     with torch.no_grad():
-        ora = O.caption(cfg, w, frames, search, prefix=pfx, cached=False)
+        trace = []
+        ora = O.caption(cfg, w, frames, search, prefix=pfx, cached=False, trace=trace)
         ora_tf = O.textual_logits_full(cfg, w, ora["visual_features"], tf_tokens)[:, -1, :]
         ora_c = O.caption(cfg, w, frames, search, prefix=pfx, cached=True, feats=ora["visual_features"])
     t_ora = time.time() - t0
@@ -154,9 +162,11 @@ def run_case(name: str):
     assert lp_err < 1e-4, (name, "logprobs", lp_err)
     assert torch.equal(ora_c["predictions"], ref["predictions"]), (name, "cached variant tokens")
     assert (ora_c["logprobs"] - ref["logprobs"]).abs().max().item() < 1e-4
+    margins = torch.stack(trace, dim=1) if trace else torch.zeros(B, 0)
+    uniq = [len(set(r.tolist())) for r in ref["predictions"]]
     print(f"[{name}] OK  ref {t_ref:.1f}s oracle {t_ora:.1f}s  feat_err {feat_err:.2e} tf_err {tf_err:.2e} "
-          f"lp_err {lp_err:.2e}  pred shape {tuple(ref['predictions'].shape)}  "
-          f"row0 {ref['predictions'][0].tolist()}")
+          f"lp_err {lp_err:.2e}  pred shape {tuple(ref['predictions'].shape)}  distinct ids/row {uniq}  "
+          f"row0 {ref['predictions'][0].tolist()}", flush=True)
 
     # ---- freeze the REFERENCE outputs ------------------------------------------
     big = cfg.vocab > 5000
@@ -173,6 +183,83 @@ def run_case(name: str):
         tf_logits=(ref_tf[:, ::3] if big else ref_tf).numpy().astype(np.float32),
         tf_argmax=ref_tf.argmax(-1).numpy(),
         tf_top2_margin=(ref_tf.topk(2).values[:, 0] - ref_tf.topk(2).values[:, 1]).numpy(),
+        step_margin=margins.numpy().astype(np.float32),     # oracle (== reference, asserted above) decision margins per step
+    )
+
+
+# ---- BASELINE.json configs at their full batch sizes ---------------------------------------------
+# name: (config, weights, batch, frames, search).  weights: dict -> O.make_weights(**kw);
+# "bench" -> generativeimage2text_amd.synthetic.random_state_dict(seed=1234) + random_frames(seed=0),
+# i.e. exactly what `python bench.py` runs, so the bench line can report id parity for its own workload.
+FULL_CASES = {
+    "full_bench_b64_greedy": ("GIT_BASE", ("bench", 1234, -5.0), 64, 1, O.GREEDY),                           # cfg2 exactly as benchmarked
+    "full_base_b64_greedy": ("GIT_BASE", dict(seed=1240, tie_output=False, successor=1.0), 64, 1, O.GREEDY),  # cfg2, perturbed LN affines / biases
+    "full_base_b64_beam4": ("GIT_BASE", dict(seed=1241, tie_output=False, successor=4.0, eos_bias=12.0), 64, 1, O.BEAM4),   # cfg3
+    "full_large_b32_greedy": ("GIT_LARGE", ("bench", 1242, -5.0), 32, 1, O.GREEDY),                          # cfg4 per GPU
+    "full_vatex_b16_greedy": ("GIT_BASE_VATEX", ("bench", 1243, -5.0), 16, 6, O.GREEDY),                     # cfg5
+}
+
+
+def full_case_inputs(name: str):
+    """weights: dict -> O.make_weights(**kw); ("bench", seed, eos_bias) -> the benchmark's own generator
+    generativeimage2text_amd.synthetic.random_state_dict (identity LayerNorms, N(0, .02) decoder: 19-step greedy
+    decodes with ~19 distinct ids per row, every row different) with frames = synthetic.random_frames(seed=0) --
+    for full_bench_b64_greedy that is bit for bit what `python bench.py` runs."""
+    cfg_name, wsrc, B, F, search = FULL_CASES[name]
+    cfg = O.CONFIGS[cfg_name]
+    if isinstance(wsrc, tuple):
+        from generativeimage2text_amd.configs import config_for_model
+        from generativeimage2text_amd.synthetic import random_state_dict
+        w = {k: v.float() for k, v in random_state_dict(config_for_model(cfg_name), seed=wsrc[1], eos_bias=wsrc[2]).items()}
+        w["textual.output.weight"] = w["textual.embedding.words.weight"]      # tied (decoder.py:503-505)
+        g = torch.Generator().manual_seed(0)                                    # synthetic.random_frames(seed=0), on the CPU
+        frames = [torch.randn(B, 3, cfg.image_size, cfg.image_size, generator=g) for _ in range(F)]
+        tie = True
+    else:
+        w = O.make_weights(cfg, **wsrc)
+        frames = O.make_images(cfg, B, F, seed=sum(map(ord, name)))
+        tie = wsrc.get("tie_output", True)
+    return cfg, w, frames, search, tie
+
+
+def run_full_case(name: str):
+    """Reference ids / log-probs at a BASELINE.json batch size + the oracle's per-step decision margins.
+    The full-recompute reference costs minutes per case here (B=64 greedy ~3 min, beam-4 ~10 min on 8 vCPUs)."""
+    cfg, w, frames, search, tie = full_case_inputs(name)
+    B, F = frames[0].shape[0], len(frames)
+    model = build_reference(cfg, w, search, tie)
+    t0 = time.time()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = model({"image": frames if F > 1 else frames[0]})
+    t_ref = time.time() - t0
+    t0 = time.time()
+    trace = []
+    with torch.no_grad():
+        ora = O.caption(cfg, w, frames, search, cached=True, trace=trace)
+        # teacher-forced logits of the first rows (bf16 logit-error yardstick of the GPU test)
+        g = torch.Generator().manual_seed(5)
+        tf_tokens = torch.randint(0, cfg.vocab, (B, 5), generator=g)
+        tf_tokens[:, 0] = cfg.sos
+        ora_tf = O.make_step(cfg, w, ora["visual_features"], cached=True)(tf_tokens)[:4]
+    t_ora = time.time() - t0
+    assert ora["predictions"].shape == ref["predictions"].shape, (name, ora["predictions"].shape, ref["predictions"].shape)
+    assert torch.equal(ora["predictions"], ref["predictions"]), (name, "oracle ids != reference ids")
+    lp_err = (ora["logprobs"] - ref["logprobs"]).abs().max().item()
+    assert lp_err < 2e-4, (name, "logprobs", lp_err)
+    margins = torch.stack(trace, dim=1)                                   # [B, decisions]
+    uniq = [len(set(r.tolist())) for r in ref["predictions"]]
+    print(f"[{name}] OK  ref {t_ref:.1f}s oracle {t_ora:.1f}s lp_err {lp_err:.2e} pred shape {tuple(ref['predictions'].shape)} "
+          f"distinct ids/row min {min(uniq)} median {sorted(uniq)[len(uniq)//2]}  margin median {margins[margins.isfinite()].median().item():.4f} "
+          f"row0 {ref['predictions'][0].tolist()}", flush=True)
+    np.savez_compressed(
+        os.path.join(GOLD, name + ".npz"),
+        config=cfg.name if cfg.name in O.CONFIGS else FULL_CASES[name][0], weights=repr(FULL_CASES[name][1]),
+        batch=B, frames=F, search=repr(dataclass_tuple(search)),
+        predictions=ref["predictions"].numpy(), logprobs=ref["logprobs"].numpy(),
+        step_margin=margins.numpy().astype(np.float32),      # oracle (== reference, asserted above) decision margins
+        tf_tokens=tf_tokens.numpy(), tf_logits=ora_tf[:, ::3].numpy().astype(np.float32),
+        tf_top2_margin=(ora_tf.topk(2).values[:, 0] - ora_tf.topk(2).values[:, 1]).numpy(),
     )
 
 
@@ -284,8 +371,11 @@ def main():
     if args.only in (None, "scripted"):
         run_scripted()
     for name in CASES:
-        if args.only in (None, name):
+        if args.only is None or name in args.only.split(","):
             run_case(name)
+    for name in FULL_CASES:          # minutes each: only on request (--only full / --only NAME[,NAME...])
+        if args.only is not None and (args.only == "full" or name in args.only.split(",")):
+            run_full_case(name)
 
 
 if __name__ == "__main__":

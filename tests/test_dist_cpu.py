@@ -1,12 +1,14 @@
-"""CPU, world_size 2 over gloo: the multi-GPU path (contiguous row shards per rank, one result
-gather to rank 0) is exercised without GPUs."""
+"""CPU, world_size 2: the multi-GPU path (contiguous row shards per rank, results delivered to rank 0) is exercised
+without GPUs -- through the TSV task's OWN code (run_tsv_inference), which must form the process group itself
+(gloo here, RCCL on a GPU box) or fall back to the reference's shard-file poll + concat (inference.py:214-225)."""
+import base64
+import json
 import os
 import socket
 import sys
 
 import pytest
 import torch
-import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import ROOT
@@ -20,33 +22,96 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tmpdir):
+N_ROWS = 11
+
+
+def _write_inputs(tmpdir, with_questions):
+    sys.path.insert(0, ROOT)
+    from generativeimage2text_amd import tsv_io
+    rows = [["key%d" % i, base64.b64encode(b"image-bytes-%03d" % i).decode()] for i in range(N_ROWS)]
+    tsv_io.tsv_writer(rows, os.path.join(tmpdir, "img.tsv"))
+    if with_questions:
+        q = [["key%d" % i, json.dumps([{"question": "q%d-%d" % (i, j), "question_id": 100 * i + j} for j in range(1 + i % 3)])]
+             for i in range(N_ROWS)]
+        tsv_io.tsv_writer(q, os.path.join(tmpdir, "q.tsv"))
+
+
+def _task_worker(rank, world, port, tmpdir, with_questions, rendezvous):
+    """What one rank of `torchrun`/`mpirun` runs: ONLY environment variables, no dist calls of its own."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    for k in ("MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    if rendezvous:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from generativeimage2text_amd import inference
+    assert not dist.is_initialized()
+    inference.run_tsv_inference(
+        os.path.join(tmpdir, "img.tsv"), os.path.join(tmpdir, "q.tsv") if with_questions else None,
+        os.path.join(tmpdir, "out.tsv"),
+        transform=lambda b: b.decode(),                                         # the "image" is its byte string
+        caption_batch=lambda imgs: ["cap<%s>" % im for im in imgs],
+        answer_questions=lambda img, qs: ["ans<%s|%s>" % (img, q) for q in qs],
+        batch_size=4, poll_s=0.05)
+    assert dist.is_initialized() == rendezvous
+    if rendezvous:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rendezvous", [True, False], ids=["gather", "shard-file-fallback"])
+@pytest.mark.parametrize("with_questions", [False, True], ids=["caption", "vqa"])
+def test_two_rank_tsv_task_delivers_all_rows_on_rank0(tmp_path, with_questions, rendezvous):
+    from generativeimage2text_amd import tsv_io, inference
+    _write_inputs(str(tmp_path), with_questions)
+    mp.spawn(_task_worker, args=(2, _free_port(), str(tmp_path), with_questions, rendezvous), nprocs=2, join=True)
+    out = str(tmp_path / "out.tsv")
+    rows = list(tsv_io.tsv_reader(out))
+    if with_questions:
+        want = []
+        for i in range(N_ROWS):
+            for j in range(1 + i % 3):
+                want.append([inference.json_dump({"answer": "ans<image-bytes-%03d|q%d-%d>" % (i, i, j), "question_id": 100 * i + j})])
+        assert rows == want
+        # the reference's convert_tsv_to_vqa_json reads exactly one column per row (inference.py:227-229)
+        assert [json.loads(s)["question_id"] for s, in tsv_io.tsv_reader(out)] == [json.loads(w[0])["question_id"] for w in want]
+    else:
+        assert rows == [["key%d" % i, inference.json_dump([{"caption": "cap<image-bytes-%03d>" % i}])] for i in range(N_ROWS)]
+    # both shard files exist, and the line index of the merged file addresses every row
+    for r in range(2):
+        assert os.path.isfile("%s.%d.2.tsv" % (out, r))
+    t = tsv_io.TSVFile(out)
+    assert len(t) == len(rows) and t[len(rows) - 1] == rows[-1]
+
+
+def _bench_gather_worker(rank, world, port, tmpdir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
+    import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from generativeimage2text_amd import inference
     import bench
-    n = 11
-    s, e = inference.shard_range(n, inference.get_mpi_rank(), inference.get_mpi_size())
-    rows = [["key%d" % i, "cap%d" % i] for i in range(s, e)]
-    allrows = inference._gather_rows(rows)
     # bench.py's token gather: every rank contributes [B, T] tokens + [B] logprobs
     toks = torch.full((3, 5), rank, dtype=torch.int64)
     lps = torch.full((3,), float(rank))
     g_t, g_l = bench.gather_results(toks, lps)
     if rank == 0:
-        assert [r[0] for r in allrows] == ["key%d" % i for i in range(n)]
         assert g_t.shape == (world * 3, 5) and g_t[3:].eq(1).all() and g_t[:3].eq(0).all()
         assert g_l.tolist() == [0.0] * 3 + [1.0] * 3
         open(os.path.join(tmpdir, "ok"), "w").write("1")
     else:
-        assert allrows is None
+        assert g_t is None
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_and_gather(tmp_path):
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+def test_two_rank_bench_gather(tmp_path):
+    mp.spawn(_bench_gather_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def test_json_dump_is_the_reference_format():
+    from generativeimage2text_amd import inference
+    assert inference.json_dump({"question_id": 7, "answer": "a b"}) == '{"answer":"a b","question_id":7}'
+    assert inference.json_dump([{"caption": "x"}]) == '[{"caption":"x"}]'

@@ -142,39 +142,118 @@ def test_attention_softmax_rescale_branch():
         assert (out_b - ref_b).abs().max().item() < 5e-2, impl
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 768, 768), (64, 2304, 768), (64, 30522, 768), (256, 3072, 768),
-                                   (5, 130, 128), (100, 1002, 96), (64, 768, 3072)])
-@pytest.mark.parametrize("NT", [1, 2])
+# ---- decode-step GEMM chain (kernels_dgemm.hip) ---------------------------------------------------------------
+def _bf16_round(x):
+    return x.bfloat16().float()
+
+
+def _fold(W, bias, gamma, beta):
+    """What gitmi_finalize_weights prepares for a GEMM behind a LayerNorm: W' = bf16(W . gamma), beta W^T + b, colsum(W')."""
+    Wf = _bf16_round(W * gamma[None, :])
+    return Wf.bfloat16(), (bias.double() + W.double() @ beta.double()).float(), Wf.double().sum(1).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 2304, 768), (64, 3072, 768), (256, 3072, 768), (5, 130, 128), (33, 1002, 96),
+                                   (17, 512, 128), (100, 2304, 768)])
 @pytest.mark.parametrize("act", [0, 2])
-def test_gemm_skinny(M, N, K, NT, act):
+@pytest.mark.parametrize("fold", [False, True])
+def test_dgemm_qkv_ffn1_form(M, N, K, act, fold):
+    """QKV / FFN1 form: plain, and with the LayerNorm in front folded into weights + epilogue (stats from strip partials)."""
     from generativeimage2text_amd import engine as E
-    A = _rand(M, K, seed=21).bfloat16()
-    W = _rand(N, K, seed=22, scale=K ** -0.5).bfloat16()
+    W = _rand(N, K, seed=22, scale=K ** -0.5)
     bias = _rand(N, seed=23)
-    res = _rand(M, N, seed=24)
-    ref = _act(A.double() @ W.double().t() + bias.double(), act) + res.double()
-    out = E.op_gemm_skinny(A.cuda(), W.cuda(), bias.cuda(), res.cuda(), act, torch.float32, NT).cpu().double()
-    assert (out - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
-    out_b = E.op_gemm_skinny(A.cuda(), W.cuda(), bias.cuda(), None, act, torch.bfloat16, NT).cpu().double()
-    ref_b = _act(A.double() @ W.double().t() + bias.double(), act)
-    assert (out_b - ref_b).abs().max().item() < 1e-2 * max(1.0, ref_b.abs().max().item())
+    if not fold:
+        A = _rand(M, K, seed=21).bfloat16()
+        ref = _act(A.double() @ _bf16_round(W).double().t() + bias.double(), act)
+        out = E.op_dgemm(A.cuda(), W.bfloat16().cuda(), bias.cuda(), act=act).cpu().double()
+        assert (out - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
+        return
+    if K % 16:
+        pytest.skip("strip partials need K % 16 == 0")
+    x = _rand(M, K, seed=21, scale=1.3) + 0.2                      # raw rows: non-zero mean, non-unit variance
+    gamma, beta = 1 + _rand(K, seed=24, scale=0.1), _rand(K, seed=25, scale=0.1)
+    ref = _act(torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-12) @ W.double().t()
+               + bias.double(), act)
+    Wf, bf, cs = _fold(W, bias, gamma, beta)
+    stats = E.strip_stats(x.cuda())
+    out = E.op_dgemm(x.bfloat16().cuda(), Wf.cuda(), bf.cuda(), cs.cuda(), stats, 1e-12, act).cpu().double()
+    # bf16 operands on both sides: error ~ 2^-8 relative to the output scale
+    assert (out - ref).abs().max().item() < 2.5e-2 * max(1.0, ref.abs().max().item())
+    # against the same arithmetic in fp64 (bf16 operands as the kernel sees them): only fp32 summation-order error + bf16 output rounding
+    mean, var = x.double().mean(1, keepdim=True), x.double().var(1, unbiased=False, keepdim=True)
+    exact = _act((x.bfloat16().double() @ Wf.double().t() - mean * cs.double()) / torch.sqrt(var + 1e-12) + bf.double(), act)
+    assert (out - exact).abs().max().item() < 6e-3 * max(1.0, exact.abs().max().item())
 
 
-@pytest.mark.parametrize("M,N,K,S", [(64, 768, 768, 3), (64, 768, 3072, 4), (256, 768, 3072, 2), (7, 128, 512, 4),
-                                     (33, 128, 128, 2), (64, 768, 768, 8)])
-def test_gemm_splitk_layernorm(M, N, K, S):
+@pytest.mark.parametrize("M,N,K", [(64, 768, 768), (64, 768, 3072), (256, 768, 3072), (7, 128, 512), (33, 128, 128), (100, 768, 768)])
+@pytest.mark.parametrize("ln_res", [False, True])
+def test_dgemm_residual_stats_form(M, N, K, ln_res):
+    """N = hidden form: x = A W^T + bias + residual (the hidden state, or LayerNorm(previous raw x) rebuilt from its
+    strip partials), plus the strip partials of x; fixed summation order => bitwise reproducible."""
     from generativeimage2text_amd import engine as E
     A = _rand(M, K, seed=31).bfloat16()
     W = _rand(N, K, seed=32, scale=K ** -0.5).bfloat16()
-    bias, res = _rand(N, seed=33), _rand(M, N, seed=34)
+    bias, xprev = _rand(N, seed=33), _rand(M, N, seed=34, scale=1.2) + 0.1
     g, b = 1 + _rand(N, seed=35, scale=0.1), _rand(N, seed=36, scale=0.1)
-    pre = A.double() @ W.double().t() + bias.double() + res.double()
-    ref = torch.nn.functional.layer_norm(pre, (N,), g.double(), b.double(), 1e-12)
-    y_f, y_t = E.op_gemm_splitk_ln(A.cuda(), W.cuda(), bias.cuda(), res.cuda(), g.cuda(), b.cuda(), 1e-12, S)
-    assert (y_f.cpu().double() - ref).abs().max().item() < 3e-4
-    assert (y_t.cpu().double() - ref).abs().max().item() < 3e-2
-    y_f2, _ = E.op_gemm_splitk_ln(A.cuda(), W.cuda(), bias.cuda(), res.cuda(), g.cuda(), b.cuda(), 1e-12, S)
-    assert torch.equal(y_f, y_f2)            # fixed summation order: bitwise reproducible
+    res = torch.nn.functional.layer_norm(xprev.double(), (N,), g.double(), b.double(), 1e-12) if ln_res else xprev.double()
+    ref = A.double() @ W.double().t() + bias.double() + res
+    args = (A.cuda(), W.cuda(), bias.cuda(), xprev.cuda())
+    kw = dict(res_stats=E.strip_stats(xprev.cuda()), res_gamma=g.cuda(), res_beta=b.cuda()) if ln_res else {}
+    x, xb, st = E.op_dgemm_res(*args, **kw)
+    assert (x.cpu().double() - ref).abs().max().item() < 3e-4 * max(1.0, ref.abs().max().item())
+    assert (xb.cpu().double() - ref).abs().max().item() < 1.2e-2 * max(1.0, ref.abs().max().item())
+    want = E.strip_stats(x).cpu()
+    assert (st.cpu() - want).abs().max().item() < 1e-3 * max(1.0, want.abs().max().item())
+    x2, _, st2 = E.op_dgemm_res(*args, **kw)
+    assert torch.equal(x, x2) and torch.equal(st, st2)
+    # a row's result does not depend on its batch-mates
+    x3, _, _ = E.op_dgemm_res(A[:3].contiguous().cuda(), W.cuda(), bias.cuda(), xprev[:3].contiguous().cuda(),
+                              **({k: (v[:, :3].contiguous() if k == "res_stats" else v) for k, v in kw.items()}))
+    assert torch.equal(x3, x[:3])
+
+
+@pytest.mark.parametrize("M,V,K,mtop", [(64, 30522, 768, 1), (64, 30522, 768, 8), (256, 30522, 768, 8), (5, 1000, 128, 4),
+                                        (33, 1000, 128, 2), (16, 5003, 256, 16)])
+@pytest.mark.parametrize("fold", [False, True])
+def test_vocab_head_fused_topm(M, V, K, mtop, fold):
+    """Vocabulary head with running top-M / log-sum-exp: merging the per-workgroup lists must give exactly the top-M
+    and the log-softmax of the logits the same kernel materialises on request; those logits against fp64."""
+    from generativeimage2text_amd import engine as E
+    W = _rand(V, K, seed=41, scale=K ** -0.5 * 2.0)
+    bias = _rand(V, seed=42, scale=0.5)
+    x = _rand(M, K, seed=43, scale=1.1) + 0.15
+    sup = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(44), dtype=torch.int32)
+    if fold:
+        gamma, beta = 1 + _rand(K, seed=45, scale=0.1), _rand(K, seed=46, scale=0.1)
+        ref = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-12) @ W.double().t() + bias.double()
+        Wf, bf, cs = _fold(W, bias, gamma, beta)
+        pv, pi, pl, lg = E.op_vocab_topm(x.bfloat16().cuda(), Wf.cuda(), bf.cuda(), mtop, 128, cs.cuda(), E.strip_stats(x.cuda()),
+                                         1e-12, sup.cuda(), True)
+    else:
+        ref = x.bfloat16().double() @ _bf16_round(W).double().t() + bias.double()
+        pv, pi, pl, lg = E.op_vocab_topm(x.bfloat16().cuda(), W.bfloat16().cuda(), bias.cuda(), mtop, 128, suppress_tok=sup.cuda(),
+                                         want_logits=True)
+    lg = lg.cpu()
+    tol = (2.5e-2 if fold else 2e-4) * max(1.0, ref.abs().max().item())
+    assert (lg.double() - ref).abs().max().item() < tol
+    # the lists: built from the suppressed logits (decoder.py:330)
+    sl = lg.clone()
+    sl[torch.arange(M), sup.long()] = -10000.0
+    pv, pi, pl = pv.cpu(), pi.cpu().long(), pl.cpu()
+    nparts = pv.shape[1]
+    for p in range(nparts):
+        cols = sl[:, p * 128:(p + 1) * 128]
+        k = min(mtop, cols.shape[1])
+        tv, ti = cols.topk(k, dim=1)
+        assert torch.equal(pv[:, p, :k], tv), p
+        # ties may be broken either way only if values are equal: compare through the values the indices point at
+        assert torch.equal(torch.gather(sl, 1, pi[:, p, :k]), tv), p
+        assert torch.allclose(pl[:, p, 0], cols.max(1).values)
+        assert torch.allclose(pl[:, p, 1], torch.exp(cols - cols.max(1, keepdim=True).values).sum(1), rtol=2e-5)
+    lse = torch.logsumexp(sl.double(), 1)
+    got = torch.log((pl[:, :, 1].double() * torch.exp(pl[:, :, 0].double() - pl[:, :, 0].double().max(1, keepdim=True).values)).sum(1)) \
+        + pl[:, :, 0].double().max(1).values
+    assert (got - lse).abs().max().item() < 1e-4
 
 
 @pytest.mark.parametrize("B,H,N_img,pos,beams", [(2, 2, 17, 0, 1), (3, 12, 197, 5, 1), (2, 12, 197, 7, 4), (1, 2, 300, 3, 3),

@@ -2,11 +2,14 @@
 were generated from the real reference (oracle/make_golden.py).
 
 Tolerances (stated per north_star):
-  f32 engine mode  : tokens bit-identical; features/logits |err| <= 2e-3 (fp32 summation order only)
-  bf16 engine mode : logits within 1e-3 * 30 of the fp32 reference relative to the logit range
-                     (bf16 has 8 mantissa bits; see DESIGN.md "parity budget"), features <= 0.12 abs on
-                     unit-variance LayerNorm outputs, and the teacher-forced argmax must match wherever
-                     the reference's top-1/top-2 margin exceeds 4x the measured logit error.
+  f32 engine mode  : tokens bit-identical to the reference; features / logits / log-probs |err| <= 1e-4
+                     (measured ~3e-6: fp32 summation order only)
+  bf16 engine mode : features <= 0.05 abs on unit-variance LayerNorm outputs (measured ~0.02), teacher-forced logits
+                     within 8e-3 of the logit range (measured ~3e-3; bf16 carries 2^-9 per operand through 18 layers,
+                     DESIGN.md "parity budget"), teacher-forced argmax identical wherever the reference's top-1/top-2
+                     margin exceeds 4x the measured error, and END-TO-END ids compared on EVERY row: a row may leave
+                     the reference's ids only at a step whose fp32 decision margin (golden `step_margin`) is below
+                     4x the measured bf16 logit error -- a genuine near-tie; rows without such a step must be identical.
 """
 import numpy as np
 import pytest
@@ -16,12 +19,14 @@ from conftest import golden_case, load_golden
 
 pytestmark = pytest.mark.gpu
 
-TINY_CASES = ["tiny_greedy", "tiny_greedy_untied", "tiny_beam4", "tiny_beam4_noeos", "tiny_beam3_pn3",
-              "tiny_ar_beam3", "tiny_prefix_greedy", "tiny_prefix_beam4", "tiny_video_greedy",
-              "tiny_video_beam4", "tinyl_greedy",
+TINY_CASES = ["tiny_greedy_early_return", "tiny_greedy_untied", "tiny_greedy_long", "tiny_beam4", "tiny_beam4_noeos",
+              "tiny_beam4_early_done", "tiny_beam3_pn3", "tiny_ar_beam3", "tiny_prefix_greedy", "tiny_prefix_beam4",
+              "tiny_video_greedy", "tiny_video_beam4", "tinyl_greedy",
               "tiny_varres_up", "tiny_varres_down_beam4", "tiny_varres_prefix", "tinyl_varres"]
 BIG_CASES = ["base_greedy", "base_greedy_eos", "base_beam4", "base_prefix_beam4", "large_greedy", "vatex_greedy",
              "vqa_base_480x640"]
+FULL_CASES = ["full_bench_b64_greedy", "full_base_b64_greedy", "full_base_b64_beam4", "full_large_b32_greedy",
+              "full_vatex_b16_greedy"]
 
 
 def make_engine(cfg, w, precision, B, search, frames=1, T=None, max_image_hw=None):
@@ -71,13 +76,13 @@ def check_f32(name):
     g, cfg, feats, logits, preds, lps = run_case(name, "f32")
     big = cfg.vocab > 5000
     fs = feats[:, ::7, ::5] if big else feats
-    assert np.abs(fs.numpy() - g["feat_sample"]).max() < 2e-3
+    assert np.abs(fs.numpy() - g["feat_sample"]).max() < 1e-4
     ls = logits[:, ::3] if big else logits
-    assert np.abs(ls.numpy() - g["tf_logits"]).max() < 2e-3
+    assert np.abs(ls.numpy() - g["tf_logits"]).max() < 1e-4
     assert np.array_equal(logits.argmax(-1).numpy(), g["tf_argmax"])
     assert preds.shape == g["predictions"].shape, (preds.shape, g["predictions"].shape)
     assert np.array_equal(preds.numpy(), g["predictions"]), (preds, g["predictions"])
-    assert np.allclose(lps.numpy(), g["logprobs"], atol=2e-3), (lps, g["logprobs"])
+    assert np.allclose(lps.numpy(), g["logprobs"], atol=1e-4), (lps, g["logprobs"])
 
 
 def check_bf16(name):
@@ -85,18 +90,31 @@ def check_bf16(name):
     big = cfg.vocab > 5000
     fs = feats[:, ::7, ::5] if big else feats
     ferr = np.abs(fs.numpy() - g["feat_sample"]).max()
-    assert ferr < 0.12, ferr
+    assert ferr < 0.05, ferr
     ls = logits[:, ::3] if big else logits
     ref = g["tf_logits"]
     lerr = np.abs(ls.numpy() - ref).max()
     span = ref.max() - ref.min()
-    assert lerr < 3e-2 * span, (lerr, span)
+    assert lerr < 8e-3 * span, (lerr, span)
     # token identity wherever the reference's own margin is resolvable at bf16 precision
     am = logits.argmax(-1).numpy()
     for r in range(am.shape[0]):
         if g["tf_top2_margin"][r] > 4 * lerr:
             assert am[r] == g["tf_argmax"][r]
-    assert preds.shape[0] == g["predictions"].shape[0]
+    # end-to-end ids, every row
+    ref_p = g["predictions"]
+    kind = eval(str(g["search"]), {"__builtins__": {}}, {})[0]
+    if ref_p.shape[1] <= 1 and kind == "greedy":                        # first-step early return (decoder.py:279-291)
+        if preds.shape == ref_p.shape:
+            assert np.array_equal(preds.numpy(), ref_p)
+        return
+    from generativeimage2text_amd.parity import ids_parity
+    kind, _, k, _, _ = eval(str(g["search"]), {"__builtins__": {}}, {})
+    chained = not (kind == "greedy" and k == 1)
+    # golden predictions of prefixed cases have the prefix stripped (decoder.py:1004-1006): decision s wrote position s
+    stats = ids_parity(preds.numpy(), ref_p, g["step_margin"], 4 * lerr * (2 if chained else 1), chained,
+                       first_decision_pos=0 if g["prefix"].size else 1)
+    print(name, stats)
 
 
 @pytest.mark.parametrize("name", TINY_CASES)
@@ -119,42 +137,6 @@ def test_full_size_bf16_within_tolerance(name):
     check_bf16(name)
 
 
-def test_bf16_greedy_diverges_from_reference_only_at_near_ties():
-    """End-to-end greedy ids in bf16 vs the reference ids: rows must agree token for token until a step
-    where the fp32 top-1/top-2 margin is within 4x the bf16 logit error (a genuine near-tie)."""
-    g, cfg, w, frames, search, prefix = golden_case("base_greedy")
-    ref = g["predictions"]
-    B = ref.shape[0]
-    dev = [f.cuda() for f in frames]
-    eb = make_engine(cfg, w, "bf16", B, search)
-    tokens, _, info = eb.generate(dev, search_struct(search))
-    got = tokens[:, :info.tolist()[0]].cpu().numpy()
-    ef = make_engine(cfg, w, "f32", B, search)
-    ef.encode(dev, return_features=False)
-    eb.encode(dev, return_features=False)
-    n_equal = 0
-    for r in range(B):
-        L = min(got.shape[1], ref.shape[1])
-        diff = [t for t in range(L) if got[r, t] != ref[r, t]]
-        if not diff:
-            n_equal += 1
-            continue
-        t = diff[0]
-        # logits of the step that produced position t, teacher-forced on the agreed prefix (all rows get it)
-        pfx = torch.from_numpy(np.repeat(ref[r:r + 1, :t], B, axis=0))
-        lf = ef.step_logits(pfx)[r].cpu()
-        lb = eb.step_logits(pfx)[r].cpu()
-        err = (lf - lb).abs().max().item()
-        lf[ref[r, t - 1]] = -1e4                       # decoder.py:330 (no immediate repeat)
-        top2 = lf.topk(2).values
-        margin = (top2[0] - top2[1]).item()
-        assert margin <= 4 * err, (r, t, margin, err)
-    assert n_equal >= 1
-    eb.close()
-    ef.close()
-
-
-# ---- the search seam with scripted logits (no model): device search == reference search ----------
 def _scripted_module():
     import importlib.util, os
     from conftest import ROOT
@@ -167,6 +149,40 @@ def _scripted_module():
 MG = _scripted_module()
 
 
+@pytest.mark.parametrize("name", FULL_CASES)
+def test_full_batch_ids_against_reference(name):
+    """BASELINE.json configs at their full batch sizes (cfg2 B=64 greedy as benchmarked and with perturbed affines, cfg3
+    B=64 beam 4, cfg4 GIT_LARGE B=32, cfg5 VATEX 6 frames B=16): reference ids from tests/golden/full_*.npz.
+    f32 mode: bit-identical ids on every row.  bf16 mode (the benchmarked one): every row compared, divergence only at
+    a near-tie of the fp32 reference (generativeimage2text_amd.parity)."""
+    from generativeimage2text_amd.parity import ids_parity
+    g = load_golden(name)
+    cfg, w, frames, search, _ = MG.full_case_inputs(name)
+    B, F = frames[0].shape[0], len(frames)
+    dev = [f.cuda() for f in frames]
+    ref_p, ref_l = g["predictions"], g["logprobs"]
+    chained = search.kind != "greedy"
+    tf = torch.from_numpy(g["tf_tokens"])
+    for prec in ("f32", "bf16"):
+        eng = make_engine(cfg, w, prec, B, search, frames=F)
+        tokens, logprobs, info = eng.generate(dev, search_struct(search))
+        preds, lps = format_like_reference(search, tokens, logprobs, info, None)
+        logits = eng.step_logits(tf)[:4, ::3].cpu().numpy()
+        eng.close()
+        lerr = float(np.abs(logits - g["tf_logits"]).max())
+        if prec == "f32":
+            assert lerr < 1e-4, lerr
+            assert preds.shape == ref_p.shape and np.array_equal(preds.numpy(), ref_p)
+            assert np.allclose(lps.numpy(), ref_l, atol=1e-4)
+        else:
+            span = float(g["tf_logits"].max() - g["tf_logits"].min())
+            assert lerr < 8e-3 * span, (lerr, span)
+            stats = ids_parity(preds.numpy(), ref_p, g["step_margin"], 4 * lerr * (2 if chained else 1), chained)
+            print(name, prec, "logit err %.4f of span %.2f" % (lerr, span), stats)
+            assert stats["identical"] >= stats["safe_rows"]
+
+
+# ---- the search seam with scripted logits (no model): device search == reference search ----------
 @pytest.mark.parametrize("name", sorted(MG.SCRIPTED))
 def test_device_search_scripted(name):
     from generativeimage2text_amd.engine import Engine
@@ -411,8 +427,9 @@ def test_task_function_vqa_tsv_variable_resolution(tmp_path, monkeypatch):
     out = str(tmp_path / "out.tsv")
     I.test_git_inference_single_tsv(str(tmp_path / "img.tsv"), "GIT_BASE_VQAv2", str(tmp_path / "q.tsv"), out, checkpoint=w,
                                     precision="f32")
-    got = [(r[0], json.loads(r[1])["question_id"], json.loads(r[1])["answer"]) for r in tsv_io.tsv_reader(out)]
-    assert got == want, (got, want)
+    # one-column rows json_dump({"answer", "question_id"}) (inference.py:199), questions of an image answered in ONE engine call
+    got = [(json.loads(s)["question_id"], json.loads(s)["answer"]) for s, in tsv_io.tsv_reader(out)]
+    assert got == [(qid, ans) for _, qid, ans in want], (got, want)
 
 
 @pytest.mark.parametrize("kind", ["greedy", "beam"])
@@ -437,3 +454,112 @@ def test_long_step_budget_polling_path(kind):
             assert torch.allclose(lps, ref["logprobs"], atol=2e-3)
             assert info.tolist()[2] < 59          # stopped early: fewer decode steps than the budget
         eng.close()
+
+
+# ---- batched VQA: ragged per-sentence prefixes in one call == one reference call per question --------------------
+@pytest.mark.parametrize("kind", ["greedy", "beam", "ar_beam"])
+def test_ragged_prefixes_equal_per_question_reference_calls(kind):
+    """The reference answers one question per model call (decoder.py:984-989; inference.py:172-199).  The engine runs
+    questions of different lengths about several images in one call (image K/V shared by the questions of an image);
+    in f32 mode every sentence must get bit for bit what its own batch-1 call returns, incl. early ends."""
+    from oracle import git_oracle as O
+    cfg = O.CONFIGS["TINY"]
+    w = O.make_weights(cfg, seed=51, tie_output=False, successor=2.0, eos_bias=1.0)
+    frames = O.make_images(cfg, 3, 1, seed=9)
+    search = {"greedy": O.SearchConfig("greedy", 18, 1, 1), "beam": O.SearchConfig("beam", 18, 4, 2, 0.6),
+              "ar_beam": O.SearchConfig("greedy", 18, 3, 2)}[kind]
+    prefixes = [[101, 7, 44], [101], [101, 300, 2, 9, 512, 77], [101, 5], [101, 7, 44, 13, 8], [101, 640, 3, 3, 21, 90, 14, 2]]
+    image_of = [0, 0, 1, 2, 2, 1]
+    want = []
+    with torch.no_grad():
+        for p, im in zip(prefixes, image_of):
+            ref = O.caption(cfg, w, [frames[0][im:im + 1]], search, prefix=torch.tensor([p]), cached=True)
+            want.append((ref["predictions"][0].tolist(), float(ref["logprobs"].flatten()[0])))
+    eng = make_engine(cfg, w, "f32", 8, search)
+    dev = [f.cuda() for f in frames]
+    for graph in (True, False):
+        eng.set_graph(graph)
+        tokens, logprobs, sent, info = eng.generate_prefixed(dev, search_struct(search), prefixes, image_of)
+        tokens, logprobs, sent = tokens.cpu(), logprobs.cpu(), sent.cpu()
+        for q, p in enumerate(prefixes):
+            P, (L, early) = len(p), sent[q].tolist()
+            if search.kind == "greedy":
+                got = (tokens[q, P:P + 1] if early else tokens[q, :L])[P:].tolist()
+            else:
+                got = tokens[q, P:].tolist()
+            assert got == want[q][0], (kind, q, got, want[q][0])
+            assert abs(float(logprobs[q]) - want[q][1]) < 1e-4, (kind, q)
+    # bf16 mode runs the same call (fused vocabulary head, folded LayerNorms): shapes / termination sane
+    eb = make_engine(cfg, w, "bf16", 8, search)
+    tb, lb, sb, _ = eb.generate_prefixed(dev, search_struct(search), prefixes, image_of)
+    for q, p in enumerate(prefixes):
+        assert tb[q, :len(p)].tolist() == p
+    assert torch.isfinite(lb).all()
+    eng.close()
+    eb.close()
+
+
+def test_model_answer_matches_single_prefix_calls():
+    """CaptioningModel.answer(image, [prefixes]) == [model({'image', 'prefix'}) per prefix] (the reference loop)."""
+    from oracle import git_oracle as O
+    from generativeimage2text_amd.model import CaptioningModel, GeneratorWithBeamSearch
+    cfg = O.CONFIGS["TINY"]
+    w = O.make_weights(cfg, seed=52, tie_output=False, successor=2.0, eos_bias=1.5)
+    img = O.make_images(cfg, 1, 1, seed=4)[0].cuda()
+    dec = GeneratorWithBeamSearch(eos_index=cfg.eos, max_steps=16, beam_size=4, length_penalty=0.6)
+    model = CaptioningModel(cfg, dec, precision="f32", max_batch=4)
+    model.load_state_dict(w)
+    prefixes = [[101, 9, 8, 7], [101, 400], [101, 3, 3, 3, 3, 3, 3]]
+    batched = model.answer(img, prefixes)
+    for p, got in zip(prefixes, batched):
+        single = model({"image": img, "prefix": torch.tensor([p]).cuda()})["predictions"][0].tolist()
+        assert got == single
+
+
+def test_video_model_with_bare_tensor_skips_temporal_embedding():
+    """decoder.py:845-857: img_temperal_embedding is added only when batch['image'] is a LIST of frames."""
+    from oracle import git_oracle as O
+    from generativeimage2text_amd.model import CaptioningModel, AutoRegressiveBeamSearch
+    cfg = O.CONFIGS["TINY_VIDEO"]
+    w = O.make_weights(cfg, seed=53, tie_output=False, successor=2.0)
+    frames = O.make_images(cfg, 2, 1, seed=6)
+    dec = AutoRegressiveBeamSearch(eos_index=cfg.eos, max_steps=12, beam_size=1, per_node_beam_size=1, fix_missing_prefix=True)
+    model = CaptioningModel(cfg, dec, precision="f32", max_batch=2)
+    model.load_state_dict(w)
+    search = O.SearchConfig("greedy", 12, 1, 1)
+    with torch.no_grad():
+        ref_tensor = O.caption(cfg, w, frames, search, cached=True, feats=O.visual_features(cfg, w, frames, as_list=False))
+        ref_list = O.caption(cfg, w, frames, search, cached=True)
+    got_tensor = model({"image": frames[0].cuda()})["predictions"].cpu()
+    got_list = model({"image": [frames[0].cuda()]})["predictions"].cpu()
+    assert torch.equal(got_tensor, ref_tensor["predictions"])
+    assert torch.equal(got_list, ref_list["predictions"])
+    assert not torch.equal(ref_tensor["predictions"], ref_list["predictions"])      # the embedding matters for this seed
+
+
+def test_single_rank_rccl_gather_path(tmp_path):
+    """The RCCL ("nccl") result gather, executed for real on one rank: bench.gather_results with an initialised
+    1-rank group is a no-op by design, so the collective itself is driven directly with the same packing."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29543', RANK='0', WORLD_SIZE='1')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "toks = torch.arange(64 * 20, device='cuda').reshape(64, 20)\n"
+        "lps = torch.linspace(-3, 0, 64, device='cuda')\n"
+        "packed = torch.cat([toks, lps.view(torch.int32).to(torch.int64)[:, None]], 1).contiguous()\n"
+        "out = [torch.empty_like(packed)]\n"
+        "dist.gather(packed, out, dst=0)\n"
+        "dist.barrier(); torch.cuda.synchronize()\n"
+        "assert torch.equal(out[0], packed)\n"
+        "rows = [['k%d' % i, 'c%d' % i] for i in range(5)]\n"
+        "got = [None]\n"
+        "dist.gather_object(rows, got, dst=0)\n"
+        "assert got[0] == rows\n"
+        "dist.destroy_process_group()\n"
+        "print('RCCL-1-RANK-OK')\n")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert "RCCL-1-RANK-OK" in r.stdout, r.stdout + r.stderr

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(engine.EXPORTED_SYMBOLS) == declared
-    assert lib.gitmi_abi_version() == 2
+    assert lib.gitmi_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
