@@ -13,8 +13,10 @@ collective on the data path ("scaling": "weak").
 
 Rank 0 prints ONE JSON line.  `value` is whole-job captions/s.  `roofline` describes the dominant
 kernel (the bf16 MFMA GEMM inside the image encoder, MFMA-bound) from a separate HIP-event-instrumented
-pass of the same workload; `roofline_decode` the HBM-bound decode step; `cpu_baseline` times the CPU
-oracle (a port of the reference algorithm, full recompute like the reference) on a bounded sample.
+pass of the same workload; `roofline_decode` the HBM-bound decode step (hipGraph replays, events around the
+decode graph); `parity` compares the generated ids with the reference's ids for this very workload
+(tests/golden/full_bench_b64_greedy.npz); `cpu_baseline` times the CPU oracle (a port of the reference
+algorithm, full recompute like the reference) on a bounded sample.
 """
 from __future__ import annotations
 
@@ -56,7 +58,8 @@ def cpu_baseline(sample_batch: int, max_steps: int, threads: int = 0):
     """Reference algorithm on the host cores: oracle (fp32, full recompute exactly like the reference's
     CaptioningModel.infer as shipped), greedy, GIT_BASE.  Bounded sample.  torch's CPU kernels
     oversubscribe badly on a 256-thread host (measured 85x slower than 16 threads), so the thread
-    count is capped and reported."""
+    count is capped and reported; `python bench.py --cpu-sweep` measures other thread counts
+    (profiles/r02_cpu_sweep.json).  Also reports the image-encoder / decode split of the sample."""
     from oracle import git_oracle as O
     cores = os.cpu_count() or 1
     threads = threads or min(cores, 16)
@@ -67,37 +70,82 @@ def cpu_baseline(sample_batch: int, max_steps: int, threads: int = 0):
     search = O.SearchConfig("greedy", max_steps, 1, 1)
     t0 = time.time()
     with torch.no_grad():
-        out = O.caption(cfg, w, frames, search, cached=False)
+        feats = O.visual_features(cfg, w, frames)
+        t1 = time.time()
+        out = O.caption(cfg, w, frames, search, cached=False, feats=feats)
     dt = time.time() - t0
     steps = out["predictions"].shape[1] - 1
     return {"value": round(sample_batch / dt, 4), "unit": "captions/s", "cores": threads,
-            "kind": "port", "host_cpus": cores,
+            "kind": "port", "host_cpus": cores, "vit_s": round(t1 - t0, 2), "decode_s": round(dt - (t1 - t0), 2),
             "sample": f"GIT_BASE fp32 bs={sample_batch} greedy {steps} decode steps, full recompute per step "
                       f"(reference semantics), {dt:.1f}s wall on {threads} threads"}
 
 
-def pmc_traffic(kernel_substr: str):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/*pmc_summary.tsv; FETCH_SIZE and WRITE_SIZE collected in separate passes, KiB per dispatch;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).
-    PMC counters cannot be collected from inside this process, so the figure is the profiled one."""
+def csrc_sha() -> str:
+    import glob, hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "generativeimage2text_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "generativeimage2text_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(kernel_substrs):
+    """Counter figures of the named kernels from the newest committed rocprofv3 --pmc summary
+    (profiles/*pmc_summary.tsv, tools/gpu_pmc.sh + tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE / SQ / GRBM groups in
+    separate passes; HBM bytes = 2*FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).
+    PMC counters cannot be collected from inside this process, so the figures are the profiled ones; `stale` says
+    whether the kernels' sources changed since that profile (hash of csrc/ recorded in its header)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.tsv")))
     if not files:
         return None
-    rows = [l.rstrip("\n").split("\t") for l in open(files[-1]) if not l.startswith("#")]
+    lines = open(files[-1]).read().splitlines()
+    sha = next((l.split("=", 1)[1].strip() for l in lines if l.startswith("# csrc_sha=")), None)
+    rows = [l.split("\t") for l in lines if not l.startswith("#")]
     hdr = rows[0]
-    if "FETCH_SIZE" not in hdr or "WRITE_SIZE" not in hdr:
+    out = {"source": os.path.relpath(files[-1], ROOT), "stale": sha != csrc_sha()}
+    for key, sub in kernel_substrs.items():
+        acc, n = {}, 0.0
+        for r in rows[1:]:
+            if sub not in r[0]:
+                continue
+            d = {h: float(v) for h, v in zip(hdr[1:], r[1:]) if v != "-"}
+            wgt = d.get("DISPATCHES", 1.0)
+            n += wgt
+            for h in ("HBM_BYTES", "MFMA_UTIL_PCT", "L2_HIT_PCT"):
+                if h in d:
+                    acc[h] = acc.get(h, 0.0) + wgt * d[h]
+        if n:
+            out[key] = {h.lower(): round(v / n, 2) for h, v in acc.items()}
+    return out
+
+
+def bench_parity(eng, tokens, info, args):
+    """Ids of the timed workload against the REFERENCE's ids for exactly this workload (tests/golden/
+    full_bench_b64_greedy.npz: GIT_BASE, synthetic.random_state_dict(seed=1234), random_frames(seed=0), B=64 greedy
+    max_len=20, frozen by oracle/make_golden.py).  Rows may leave the reference only at a near-tie of its fp32 logits
+    (generativeimage2text_amd.parity); the counts go into the bench line."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "full_bench_b64_greedy.npz")
+    if not (args.model == "GIT_BASE" and args.batch == 64 and args.search == "greedy" and args.max_steps == 20
+            and args.frames == 1 and os.path.isfile(path)):
         return None
-    fi, wi = hdr.index("FETCH_SIZE"), hdr.index("WRITE_SIZE")
-    vals = []
-    for r in rows[1:]:
-        if kernel_substr in r[0] and r[fi] != "-" and r[wi] != "-":
-            vals.append((2.0 * float(r[fi]) + float(r[wi])) * 1024.0)
-    if not vals:
-        return None
-    return {"bytes_per_launch": sum(vals) / len(vals), "source": os.path.relpath(files[-1], ROOT),
-            "note": "2*FETCH_SIZE + WRITE_SIZE per dispatch, averaged over the profiled launches of this kernel"}
+    from generativeimage2text_amd.parity import ids_parity
+    g = np.load(path)
+    seq_len = int(info.tolist()[0])
+    got = tokens[:, :seq_len].cpu().numpy()
+    lg = eng.step_logits(torch.from_numpy(g["tf_tokens"]))[:4, ::3].float().cpu().numpy()
+    lerr = float(np.abs(lg - g["tf_logits"]).max())
+    try:
+        st = ids_parity(got, g["predictions"], g["step_margin"], 4 * lerr, chained=False)
+        st["ok"] = True
+    except AssertionError as exc:
+        st = {"ok": False, "violation": str(exc)[:200]}
+    st["logit_err"] = round(lerr, 5)
+    st["logit_span"] = round(float(g["tf_logits"].max() - g["tf_logits"].min()), 3)
+    st["reference"] = "tests/golden/full_bench_b64_greedy.npz"
+    return st
 
 
 def main():
@@ -117,7 +165,19 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--contexts", type=int, default=4,
                     help="engine contexts (shared weights) kept in flight on separate HIP streams")
+    ap.add_argument("--cpu-sweep", action="store_true",
+                    help="only time the CPU port at several thread counts (median of 3, bs=8) and print JSON")
     args = ap.parse_args()
+    if args.cpu_sweep:
+        import statistics
+        res = []
+        for th in (16, 32, 64, 128):
+            runs = [cpu_baseline(8, args.max_steps, th) for _ in range(3)]
+            med = sorted(runs, key=lambda r: r["value"])[1]
+            med["values"] = [r["value"] for r in runs]
+            res.append(med)
+        print(json.dumps({"cpu_sweep": res, "host_cpus": os.cpu_count()}), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -156,13 +216,21 @@ def main():
     else:
         search = Engine.make_search("beam", args.max_steps, 4, 2, 0.6)
 
-    def step():
+    lat_events = []
+
+    def step(record_latency=False):
         i = counter[0] % len(ctxs)
         counter[0] += 1
         with torch.cuda.stream(streams[i]):
+            if record_latency:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             tokens, logprobs, info = ctxs[i].generate(frames, search, sync=False)
             if world > 1:
                 gather_results(tokens, logprobs)
+            if record_latency:
+                e1.record()
+                lat_events.append((e0, e1))
         return tokens, info
 
     def fence():
@@ -175,9 +243,10 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tokens, info = step()
+        tokens, info = step(record_latency=True)
     fence()
     elapsed = time.perf_counter() - t0
+    lat = sorted(a.elapsed_time(b) for a, b in lat_events)
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -201,15 +270,27 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "decode_steps_per_caption": steps_run, "seq_len_returned": info_h[0],
                        "hip_graph": not args.no_graph, "contexts_in_flight": len(ctxs)},
+            # a batch's own latency (submit -> ids ready) while `contexts_in_flight` batches share the GPU
+            "batch_latency_ms": {"median": round(lat[len(lat) // 2], 3), "max": round(lat[-1], 3)},
         }
 
-    # ---- roofline pass (rank 0 of N=1 only): HIP events around phases and every GEMM launch ----
+    # ---- roofline passes (rank 0 of N=1 only) ---------------------------------------------------------------
     if rank == 0 and world == 1:
-        eng.profile_enable(True)
+        pmc = pmc_profile({"gemm": "gemm_p8", "attn_decode": "attn_decode", "dgemm": "dgemm_kernel", "vocab": "vocab_topm"})
+        # (1) eager launches, HIP events around every GEMM launch on the launch stream: per-kernel durations
+        eng.profile_enable(1)
         for _ in range(2):
             eng.generate(frames, search, sync=True)
             prof = eng.profile_read()
-        eng.profile_enable(False)
+        # (2) the production launch path: hipGraph replays of one context alone, split into an (encode + prefill)
+        #     graph and a decode graph with HIP events between them
+        eng.profile_enable(2)
+        for it in range(6):
+            tokens_solo, _, info_solo = eng.generate(frames, search, sync=True)
+            if it == 0:
+                eng.profile_read()          # drop the capture + first replay
+        gprof = eng.profile_read()
+        eng.profile_enable(0)
         n = max(1, prof["vit_gemm_launches"])
         flops_per_launch = prof["vit_gemm_flops"] / n
         avg_ms = prof["vit_gemm_ms"] / n
@@ -219,21 +300,39 @@ def main():
                       if args.precision == "bf16" else "gitmi::gemm_kernel<f32>",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "traffic_detail": pmc_traffic("gemm_p8"),
             "launches_per_step": prof["vit_gemm_launches"], "avg_launch_ms": round(avg_ms, 4),
             "flops_per_launch": flops_per_launch,
             "method": "HIP events around each launch on the launch stream, eager (no graph) pass after the timed region",
         }
-        if result["roofline"]["traffic_detail"]:
-            result["roofline"]["traffic"] = round(result["roofline"]["traffic_detail"]["bytes_per_launch"])
-        step_gbs = prof["decode_step_bytes"] / (prof["decode_step_ms"] * 1e-3) / 1e9 if prof["decode_step_ms"] > 0 else 0.0
+        if pmc and "gemm" in pmc:
+            result["roofline"]["traffic"] = round(pmc["gemm"].get("hbm_bytes", 0)) or None
+            result["roofline"]["mfma_busy_pct"] = pmc["gemm"].get("mfma_util_pct")
+            result["roofline"]["l2_hit_pct"] = pmc["gemm"].get("l2_hit_pct")
+            result["roofline"]["traffic_source"] = pmc["source"]
+            result["roofline"]["traffic_stale"] = pmc["stale"]
+        step_ms = gprof["decode_step_ms"]
+        step_gbs = gprof["decode_step_bytes"] / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         result["roofline_decode"] = {
             "bound": "hbm", "achieved": round(step_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(step_gbs / PEAK_HBM_GBS, 4), "traffic": None,
-            "bytes_per_step": prof["decode_step_bytes"], "avg_step_ms": round(prof["decode_step_ms"], 4),
-            "steps": prof["decode_steps"],
+            "bytes_per_step": gprof["decode_step_bytes"], "avg_step_ms": round(step_ms, 4),
+            "steps": gprof["decode_steps"], "eager_step_ms": round(prof["decode_step_ms"], 4),
+            "method": "HIP events around the decode hipGraph of one context (production launch path), averaged over "
+                      "5 replays; eager_step_ms = the same step with one host launch per kernel",
         }
+        if pmc:
+            per_step = 0.0
+            for key, launches in (("dgemm", 4 * cfg.dec_layers), ("attn_decode", cfg.dec_layers), ("vocab", 1)):
+                if key in pmc and "hbm_bytes" in pmc[key]:
+                    per_step += launches * pmc[key]["hbm_bytes"]
+            if per_step > 0:
+                result["roofline_decode"]["traffic"] = round(per_step)
+                result["roofline_decode"]["traffic_source"] = pmc["source"]
+                result["roofline_decode"]["traffic_stale"] = pmc["stale"]
         result["phases_ms"] = {k: round(prof[k], 3) for k in ("vit_ms", "prefill_ms", "decode_ms", "total_ms", "gemm_ms")}
+        result["phases_ms"]["graph_encode_prefill_ms"] = round(gprof["vit_ms"], 3)
+        result["phases_ms"]["graph_decode_ms"] = round(gprof["decode_ms"], 3)
+        result["parity"] = bench_parity(eng, tokens_solo, info_solo, args)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.max_steps, args.cpu_threads)
 

@@ -139,8 +139,17 @@ struct gitmi_engine {
     int cur_B = 0, cur_F = 0, cur_Nimg = 0;
     bool have_feats = false, have_prefill = false;
 
-    // profiling
-    bool profiling = false;
+    // profiling: 1 = eager launches with HIP events around phases, decode steps and every GEMM;
+    //            2 = hipGraph replays, the call split into an encode graph and a decode graph with events between them
+    //                (what the production path costs: no per-launch host work, no event records inside the chain)
+    int profile_mode = 0;
+    bool profiling = false;             // profile_mode == 1
+    hipGraph_t graph_b = nullptr;
+    hipGraphExec_t graph_exec_b = nullptr;
+    bool graph_is_split = false;
+    hipEvent_t gev[3] = {nullptr, nullptr, nullptr};
+    double split_encode_ms = 0, split_decode_ms = 0;
+    int split_calls = 0, split_steps = 0;
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> event_pool;
     size_t event_next = 0;
@@ -263,8 +272,10 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
 static void destroy_graph(gitmi_engine* e) {
     if (e->graph_exec) hipGraphExecDestroy(e->graph_exec);
     if (e->graph) hipGraphDestroy(e->graph);
-    e->graph_exec = nullptr;
-    e->graph = nullptr;
+    if (e->graph_exec_b) hipGraphExecDestroy(e->graph_exec_b);
+    if (e->graph_b) hipGraphDestroy(e->graph_b);
+    e->graph_exec = e->graph_exec_b = nullptr;
+    e->graph = e->graph_b = nullptr;
     e->graph_valid = false;
 }
 
@@ -276,6 +287,8 @@ extern "C" void gitmi_destroy(gitmi_engine* e) {
     if (e->own_stream) hipStreamDestroy(e->own_stream);
     if (e->fence_in) hipEventDestroy(e->fence_in);
     if (e->fence_out) hipEventDestroy(e->fence_out);
+    for (auto ev : e->gev)
+        if (ev) hipEventDestroy(ev);
     for (auto ev : e->event_pool) hipEventDestroy(ev);
     for (void* p : e->allocs) hipFree(p);
     delete e;
@@ -1119,27 +1132,58 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     key.B = B; key.Q = Q; key.F = F_eff; key.P = minP; key.kind = sp->kind; key.k = sp->beam_size; key.pn = sp->per_node_beam_size;
     key.T = sp->max_steps; key.H = e->H; key.W = e->W; key.lp = sp->length_penalty;
     key.ragged = ragged ? 1 : 0; key.ident = e->img_identity ? 1 : 0; key.temb = e->use_temb ? 1 : 0;
-    if (!e->graph_valid || !(key == e->graph_key)) {
+    const bool split = e->profile_mode == 2;
+    if (!e->graph_valid || !(key == e->graph_key) || split != e->graph_is_split) {
         destroy_graph(e);
         std::vector<const float*> fp(F_eff);
         for (int f = 0; f < F_eff; ++f) fp[f] = e->frame_stage[f];
-        HIPCK(hipStreamBeginCapture(x, hipStreamCaptureModeThreadLocal));
-        int rc = generate_body(e, fp.data(), F_eff, B, Q, minP, maxP, ragged, sp, e->out_tokens, e->out_lp, e->out_info,
-                               e->out_sent, x, false);
-        hipGraph_t gr = nullptr;
-        hipError_t ce = hipStreamEndCapture(x, &gr);
-        if (rc != 0) { if (gr) hipGraphDestroy(gr); return rc; }
-        HIPCK(ce);
-        e->graph = gr;
-        HIPCK(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+        auto capture = [&](int part, hipGraph_t* gr_out) -> int {       // part 0: whole call, 1: encode + prefill, 2: decode
+            HIPCK(hipStreamBeginCapture(x, hipStreamCaptureModeThreadLocal));
+            int rc = 0;
+            if (part == 0) rc = generate_body(e, fp.data(), F_eff, B, Q, minP, maxP, ragged, sp, e->out_tokens, e->out_lp,
+                                              e->out_info, e->out_sent, x, false);
+            else if (part == 1) rc = generate_encode(e, fp.data(), F_eff, B, x);
+            else rc = generate_decode(e, Q, minP, maxP, ragged, sp, e->out_tokens, e->out_lp, e->out_info, e->out_sent, x, false);
+            hipGraph_t gr = nullptr;
+            hipError_t ce = hipStreamEndCapture(x, &gr);
+            if (rc != 0) { if (gr) hipGraphDestroy(gr); return rc; }
+            HIPCK(ce);
+            *gr_out = gr;
+            return 0;
+        };
+        if (!split) {
+            RCK(capture(0, &e->graph));
+            HIPCK(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+        } else {
+            RCK(capture(1, &e->graph));
+            HIPCK(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+            RCK(capture(2, &e->graph_b));
+            HIPCK(hipGraphInstantiate(&e->graph_exec_b, e->graph_b, nullptr, nullptr, 0));
+            for (auto& ev : e->gev)
+                if (!ev) HIPCK(hipEventCreate(&ev));
+        }
         e->graph_key = key;
         e->graph_valid = true;
+        e->graph_is_split = split;
     } else {
         // host-side mirror of the state generate_body leaves behind
         e->cur_B = B; e->cur_F = F_eff; e->cur_Nimg = F_eff * e->N;
         e->have_feats = e->have_prefill = true;
     }
-    HIPCK(hipGraphLaunch(e->graph_exec, x));
+    if (!split) {
+        HIPCK(hipGraphLaunch(e->graph_exec, x));
+    } else {
+        HIPCK(hipEventRecord(e->gev[0], x));
+        HIPCK(hipGraphLaunch(e->graph_exec, x));
+        HIPCK(hipEventRecord(e->gev[1], x));
+        HIPCK(hipGraphLaunch(e->graph_exec_b, x));
+        HIPCK(hipEventRecord(e->gev[2], x));
+        HIPCK(hipStreamSynchronize(x));
+        float a = 0, b = 0;
+        HIPCK(hipEventElapsedTime(&a, e->gev[0], e->gev[1]));
+        HIPCK(hipEventElapsedTime(&b, e->gev[1], e->gev[2]));
+        e->split_encode_ms += a; e->split_decode_ms += b; e->split_calls += 1; e->split_steps += sp->max_steps - 1;
+    }
     HIPCK(hipMemcpyAsync(tokens_out, e->out_tokens, (size_t)Q * sp->max_steps * sizeof(long long), hipMemcpyDeviceToDevice, x));
     HIPCK(hipMemcpyAsync(logprob_out, e->out_lp, (size_t)Q * sizeof(float), hipMemcpyDeviceToDevice, x));
     HIPCK(hipMemcpyAsync(info_out, e->out_info, 4 * sizeof(int), hipMemcpyDeviceToDevice, x));
@@ -1209,7 +1253,9 @@ extern "C" int gitmi_generate_prefixed(gitmi_engine* e, const float* const* fram
 // ---- profiling --------------------------------------------------------------------------
 extern "C" int gitmi_profile_enable(gitmi_engine* e, int on) {
     if (!e) return fail("null engine");
-    e->profiling = on != 0;
+    e->profile_mode = on;
+    e->profiling = on == 1;
+    e->split_encode_ms = e->split_decode_ms = 0; e->split_calls = e->split_steps = 0;
     e->spans.clear();
     e->event_next = 0;
     return 0;
@@ -1231,6 +1277,18 @@ extern "C" int gitmi_profile_read(gitmi_engine* e, gitmi_profile* out) {
     HIPCK(hipSetDevice(e->device));
     HIPCK(hipDeviceSynchronize());
     memset(out, 0, sizeof(*out));
+    if (e->profile_mode == 2) {
+        // graph-replay timing: (encode + prefill) graph and decode graph of every call since enable, averaged per call
+        const double n = e->split_calls ? (double)e->split_calls : 1.0;
+        out->vit_ms = (float)(e->split_encode_ms / n);            // encode + prefill together (one graph)
+        out->decode_ms = (float)(e->split_decode_ms / n);
+        out->total_ms = out->vit_ms + out->decode_ms;
+        out->decode_steps = e->split_calls ? e->split_steps / e->split_calls : 0;
+        out->decode_step_ms = e->split_steps ? (float)(e->split_decode_ms / e->split_steps) : 0.f;
+        out->decode_step_bytes = e->last_decode_step_bytes;
+        e->split_encode_ms = e->split_decode_ms = 0; e->split_calls = e->split_steps = 0;
+        return 0;
+    }
     double step_ms = 0;
     for (const TimedSpan& sp : e->spans) {
         float ms = 0;
@@ -1291,9 +1349,12 @@ extern "C" int gitmi_op_attention(const void* qkv, void* out, int B, int N, int 
 }
 
 // ---- decode-chain kernels (kernels_dgemm.hip), one launch each -----------------------------------------------
+static int g_dgemm_dbg = 0;
+extern "C" int gitmi_debug_set_dgemm(int dbg) { g_dgemm_dbg = dbg; return 0; }
 extern "C" int gitmi_op_dgemm(const void* A, const void* W, const float* bias, const float* colsum, const float* stats,
                               int strips, float eps, void* C, int M, int N, int K, int act, void* stream) {
     DGemmArgs g{};
+    g.dbg = g_dgemm_dbg;
     g.A = (const unsigned short*)A; g.lda = K; g.W = (const unsigned short*)W; g.bias = bias;
     if (stats) { g.colsum = colsum; g.stats_in = (const float2*)stats; g.strips_in = strips; g.inv_d = 1.0f / (float)K; g.eps_in = eps; }
     g.C = C; g.ldc = N; g.act = act; g.M = M; g.N = N; g.K = K;
@@ -1305,6 +1366,7 @@ extern "C" int gitmi_op_dgemm_res(const void* A, const void* W, const float* bia
                                   int res_strips, const float* res_gamma, const float* res_beta, float res_eps,
                                   float* x_out, void* xb_out, float* stats_out, int M, int N, int K, void* stream) {
     DGemmArgs g{};
+    g.dbg = g_dgemm_dbg;
     g.A = (const unsigned short*)A; g.lda = K; g.W = (const unsigned short*)W; g.bias = bias;
     g.res_x = res_x;
     if (res_stats) { g.res_stats = (const float2*)res_stats; g.res_strips = res_strips; g.res_gamma = res_gamma; g.res_beta = res_beta; g.res_inv_d = 1.0f / (float)N; g.res_eps = res_eps; }

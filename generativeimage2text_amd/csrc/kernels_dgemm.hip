@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs g) {
         r.w = p[n + 3 < g.N ? n + 3 : g.N - 1];
         return r;
     };
-    if (finisher) {
+    if (finisher && !(g.dbg & 8)) {
         ep_a = ld4(g.bias, fn);
         if constexpr (EPI == DEPI_BF16) {
             if (g.stats_in) {
@@ -136,9 +136,22 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs g) {
         bf16x8_t wf[U], xf[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)(k0 + u) * 32));
+            if (!(g.dbg & 2)) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)(k0 + u) * 32));
+            else wf[u] = bf16x8_t{1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
-            for (int i = 0; i < MT; ++i) xf[u][i] = *reinterpret_cast<const bf16x8_t*>(xp[i] + (size_t)(k0 + u) * 32);
+            for (int i = 0; i < MT; ++i) {
+                if (!(g.dbg & 1)) xf[u][i] = *reinterpret_cast<const bf16x8_t*>(xp[i] + (size_t)(k0 + u) * 32);
+                else xf[u][i] = bf16x8_t{1, 1, 1, 1, 1, 1, 1, 1};
+            }
+        }
+        if (g.dbg & 4) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                asm volatile("" ::"v"(wf[u]));
+#pragma unroll
+                for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(xf[u][i]));
+            }
+            return;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)

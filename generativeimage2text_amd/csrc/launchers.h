@@ -38,6 +38,7 @@ struct DGemmArgs {
     const float2* res_stats; int res_strips; const float* res_gamma; const float* res_beta; float res_inv_d, res_eps;
     float* x_out; unsigned short* xb_out; float2* stats_out;
     int M, N, K, lda, ldc, act;
+    int dbg;                    // timing experiments only: 1 no activation loads, 2 no weight loads, 4 no MFMA, 8 no epilogue loads
 };
 hipError_t launch_dgemm(const DGemmArgs& g, hipStream_t s);
 

@@ -333,8 +333,10 @@ class Engine:
         return tokens, logprobs, info
 
     # -- profiling -----------------------------------------------------------------------------
-    def profile_enable(self, on: bool) -> None:
-        _ck(self.lib.gitmi_profile_enable(self._h, 1 if on else 0))
+    def profile_enable(self, on) -> None:
+        """False/0 off; True/1 eager launches with per-launch HIP events; 2 graph replays split into an
+        (encode + prefill) graph and a decode graph with events between them."""
+        _ck(self.lib.gitmi_profile_enable(self._h, int(on)))
 
     def profile_read(self) -> Dict[str, float]:
         p = GitmiProfile()

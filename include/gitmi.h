@@ -196,7 +196,11 @@ int  gitmi_search_finish(gitmi_engine* e, int64_t* tokens_out, float* logprob_ou
                          int32_t* info_out, void* stream);
 
 /* ---- profiling ---------------------------------------------------------------------- */
-int  gitmi_profile_enable(gitmi_engine* e, int on);   /* on: HIP events around phases and GEMMs */
+/* on = 1: eager launches with HIP events around phases, decode steps and every GEMM launch (per-kernel durations);
+ * on = 2: hipGraph replays with the call split into an (encode + prefill) graph and a decode graph and events
+ *         between them -- the production launch path, timed: vit_ms = encode + prefill, decode_ms, decode_step_ms;
+ * on = 0: off. */
+int  gitmi_profile_enable(gitmi_engine* e, int on);
 int  gitmi_profile_read(gitmi_engine* e, gitmi_profile* out);   /* synchronises */
 /* use hipGraph replay for gitmi_generate (default 1 unless profiling) */
 int  gitmi_set_graph(gitmi_engine* e, int on);
