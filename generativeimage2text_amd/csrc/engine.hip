@@ -61,8 +61,10 @@ struct DecLayerW {
     float *lnag = nullptr, *lnab = nullptr, *lnog = nullptr, *lnob = nullptr;
     // decode chain (bf16 mode): the LayerNorm in front of a GEMM folded into its weights (kernels_dgemm.hip):
     // W' = bf16(W . gamma), folded constant beta W^T + bias, column sums of W'
-    void *wqkv_f = nullptr; float *bqkv_f = nullptr, *cs_qkv = nullptr;   // previous layer's output LayerNorm (layers > 0)
+    // All decode-chain matrices are fragment-major copies (gitmi_common.h frag_offset), rows padded to 16.
+    void *wqkv_f = nullptr; float *bqkv_f = nullptr, *cs_qkv = nullptr;   // previous layer's output LayerNorm (layer 0: plain, cs_qkv == nullptr)
     void *w1_f = nullptr;   float *b1_f = nullptr,   *cs_1 = nullptr;     // this layer's attention-output LayerNorm
+    void *wo_p = nullptr, *w2_p = nullptr;                                 // plain, packed
 };
 
 struct TimedSpan { hipEvent_t a, b; int tag; double flops; };
@@ -387,7 +389,7 @@ static int alloc_workspaces(gitmi_engine* e) {
     const int D = c.vit_width, d = c.dec_hidden;
     const size_t Mv = (size_t)c.max_batch * c.max_frames * e->Nmax;  // ViT rows: all frames of a call in one pass
     const size_t Mp = (size_t)c.max_batch * c.max_frames * e->Nmax;  // prefill rows
-    const size_t R = (size_t)c.max_batch * c.max_beams;
+    const size_t R = (size_t)round_up(c.max_batch * c.max_beams, 16);   // fragment-major operand buffers hold whole 16-row tiles
     const int T = c.max_text_len;
     RCK(dev_alloc(e, &e->patches, (size_t)c.max_batch * c.max_frames * (e->Nmax - 1) * e->Kp_pad * esz));
     RCK(dev_alloc_t(e, &e->patch_out, (size_t)c.max_batch * c.max_frames * (e->Nmax - 1) * D));
@@ -430,7 +432,8 @@ static int alloc_workspaces(gitmi_engine* e) {
     e->ldl = round_up(c.vocab, 8);
     RCK(dev_alloc_t(e, &e->logits, R * e->ldl));
     // candidate lists of a step: the fused vocabulary head writes one list per (row, 128-column workgroup)
-    e->vocab_cols = std::max(128, round_up((c.vocab + 255) / 256, 16));
+    e->vocab_cols = 128;                  // columns per workgroup of the fused head (239 workgroups for the 30522-token vocabulary)
+    if (vocab_parts(c.vocab, e->vocab_cols) > 256) return fail("vocabularies above 32768 tokens are not supported by the fused head");
     e->vocab_nparts = vocab_parts(c.vocab, e->vocab_cols);
     RCK(dev_alloc_t(e, &e->part_val, R * (size_t)e->vocab_nparts * 16));
     RCK(dev_alloc_t(e, &e->part_idx, R * (size_t)e->vocab_nparts * 16));
@@ -495,18 +498,33 @@ static int fold_layernorm(gitmi_engine* e, const std::vector<float>& W, const st
         c2[n] = (float)sum;
         b2[n] = (float)cst;
     }
-    RCK(dev_alloc(e, Wf, (size_t)rows * K * 2));
+    const int64_t rows_pad = (rows + 127) / 128 * 128;       // the vocabulary head reads bias / colsum a workgroup (128 columns) at a time
+    RCK(dev_alloc(e, Wf, (size_t)rows_pad * K * 2));
     float* tmp = nullptr;
+    void* tmp_b = nullptr;
     HIPCK(hipMalloc((void**)&tmp, wf.size() * 4));
-    hipError_t err = hipMemcpy(tmp, wf.data(), wf.size() * 4, hipMemcpyHostToDevice);
-    if (err == hipSuccess) err = launch_convert_pad(tmp, *Wf, false, (size_t)rows, K, K, 0);
+    hipError_t err = hipMalloc(&tmp_b, wf.size() * 2);
+    if (err == hipSuccess) err = hipMemcpy(tmp, wf.data(), wf.size() * 4, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = launch_convert_pad(tmp, tmp_b, false, (size_t)rows, K, K, 0);
+    if (err == hipSuccess) err = launch_frag_pack(tmp_b, *Wf, (int)rows, (int)rows_pad, K, 0);
     if (err == hipSuccess) err = hipDeviceSynchronize();
     hipFree(tmp);
+    if (tmp_b) hipFree(tmp_b);
     HIPCK(err);
-    RCK(dev_alloc_t(e, bf, (size_t)rows));
-    RCK(dev_alloc_t(e, cs, (size_t)rows));
-    HIPCK(hipMemcpy(*bf, b2.data(), (size_t)rows * 4, hipMemcpyHostToDevice));
-    HIPCK(hipMemcpy(*cs, c2.data(), (size_t)rows * 4, hipMemcpyHostToDevice));
+    b2.resize((size_t)rows_pad, 0.f);
+    c2.resize((size_t)rows_pad, 0.f);
+    RCK(dev_alloc_t(e, bf, (size_t)rows_pad));
+    RCK(dev_alloc_t(e, cs, (size_t)rows_pad));
+    HIPCK(hipMemcpy(*bf, b2.data(), (size_t)rows_pad * 4, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(*cs, c2.data(), (size_t)rows_pad * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+// fragment-major copy of an already packed row-major bf16 matrix [rows, K]
+static int pack_frag(gitmi_engine* e, const void* src, int64_t rows, int K, void** dst) {
+    const int64_t rows_pad = (rows + 15) / 16 * 16;
+    RCK(dev_alloc(e, dst, (size_t)rows_pad * K * 2));
+    HIPCK(launch_frag_pack(src, *dst, (int)rows, (int)rows_pad, K, 0));
+    HIPCK(hipDeviceSynchronize());
     return 0;
 }
 static int host_vec(gitmi_engine* e, const std::string& key, size_t n, const std::vector<float>** out) {
@@ -537,7 +555,12 @@ static int fold_decoder(gitmi_engine* e) {
                 std::copy(bi->begin(), bi->end(), bq.begin() + (size_t)j * d);
             }
             RCK(fold_layernorm(e, wq, bq, *g, *b, 3 * d, d, &L.wqkv_f, &L.bqkv_f, &L.cs_qkv));
+        } else {          // layer 0 consumes the embedding LayerNorm's output directly: plain weights, packed
+            RCK(pack_frag(e, L.wqkv, 3 * d, d, &L.wqkv_f));
+            L.bqkv_f = L.bqkv;
         }
+        RCK(pack_frag(e, L.wo, d, d, &L.wo_p));
+        RCK(pack_frag(e, L.w2, d, f, &L.w2_p));
         RCK(host_vec(e, pre + "attention.output.LayerNorm.weight", d, &g));
         RCK(host_vec(e, pre + "attention.output.LayerNorm.bias", d, &b));
         RCK(host_vec(e, pre + "intermediate.dense.weight", (size_t)f * d, &w));
@@ -635,7 +658,7 @@ extern "C" int gitmi_finalize_weights(gitmi_engine* e) {
     RCK(up_f32(e, "textual.output.bias", {V}, &e->out_b));
     wbytes += (double)V * d * e->esz;
     e->dec_weight_bytes = wbytes;
-    if (!e->f32 && d % 16 == 0 && d <= 768) RCK(fold_decoder(e));      // the bf16 decode chain (else: generic GEMM + LayerNorm launches)
+    if (!e->f32 && d % 32 == 0 && f % 32 == 0 && d <= 768 && V <= 32768) RCK(fold_decoder(e));      // the bf16 decode chain (else: generic GEMM + LayerNorm launches)
     else e->skinny = false;
     e->host_w.clear();
     RCK(alloc_workspaces(e));
@@ -814,8 +837,8 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
         if (chain) {
             DGemmArgs q{};
             q.A = (const unsigned short*)(l == 0 ? e->d_ht : e->xo_b); q.lda = d;
-            q.W = (const unsigned short*)(l == 0 ? L.wqkv : L.wqkv_f);
-            q.bias = l == 0 ? L.bqkv : L.bqkv_f;
+            q.W = (const unsigned short*)L.wqkv_f;
+            q.bias = L.bqkv_f;
             if (l > 0) { q.colsum = L.cs_qkv; q.stats_in = e->stats_o; q.strips_in = strips; q.inv_d = inv_d; q.eps_in = 1e-12f; }
             q.C = e->d_qkv; q.ldc = 3 * d; q.act = 0; q.M = R; q.N = 3 * d; q.K = d;
             RCK(dgemm(e, s, q));
@@ -827,10 +850,11 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
         a.kv_src = kv_src; a.ld_src = ld_ids; a.d = d; a.N_img = e->cur_Nimg; a.T_max = c.max_text_len;
         a.img_of = e->img_identity ? nullptr : e->img_of_dev;
         a.pos = pos; a.beams = beams; a.scale = 0.125f;
+        a.out_frag = chain ? 1 : 0;
         HIPCK(launch_attn_decode(a, B, c.dec_heads, e->f32, s));
         if (chain) {
             DGemmArgs o{};
-            o.A = (const unsigned short*)e->d_ctx; o.lda = d; o.W = (const unsigned short*)L.wo; o.bias = L.bo;
+            o.A = (const unsigned short*)e->d_ctx; o.lda = d; o.W = (const unsigned short*)L.wo_p; o.bias = L.bo;
             o.res_x = l == 0 ? e->d_hf : e->xo_f;
             if (l > 0) { o.res_stats = e->stats_o; o.res_strips = strips; o.res_gamma = Lp->lnog; o.res_beta = Lp->lnob; o.res_inv_d = inv_d; o.res_eps = 1e-12f; }
             o.x_out = e->xa_f; o.xb_out = (unsigned short*)e->xa_b; o.stats_out = e->stats_a;
@@ -839,10 +863,10 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
             DGemmArgs f1{};
             f1.A = (const unsigned short*)e->xa_b; f1.lda = d; f1.W = (const unsigned short*)L.w1_f; f1.bias = L.b1_f; f1.colsum = L.cs_1;
             f1.stats_in = e->stats_a; f1.strips_in = strips; f1.inv_d = inv_d; f1.eps_in = 1e-12f;
-            f1.C = e->d_u; f1.ldc = ffn; f1.act = 2; f1.M = R; f1.N = ffn; f1.K = d;
+            f1.C = e->d_u; f1.ldc = ffn; f1.c_frag = 1; f1.act = 2; f1.M = R; f1.N = ffn; f1.K = d;
             RCK(dgemm(e, s, f1));
             DGemmArgs f2{};
-            f2.A = (const unsigned short*)e->d_u; f2.lda = ffn; f2.W = (const unsigned short*)L.w2; f2.bias = L.b2;
+            f2.A = (const unsigned short*)e->d_u; f2.lda = ffn; f2.W = (const unsigned short*)L.w2_p; f2.bias = L.b2;
             f2.res_x = e->xa_f; f2.res_stats = e->stats_a; f2.res_strips = strips; f2.res_gamma = L.lnag; f2.res_beta = L.lnab;
             f2.res_inv_d = inv_d; f2.res_eps = 1e-12f;
             f2.x_out = e->xo_f; f2.xb_out = (unsigned short*)e->xo_b; f2.stats_out = e->stats_o;
@@ -933,7 +957,7 @@ extern "C" int gitmi_step_logits(gitmi_engine* e, const int64_t* tokens, int R, 
     for (int pos = 0; pos < t; ++pos) {
         SpanGuard step(e, s, TAG_STEP, 0);
         HIPCK(launch_embed_ln(e->ss.ids[0], T, pos, e->words_f, e->positions_f, e->emb_lng, e->emb_lnb, 1e-8f, e->d_hf,
-                              e->d_ht, e->f32, R, c.dec_hidden, c.vocab, s));
+                              e->d_ht, e->f32, R, c.dec_hidden, c.vocab, e->skinny && !e->f32, s));
         RCK(decode_layers_impl(e, e->ss.kv_src[0], T, pos, R, beams, s));
         if (pos == t - 1) RCK(decode_head_impl(e, nullptr, T, t, R, beams, 0, 1, logits_out, c.vocab, s, &cands));
     }
@@ -976,6 +1000,7 @@ static EmbedArgs embed_args(gitmi_engine* e, bool on) {
     if (!on) return em;
     em.words = e->words_f; em.positions = e->positions_f; em.gamma = e->emb_lng; em.beta = e->emb_lnb; em.eps = 1e-8f;
     em.h_f = e->d_hf; em.h_t = e->d_ht; em.D = e->cfg.dec_hidden; em.vocab = e->cfg.vocab;
+    em.frag = (e->skinny && !e->f32) ? 1 : 0;
     return em;
 }
 
@@ -1067,7 +1092,7 @@ static int generate_decode(gitmi_engine* e, int Q, int minP, int maxP, bool ragg
         SpanGuard phase(e, s, TAG_DECODE, 0);
         // position 0 is embedded here; every later position by the search step that appends its token
         HIPCK(launch_embed_ln(st.ids[0], T, 0, e->words_f, e->positions_f, e->emb_lng, e->emb_lnb, 1e-8f, e->d_hf, e->d_ht,
-                              e->f32, R, c.dec_hidden, c.vocab, s));
+                              e->f32, R, c.dec_hidden, c.vocab, e->skinny && !e->f32, s));
         e->ss_len = 1;
         StepCands cands{e->part_val, e->part_idx, e->part_lse, 1, 1};
         while (e->ss_len < T) {
@@ -1352,9 +1377,11 @@ extern "C" int gitmi_op_attention(const void* qkv, void* out, int B, int N, int 
 static int g_dgemm_dbg = 0;
 extern "C" int gitmi_debug_set_dgemm(int dbg) { g_dgemm_dbg = dbg; return 0; }
 extern "C" int gitmi_op_dgemm(const void* A, const void* W, const float* bias, const float* colsum, const float* stats,
-                              int strips, float eps, void* C, int M, int N, int K, int act, void* stream) {
+                              int strips, float eps, void* C, int c_frag, int M, int N, int K, int act, void* stream) {
     DGemmArgs g{};
     g.dbg = g_dgemm_dbg;
+    g.c_frag = c_frag;
+    if (c_frag && N % 32) return fail("op_dgemm: a fragment-major output needs N %% 32 == 0");
     g.A = (const unsigned short*)A; g.lda = K; g.W = (const unsigned short*)W; g.bias = bias;
     if (stats) { g.colsum = colsum; g.stats_in = (const float2*)stats; g.strips_in = strips; g.inv_d = 1.0f / (float)K; g.eps_in = eps; }
     g.C = C; g.ldc = N; g.act = act; g.M = M; g.N = N; g.K = K;
@@ -1384,6 +1411,7 @@ extern "C" int gitmi_op_vocab_topm(const void* A, const void* W, const float* bi
     v.A = (const unsigned short*)A; v.lda = K; v.W = (const unsigned short*)W; v.bias = bias;
     if (stats) { v.colsum = colsum; v.stats_in = (const float2*)stats; v.strips_in = strips; v.inv_d = 1.0f / (float)K; v.eps_in = eps; }
     v.M = M; v.N = V; v.K = K; v.cols_per_wg = cols_per_wg;
+    if (cols_per_wg != 64 && cols_per_wg != 128) return fail("op_vocab_topm: cols_per_wg must be 64 or 128");
     // the rule is driven through the search tables in the engine; the unit entry point takes one token per row
     // (ids [M][1], cur_len 1, prefix length 0 => "past the first step")
     static int* zero_plen = nullptr;

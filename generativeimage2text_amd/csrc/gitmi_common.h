@@ -72,6 +72,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- fragment-major operand layout of the decode chain (kernels_dgemm.hip) -------------------------------------
+// A [rows, K] bf16 matrix is stored as 16-row x 32-k tiles, each tile in MFMA 16x16x32 operand order: lane = (k%32)/8*16 + row%16
+// holds 8 consecutive k.  A wave's fragment load is then ONE contiguous 1-KiB read (8 full cache lines) instead of
+// 16 rows x 64 B gathered from 16 different lines.  ksteps = K / 32.
+__device__ __host__ __forceinline__ size_t frag_offset(int row, int k, int ksteps) {
+    return (((size_t)(row >> 4) * ksteps + (k >> 5)) * 64 + (size_t)(((k & 31) >> 3) * 16 + (row & 15))) * 8 + (k & 7);
+}
+// start of tile (row tile rt, k-step ks) for a given lane
+__device__ __forceinline__ size_t frag_tile(int rt, int ks, int ksteps, int lane) {
+    return (((size_t)rt * ksteps + ks) * 64 + lane) * 8;
+}
+
 // activation codes shared with the host
 #define GITMI_ACT_NONE 0
 #define GITMI_ACT_QUICKGELU 1   // x * sigmoid(1.702 x)            CLIP/model.py:171-173

@@ -720,6 +720,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs a) {
             num += aw * part[w][j][dd];
             den += aw * part[w][j][HD + 1];
         }
+        if constexpr (sizeof(T) == 2) {
+            if (a.out_frag) { O[frag_offset(row0 + j, h * HD + dd, a.d >> 5)] = f2bf(num / den); continue; }
+        }
         st<T>(O + (size_t)(row0 + j) * a.d + h * HD + dd, num / den);
     }
 }

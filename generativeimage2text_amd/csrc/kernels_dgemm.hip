@@ -21,6 +21,11 @@
 // all loads of a chunk in flight before the first MFMA), partial accumulators are exchanged through LDS and summed
 // in a FIXED order -- deterministic, batch-invariant (a row's result does not depend on which rows share its tile).
 //
+// Operand layout: BOTH operands are fragment-major (gitmi_common.h frag_offset): every fragment load of a wave is one
+// contiguous 1-KiB read.  Weights are repacked once at finalisation; activations are WRITTEN in that order by their
+// producers (the N = 768 epilogue, the FFN1 epilogue, decode attention, the embedding), so the chain never transposes.
+// Row-major fragment gathers (16 rows x 64 B per instruction) cost 2.5 us of a 6.3 us QKV launch (profiles/r02_a).
+//
 // The vocabulary head (`vocab_topm_kernel`) keeps its 64-row activation fragments in registers and sweeps 128
 // columns per workgroup (weights double-buffered), applies the no-repeat rule (decoder.py:330), and keeps a running
 // per-row top-M and log-sum-exp in registers: logits never reach HBM (decoder.py:1054, 1169-1175 fused); what is
@@ -117,16 +122,11 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs g) {
     const int kb = wave * per;
     const int ke = min(kb + per, ksteps);
 
-    int wn = n0 + l15;
-    wn = wn < g.N ? wn : g.N - 1;
-    const bf16_t* wp = W + (size_t)wn * g.K + lg * 8;
+    // fragment-major operands: tile (row tile, k-step) is 512 elements, this lane's 8 at lane*8
+    const bf16_t* wp = W + frag_tile(blockIdx.x, 0, ksteps, lane);
     const bf16_t* xp[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        int m = m0 + i * 16 + l15;
-        m = m < g.M ? m : g.M - 1;
-        xp[i] = X + (size_t)m * g.lda + lg * 8;
-    }
+    for (int i = 0; i < MT; ++i) xp[i] = X + frag_tile(blockIdx.y * MT + i, 0, ksteps, lane);
     f32x4_t acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -136,11 +136,11 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs g) {
         bf16x8_t wf[U], xf[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!(g.dbg & 2)) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)(k0 + u) * 32));
+            if (!(g.dbg & 2)) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)(k0 + u) * 512));
             else wf[u] = bf16x8_t{1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                if (!(g.dbg & 1)) xf[u][i] = *reinterpret_cast<const bf16x8_t*>(xp[i] + (size_t)(k0 + u) * 32);
+                if (!(g.dbg & 1)) xf[u][i] = *reinterpret_cast<const bf16x8_t*>(xp[i] + (size_t)(k0 + u) * 512);
                 else xf[u][i] = bf16x8_t{1, 1, 1, 1, 1, 1, 1, 1};
             }
         }
@@ -195,6 +195,13 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs g) {
             for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], g.act);
         }
         if (fm_raw >= g.M || fn >= g.N) return;
+        if (g.c_frag) {      // operand of the next chain GEMM (N % 32 == 0): 4 consecutive columns = 8 contiguous bytes
+            uint2 t;
+            t.x = pack2bf(v[0], v[1]);
+            t.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + frag_offset(fm, fn, g.N >> 5)) = t;
+            return;
+        }
         bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (size_t)fm * g.ldc + fn;
         if (fn + 3 < g.N && (g.ldc & 3) == 0) {
             uint2 t;
@@ -229,24 +236,28 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs g) {
         uint2 t;
         t.x = pack2bf(v[0], v[1]);
         t.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(g.xb_out + (size_t)fm * g.N + fn) = t;
+        *reinterpret_cast<uint2*>(g.xb_out + frag_offset(fm, fn, g.N >> 5)) = t;      // fragment-major operand copy
         if (lg == 0) g.stats_out[(size_t)blockIdx.x * g.M + fm] = float2{s, q};
     }
 }
 
 // ---- vocabulary head + running top-M / log-sum-exp ---------------------------------------------------------
-// grid = (ceil(V / cols_per_wg), ceil(M/(16*MT))); block = 256 (K split over 4 waves, K <= 768)
+// grid = (ceil(V / (16*NS)), ceil(M/(16*MT))); block = 256 (K split over 4 waves, K <= 768).
+// A workgroup owns NS 16-column strips.  EVERY weight fragment of its strips is requested before the first MFMA
+// (NS*VKS 16-byte loads per lane = up to 96 KiB in flight per workgroup): the kernel is one HBM round trip, then NS
+// short compute/exchange rounds -- with a strip-at-a-time prefetch the same sweep waited one memory latency per strip
+// (24.7 us at 128 columns; profiles/r02_a_decode_kernel_ablation.txt).
 constexpr int VKS = 6;      // k-steps of 32 per wave held in registers
 
-template <int MT, int MTOP>
+template <int MT, int MTOP, int NS>
 __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
     __shared__ __attribute__((aligned(16))) f32x4_t red[2][4][MT][64];     // double-buffered exchange: one barrier per strip
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int m0 = blockIdx.y * (16 * MT);
-    const int c0 = blockIdx.x * g.cols_per_wg;
-    const int ncols = max(0, min(g.cols_per_wg, g.N - c0));
+    const int c0 = blockIdx.x * (16 * NS);
+    const int ncols = max(0, min(16 * NS, g.N - c0));
     const int nstrips = (ncols + 15) / 16;
 
     const bool finisher = wave < MT;
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
         }
     }
 
-    // ---- activation fragments of this wave's K range: loaded once, kept for every strip ------------------
+    // ---- every operand fragment of this wave's K range, requested up front -------------------------------
     const int ksteps = g.K >> 5;
     const int per = (ksteps + 3) / 4;
     const int kb = wave * per;
@@ -273,25 +284,34 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
     bf16x8_t xf[VKS][MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        int m = m0 + i * 16 + l15;
-        m = m < g.M ? m : g.M - 1;
-        const bf16_t* xp = g.A + (size_t)m * g.lda + lg * 8 + (size_t)kb * 32;
+        const bf16_t* xp = g.A + frag_tile(blockIdx.y * MT + i, kb, ksteps, lane);
 #pragma unroll
         for (int u = 0; u < VKS; ++u) {
-            if (u < ks) xf[u][i] = *reinterpret_cast<const bf16x8_t*>(xp + (size_t)u * 32);
+            if (u < ks) xf[u][i] = *reinterpret_cast<const bf16x8_t*>(xp + (size_t)u * 512);
             else xf[u][i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
-    auto load_w = [&](bf16x8_t (&wf)[VKS], int strip) {
-        int n = c0 + strip * 16 + l15;
-        n = n < g.N ? n : g.N - 1;
-        const bf16_t* wp = g.W + (size_t)n * g.K + lg * 8 + (size_t)kb * 32;
+    const int tile0 = c0 >> 4;                              // first 16-column tile of this workgroup
+    bf16x8_t wf[NS][VKS];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        const bf16_t* wp = g.W + frag_tile(tile0 + st, kb, ksteps, lane);        // rows >= N are zero in the packed matrix
 #pragma unroll
         for (int u = 0; u < VKS; ++u) {
-            if (u < ks) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)u * 32));
-            else wf[u] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            if (u < ks && st < nstrips) wf[st][u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)u * 512));
+            else wf[st][u] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
-    };
+    }
+    // bias / column sums of the columns this lane finishes (bias and colsum are padded to a multiple of 16*NS entries)
+    float4 eb[NS], ec[NS];
+    if (finisher) {
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int n = c0 + st * 16 + lg * 4;
+            eb[st] = *reinterpret_cast<const float4*>(g.bias + n);
+            ec[st] = fold ? *reinterpret_cast<const float4*>(g.colsum + n) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 
     // running per-lane state of the finisher: sorted top-MTOP of its 4 columns per strip, online log-sum-exp
     float tv[MTOP];
@@ -300,12 +320,11 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
     for (int j = 0; j < MTOP; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
     float mx = -INFINITY, sm = 0.f;
     float mean = 0.f, rstd = 1.f;
+    if (finisher && fold) stats_finish(sl, g.inv_d, g.eps_in, mean, rstd);
 
-    bf16x8_t wa[VKS], wb[VKS];
-    if (nstrips > 0) load_w(wa, 0);
-
-    auto do_strip = [&](bf16x8_t (&wcur)[VKS], bf16x8_t (&wnext)[VKS], int strip) {
-        if (strip + 1 < nstrips) load_w(wnext, strip + 1);          // prefetch: in flight during this strip's MFMAs
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        if (st >= nstrips) break;
         f32x4_t acc[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -313,8 +332,8 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
         for (int u = 0; u < VKS; ++u)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur[u], xf[u][i], acc[i], 0, 0, 0);
-        const int buf = strip & 1;
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[st][u], xf[u][i], acc[i], 0, 0, 0);
+        const int buf = st & 1;
 #pragma unroll
         for (int i = 0; i < MT; ++i) red[buf][wave][i][lane] = acc[i];
         __syncthreads();
@@ -325,14 +344,13 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
                 const f32x4_t t = red[buf][w][wave][lane];
                 tot[0] += t[0]; tot[1] += t[1]; tot[2] += t[2]; tot[3] += t[3];
             }
-            const int n = c0 + strip * 16 + lg * 4;
+            const int n = c0 + st * 16 + lg * 4;
             float v[4] = {tot[0], tot[1], tot[2], tot[3]};
+            const float bb[4] = {eb[st].x, eb[st].y, eb[st].z, eb[st].w}, cc[4] = {ec[st].x, ec[st].y, ec[st].z, ec[st].w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int nn = n + r < g.N ? n + r : g.N - 1;
-                const float b = g.bias[nn];
-                if (fold) v[r] = rstd * (v[r] - mean * g.colsum[nn]) + b;
-                else v[r] += b;
+                if (fold) v[r] = rstd * (v[r] - mean * cc[r]) + bb[r];
+                else v[r] += bb[r];
             }
             if (g.logits_out && fm_raw < g.M) {
 #pragma unroll
@@ -359,12 +377,6 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
                 }
             }
         }
-    };
-
-    if (finisher && fold) stats_finish(sl, g.inv_d, g.eps_in, mean, rstd);
-    for (int strip = 0; strip < nstrips; strip += 2) {
-        do_strip(wa, wb, strip);
-        if (strip + 1 < nstrips) do_strip(wb, wa, strip + 1);
     }
     if (!finisher) return;
 
@@ -438,25 +450,29 @@ hipError_t launch_dgemm(const DGemmArgs& g, hipStream_t s) {
 int vocab_parts(int V, int cols_per_wg) { return (V + cols_per_wg - 1) / cols_per_wg; }
 int vocab_mtop_slots(int mtop) { return mtop <= 1 ? 1 : mtop <= 2 ? 2 : mtop <= 4 ? 4 : mtop <= 8 ? 8 : 16; }
 
-template <int MTOP>
+template <int MTOP, int NS>
 static hipError_t launch_vocab_m(const VocabArgs& g, hipStream_t s) {
-    const int nwg = vocab_parts(g.N, g.cols_per_wg);
-    if (g.M <= 16) hipLaunchKernelGGL((vocab_topm_kernel<1, MTOP>), dim3(nwg, 1), dim3(256), 0, s, g);
-    else if (g.M <= 32) hipLaunchKernelGGL((vocab_topm_kernel<2, MTOP>), dim3(nwg, 1), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((vocab_topm_kernel<4, MTOP>), dim3(nwg, (g.M + 63) / 64), dim3(256), 0, s, g);
+    const int nwg = vocab_parts(g.N, 16 * NS);
+    if (g.M <= 16) hipLaunchKernelGGL((vocab_topm_kernel<1, MTOP, NS>), dim3(nwg, 1), dim3(256), 0, s, g);
+    else if (g.M <= 32) hipLaunchKernelGGL((vocab_topm_kernel<2, MTOP, NS>), dim3(nwg, 1), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((vocab_topm_kernel<4, MTOP, NS>), dim3(nwg, (g.M + 63) / 64), dim3(256), 0, s, g);
     return hipGetLastError();
 }
 
+// cols_per_wg: 64 (default) or 128 columns per workgroup; bias / colsum must be readable up to the next multiple of it
 hipError_t launch_vocab_topm(const VocabArgs& g, int mtop, hipStream_t s) {
     if (g.M <= 0) return hipSuccess;
-    if (g.K % 32 != 0 || (g.K >> 5) > 4 * VKS || g.cols_per_wg % 16 != 0 || mtop < 1 || mtop > 16)
+    if (g.K % 32 != 0 || (g.K >> 5) > 4 * VKS || (g.cols_per_wg != 64 && g.cols_per_wg != 128) || mtop < 1 || mtop > 16)
         return hipErrorInvalidValue;
     if (g.stats_in && (!g.colsum || g.strips_in > 4 * STRIP_SLOTS)) return hipErrorInvalidValue;
-    if (mtop <= 1) return launch_vocab_m<1>(g, s);
-    if (mtop <= 2) return launch_vocab_m<2>(g, s);
-    if (mtop <= 4) return launch_vocab_m<4>(g, s);
-    if (mtop <= 8) return launch_vocab_m<8>(g, s);
-    return launch_vocab_m<16>(g, s);
+#define GITMI_VOC(MM)                                                 \
+    return g.cols_per_wg == 64 ? launch_vocab_m<MM, 4>(g, s) : launch_vocab_m<MM, 8>(g, s)
+    if (mtop <= 1) { GITMI_VOC(1); }
+    if (mtop <= 2) { GITMI_VOC(2); }
+    if (mtop <= 4) { GITMI_VOC(4); }
+    if (mtop <= 8) { GITMI_VOC(8); }
+    GITMI_VOC(16);
+#undef GITMI_VOC
 }
 
 }  // namespace gitmi

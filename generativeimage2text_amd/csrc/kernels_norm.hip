@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps,
                                                        float* __restrict__ h_f, TOut* __restrict__ h_t, int R,
-                                                       int D, int vocab) {
+                                                       int D, int vocab, int frag) {
     __shared__ float s_part[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = blockIdx.x;
@@ -239,7 +239,9 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
             uint2 t;
             t.x = pack2bf(o[0], o[1]);
             t.y = pack2bf(o[2], o[3]);
-            *reinterpret_cast<uint2*>(h_t + (size_t)row * D + c) = t;
+            // operand of the decode chain's first GEMM: fragment-major (kernels_dgemm.hip)
+            const size_t off = frag ? frag_offset(row, c, D >> 5) : (size_t)row * D + c;
+            *reinterpret_cast<uint2*>(h_t + off) = t;
         }
     }
 }
@@ -262,6 +264,22 @@ __global__ void copy_f32_kernel(const float* __restrict__ src, int lds, float* _
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / cols, c = i % cols;
         dst[r * ldd + c] = src[r * lds + c];
+    }
+}
+
+// row-major bf16 [rows, K] -> fragment-major [ceil16(rows_out), K] (gitmi_common.h frag_offset); rows >= `rows` are zero
+__global__ void frag_pack_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int rows_out, int K) {
+    const int ksteps = K >> 5;
+    const size_t total = (size_t)rows_out * (K >> 3);                 // 8-element (16-byte) groups
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        // destination-linear index: tile, lane, so that writes are contiguous
+        const size_t tile = i >> 6;
+        const int lane = (int)(i & 63);
+        const int rt = (int)(tile / ksteps), ks = (int)(tile % ksteps);
+        const int row = rt * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (row < rows) v = *reinterpret_cast<const u32x4_t*>(src + (size_t)row * K + k);
+        *reinterpret_cast<u32x4_t*>(dst + i * 8) = v;
     }
 }
 
@@ -320,15 +338,23 @@ hipError_t launch_vit_assemble_ln(const float* patch_out, const float* cls, cons
 
 hipError_t launch_embed_ln(const int* ids, int ld_ids, int pos, const float* words, const float* positions,
                            const float* gamma, const float* beta, float eps, float* h_f, void* h_t, bool t_is_f32,
-                           int R, int D, int vocab, hipStream_t s) {
-    if (D > 1024 || (D & 3)) return hipErrorInvalidValue;
+                           int R, int D, int vocab, bool frag, hipStream_t s) {
+    if (D > 1024 || (D & 3) || (frag && (t_is_f32 || (D & 31)))) return hipErrorInvalidValue;
     dim3 grid(R), block(256);
     if (t_is_f32)
         hipLaunchKernelGGL(embed_ln_kernel<float>, grid, block, 0, s, ids, ld_ids, pos, words, positions, gamma,
-                           beta, eps, h_f, (float*)h_t, R, D, vocab);
+                           beta, eps, h_f, (float*)h_t, R, D, vocab, 0);
     else
         hipLaunchKernelGGL(embed_ln_kernel<bf16_t>, grid, block, 0, s, ids, ld_ids, pos, words, positions, gamma,
-                           beta, eps, h_f, (bf16_t*)h_t, R, D, vocab);
+                           beta, eps, h_f, (bf16_t*)h_t, R, D, vocab, frag ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_frag_pack(const void* src_bf16, void* dst_bf16, int rows, int rows_out, int K, hipStream_t s) {
+    if (K % 32 || rows_out % 16 || rows_out < rows) return hipErrorInvalidValue;
+    const size_t total = (size_t)rows_out * (K >> 3);
+    hipLaunchKernelGGL(frag_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const bf16_t*)src_bf16,
+                       (bf16_t*)dst_bf16, rows, rows_out, K);
     return hipGetLastError();
 }
 

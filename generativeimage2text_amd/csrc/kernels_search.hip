@@ -400,7 +400,8 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
                 uint2 t;
                 t.x = pack2bf(o[0], o[1]);
                 t.y = pack2bf(o[2], o[3]);
-                *reinterpret_cast<uint2*>(ht + (size_t)r * D + c) = t;
+                const size_t off = em.frag ? frag_offset(r, c, D >> 5) : (size_t)r * D + c;
+                *reinterpret_cast<uint2*>(ht + off) = t;
             }
         }
     }

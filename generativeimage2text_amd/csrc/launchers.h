@@ -27,12 +27,13 @@ void set_gemm_impl(int impl);   // -1 auto, 0 first-generation kernel only, 1 fo
 
 // ---- decode-step GEMM chain (kernels_dgemm.hip): LayerNorm folded into the consumer, row partials from the producer
 struct DGemmArgs {
-    const unsigned short* A; const unsigned short* W;   // bf16 [M, lda], [N, K]
+    const unsigned short* A; const unsigned short* W;   // bf16 [M, K], [N, K], BOTH fragment-major (gitmi_common.h frag_offset)
     const float* bias;          // [N]  bias, or the folded constant  beta W^T + bias
     const float* colsum;        // [N]  sum_k bf16(W gamma)[n][k] when the input LayerNorm is folded, else nullptr
     const float2* stats_in;     // [strips_in][M] (sum, sumsq) strip partials of the folded LayerNorm's input (nullptr: none)
     int strips_in; float inv_d, eps_in;
-    void* C;                    // bf16 [M, ldc] output of the QKV / FFN1 form
+    void* C;                    // bf16 [M, ldc] output of the QKV / FFN1 form (row-major), or fragment-major [M, N] when c_frag
+    int c_frag;
     // N = 768 form: x_out = A W^T + bias + residual (+ bf16 copy + strip partials of x_out)
     const float* res_x;         // fp32 [M, N]: the hidden state, or the raw x the residual LayerNorm is rebuilt from
     const float2* res_stats; int res_strips; const float* res_gamma; const float* res_beta; float res_inv_d, res_eps;
@@ -66,7 +67,8 @@ hipError_t launch_vit_assemble_ln(const float* patch_out, const float* cls, cons
                                   const float* beta, float eps, float* X, int B, int N, int D, hipStream_t s);
 hipError_t launch_embed_ln(const int* ids, int ld_ids, int pos, const float* words, const float* positions,
                            const float* gamma, const float* beta, float eps, float* h_f, void* h_t, bool t_is_f32,
-                           int R, int D, int vocab, hipStream_t s);
+                           int R, int D, int vocab, bool frag, hipStream_t s);
+hipError_t launch_frag_pack(const void* src_bf16, void* dst_bf16, int rows, int rows_out, int K, hipStream_t s);
 hipError_t launch_convert_pad(const float* src, void* dst, bool dst_f32, size_t rows, int K, int Kpad,
                               hipStream_t s);
 hipError_t launch_copy_f32(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s);
@@ -87,6 +89,7 @@ struct AttnDecodeArgs {
     int ld_src;
     int d;
     int N_img, T_max, pos, beams;
+    int out_frag;        // write `out` in the fragment-major operand layout of the decode chain (bf16)
     float scale;
     int dbg;             // timing experiments: 1 skip image K/V loads, 2 skip scores, 4 skip PV
 };
@@ -123,6 +126,7 @@ struct StepCands {
 struct EmbedArgs {
     const float* words; const float* positions; const float* gamma; const float* beta; float eps;
     float* h_f; void* h_t; int D, vocab;
+    int frag;            // h_t in the fragment-major operand layout of the decode chain
 };
 int row_topm_slots(int M);
 hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, int ld_ids, int cur_len,

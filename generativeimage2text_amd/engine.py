@@ -94,7 +94,7 @@ def load_library() -> C.CDLL:
     lib.gitmi_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_attention.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
-    lib.gitmi_op_dgemm.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, vp, i32, i32, i32, i32, vp]
+    lib.gitmi_op_dgemm.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, vp, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_dgemm_res.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_vocab_topm.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.gitmi_generate_prefixed.argtypes = [vp, C.POINTER(vp), i32, i32, vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -392,47 +392,87 @@ def strip_stats(x: torch.Tensor) -> torch.Tensor:
     return torch.stack([xs.sum(-1), (xs * xs).sum(-1)], dim=-1).permute(1, 0, 2).contiguous()
 
 
+def to_frag(x: torch.Tensor, row_multiple: int = 16) -> torch.Tensor:
+    """Row-major bf16 [R, K] -> the fragment-major operand layout of the decode chain (include/gitmi.h): 16-row x
+    32-k tiles in MFMA operand order, rows zero-padded to `row_multiple`."""
+    R, K = x.shape
+    Rp = (R + row_multiple - 1) // row_multiple * row_multiple
+    xp = torch.zeros(Rp, K, dtype=x.dtype, device=x.device)
+    xp[:R] = x
+    return xp.reshape(Rp // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(Rp, K)
+
+
+def from_frag(xf: torch.Tensor, rows: int) -> torch.Tensor:
+    Rp, K = xf.shape
+    return xf.reshape(Rp // 16, K // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(Rp, K)[:rows].contiguous()
+
+
+def _pad_vec(v: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
+    if v is None:
+        return None
+    out = torch.zeros(n, dtype=v.dtype, device=v.device)
+    out[:v.numel()] = v
+    return out
+
+
 def op_dgemm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, colsum: Optional[torch.Tensor] = None,
-             stats: Optional[torch.Tensor] = None, eps: float = 1e-12, act: int = ACT_NONE) -> torch.Tensor:
+             stats: Optional[torch.Tensor] = None, eps: float = 1e-12, act: int = ACT_NONE,
+             frag_out: bool = False, packed: bool = False) -> torch.Tensor:
     """Decode-chain GEMM, QKV / FFN1 form (kernels_dgemm.hip): bf16 A [M,K], W [N,K] -> bf16 [M,N].
     With `stats` ([K/16][M][2] strip partials of the raw rows behind A) the LayerNorm in front of the GEMM is folded:
-    out = rstd * (A W^T - mean * colsum) + bias."""
+    out = rstd * (A W^T - mean * colsum) + bias.  Operands are given row-major and packed here (packed=True: A, W are
+    already fragment-major and M, N are taken from bias / stats)."""
     lib = load_library()
-    M, K = A.shape
-    N = W.shape[0]
-    out = torch.empty(M, N, device=A.device, dtype=torch.bfloat16)
+    if packed:
+        Af, Wf, M, N, K = A, W, int(A.shape[0]), int(bias.numel()), int(A.shape[1])
+        if stats is not None:
+            M = int(stats.shape[1])
+    else:
+        M, K = A.shape
+        N = W.shape[0]
+        Af, Wf = to_frag(A), to_frag(W)
+    out = torch.empty((M + 15) // 16 * 16 if frag_out else M, N, device=A.device, dtype=torch.bfloat16)
     strips = 0 if stats is None else int(stats.shape[0])
-    _ck(lib.gitmi_op_dgemm(A.data_ptr(), W.data_ptr(), bias.data_ptr(), _ptr(colsum), _ptr(stats), strips, eps,
-                           out.data_ptr(), M, N, K, act, _stream()))
-    return out
+    _ck(lib.gitmi_op_dgemm(Af.data_ptr(), Wf.data_ptr(), bias.data_ptr(), _ptr(colsum), _ptr(stats), strips, eps,
+                           out.data_ptr(), 1 if frag_out else 0, M, N, K, act, _stream()))
+    return from_frag(out, M) if (frag_out and not packed) else out
 
 
 def op_dgemm_res(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, res_x: torch.Tensor,
                  res_stats: Optional[torch.Tensor] = None, res_gamma: Optional[torch.Tensor] = None,
-                 res_beta: Optional[torch.Tensor] = None, res_eps: float = 1e-12):
+                 res_beta: Optional[torch.Tensor] = None, res_eps: float = 1e-12, packed: bool = False):
     """Decode-chain GEMM, N = hidden form: x = A W^T + bias + residual, where the residual is `res_x` itself or
     LayerNorm(res_x) rebuilt from its strip partials.  -> (x fp32 [M,N], bf16 copy, strip partials of x)."""
     lib = load_library()
-    M, K = A.shape
-    N = W.shape[0]
+    M, N = res_x.shape
+    K = A.shape[1]
+    Af, Wf = (A, W) if packed else (to_frag(A), to_frag(W))
     x = torch.empty(M, N, device=A.device, dtype=torch.float32)
-    xb = torch.empty(M, N, device=A.device, dtype=torch.bfloat16)
+    xb = torch.empty((M + 15) // 16 * 16, N, device=A.device, dtype=torch.bfloat16)
     st = torch.empty(N // 16, M, 2, device=A.device, dtype=torch.float32)
     strips = 0 if res_stats is None else int(res_stats.shape[0])
-    _ck(lib.gitmi_op_dgemm_res(A.data_ptr(), W.data_ptr(), bias.data_ptr(), res_x.data_ptr(), _ptr(res_stats), strips,
+    _ck(lib.gitmi_op_dgemm_res(Af.data_ptr(), Wf.data_ptr(), bias.data_ptr(), res_x.data_ptr(), _ptr(res_stats), strips,
                                _ptr(res_gamma), _ptr(res_beta), res_eps, x.data_ptr(), xb.data_ptr(), st.data_ptr(),
                                M, N, K, _stream()))
-    return x, xb, st
+    return x, (xb if packed else from_frag(xb, M)), st
 
 
 def op_vocab_topm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, mtop: int, cols_per_wg: int = 128,
                   colsum: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, eps: float = 1e-12,
-                  suppress_tok: Optional[torch.Tensor] = None, want_logits: bool = False):
+                  suppress_tok: Optional[torch.Tensor] = None, want_logits: bool = False, packed: bool = False,
+                  rows: Optional[int] = None, V: Optional[int] = None):
     """Vocabulary head with the fused running top-M / log-sum-exp: -> (part_val [M, nparts, slots], part_idx,
-    part_lse [M, nparts, 2] = (max, sum exp), logits [M, V] or None)."""
+    part_lse [M, nparts, 2] = (max, sum exp), logits [M, V] or None).  packed=True: A / W fragment-major (W rows and
+    bias / colsum padded to a multiple of cols_per_wg), `rows` = M, `V` = vocabulary size."""
     lib = load_library()
-    M, K = A.shape
-    V = W.shape[0]
+    K = A.shape[1]
+    V = int(bias.numel()) if V is None else int(V)
+    if packed:
+        Af, Wf, M, bp, cp = A, W, int(rows), bias, colsum
+    else:
+        M = A.shape[0]
+        Vp = (V + cols_per_wg - 1) // cols_per_wg * cols_per_wg
+        Af, Wf, bp, cp = to_frag(A), to_frag(W, cols_per_wg), _pad_vec(bias, Vp), _pad_vec(colsum, Vp)
     nparts = (V + cols_per_wg - 1) // cols_per_wg
     slots = 1 if mtop <= 1 else 2 if mtop <= 2 else 4 if mtop <= 4 else 8 if mtop <= 8 else 16
     pv = torch.empty(M, nparts, slots, device=A.device, dtype=torch.float32)
@@ -440,7 +480,7 @@ def op_vocab_topm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, mtop: in
     pl = torch.empty(M, nparts, 2, device=A.device, dtype=torch.float32)
     lg = torch.empty(M, V, device=A.device, dtype=torch.float32) if want_logits else None
     strips = 0 if stats is None else int(stats.shape[0])
-    _ck(lib.gitmi_op_vocab_topm(A.data_ptr(), W.data_ptr(), bias.data_ptr(), _ptr(colsum), _ptr(stats), strips, eps,
+    _ck(lib.gitmi_op_vocab_topm(Af.data_ptr(), Wf.data_ptr(), bp.data_ptr(), _ptr(cp), _ptr(stats), strips, eps,
                                 M, V, K, cols_per_wg, mtop, _ptr(suppress_tok), pv.data_ptr(), pi.data_ptr(),
                                 pl.data_ptr(), _ptr(lg), _stream()))
     return pv, pi, pl, lg

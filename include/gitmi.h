@@ -220,7 +220,12 @@ int  gitmi_op_layernorm(const float* x, const float* gamma, const float* beta, f
 int  gitmi_op_attention(const void* qkv, void* out, int B, int N, int H, int dtype, int impl,
                         void* stream);
 
-/* decode-step GEMM chain (kernels_dgemm.hip; bf16 A [M,K], W [N,K], K % 32 == 0).  The post-norm BERT layer
+/* decode-step GEMM chain (kernels_dgemm.hip; bf16 A [M,K], W [N,K], K % 32 == 0).  BOTH operands are FRAGMENT-MAJOR:
+ * 16-row x 32-k tiles in MFMA operand order, element (row, k) at
+ *     (((row/16)*(K/32) + k/32)*64 + ((k%32)/8)*16 + row%16)*8 + k%8,   rows padded to a multiple of 16
+ * (weights: zero rows; bias / colsum of the vocabulary head padded to a multiple of cols_per_wg), so that every
+ * fragment load of a wave is one contiguous 1-KiB read.  The engine repacks weights once and its kernels write
+ * activations in this order; xb_out and (with c_frag) C come out fragment-major too.  The post-norm BERT layer
  * (modeling_bert.py:171-178, 243-250) runs WITHOUT LayerNorm launches: the N = hidden GEMMs emit the pre-LayerNorm
  * sum and per-16-column-strip row partials (sum, sum of squares), the consumer GEMM folds the LayerNorm.
  * stats layout: fp32 [strips][M][2].
@@ -229,13 +234,13 @@ int  gitmi_op_attention(const void* qkv, void* out, int B, int N, int H, int dty
  *   gitmi_op_dgemm_res : x = A W^T + bias + r,  r = res_x (res_stats == NULL) or LayerNorm(res_x; res_gamma, res_beta)
  *                        rebuilt from res_stats; writes x fp32, its bf16 copy and stats_out [N/16][M][2].  N % 16 == 0. */
 int  gitmi_op_dgemm(const void* A, const void* W, const float* bias, const float* colsum, const float* stats,
-                    int strips, float eps, void* C, int M, int N, int K, int act, void* stream);
+                    int strips, float eps, void* C, int c_frag, int M, int N, int K, int act, void* stream);
 int  gitmi_op_dgemm_res(const void* A, const void* W, const float* bias, const float* res_x, const float* res_stats,
                         int res_strips, const float* res_gamma, const float* res_beta, float res_eps,
                         float* x_out, void* xb_out, float* stats_out, int M, int N, int K, void* stream);
 /* vocabulary head with the search's top-M and log-softmax statistics fused (replaces decoder.py:1054 + the
  * log_softmax/topk of :265-271, 358-366, 1169-1175): one workgroup sweeps cols_per_wg columns for all rows and writes
- * a sorted list of `slots` = {1,2,4,8,16} >= mtop (logit, token) pairs + (max, sum exp) per (row, workgroup):
+ * (64 or 128) a sorted list of `slots` = {1,2,4,8,16} >= mtop (logit, token) pairs + (max, sum exp) per (row, workgroup):
  * part_val/part_idx [M][ceil(V/cols_per_wg)][slots], part_lse [..][2].  suppress_tok int32 [M] (or NULL): that
  * token's logit counts as -10000 (decoder.py:330).  logits_out fp32 [M,V] optional.  K <= 768. */
 int  gitmi_op_vocab_topm(const void* A, const void* W, const float* bias, const float* colsum, const float* stats,

@@ -47,8 +47,8 @@ def graph_timeit(fn, n=100):
 gen = torch.Generator().manual_seed(0)
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 for name, (N, K, res) in {"qkv": (2304, 768, False), "ffn1": (3072, 768, False), "out": (768, 768, True), "ffn2": (768, 3072, True)}.items():
-    A = torch.randn(R, K, generator=gen).bfloat16().cuda()
-    W = (torch.randn(N, K, generator=gen) * K ** -0.5).bfloat16().cuda()
+    A = E.to_frag(torch.randn(R, K, generator=gen).bfloat16().cuda())
+    W = E.to_frag((torch.randn(N, K, generator=gen) * K ** -0.5).bfloat16().cuda())
     bias = torch.randn(N, generator=gen).cuda()
     x = torch.randn(R, K if not res else N, generator=gen).cuda()
     stats = E.strip_stats(x)
@@ -58,9 +58,9 @@ for name, (N, K, res) in {"qkv": (2304, 768, False), "ffn1": (3072, 768, False),
     for dbg in (0, 1, 2, 3, 4, 8, 15):
         lib.gitmi_debug_set_dgemm(dbg)
         if res:
-            fn = lambda: E.op_dgemm_res(A, W, bias, x, stats, gm, bt)
+            fn = lambda: E.op_dgemm_res(A, W, bias, x, stats, gm, bt, packed=True)
         else:
-            fn = lambda: E.op_dgemm(A, W, bias, cs, stats, 1e-12, 0)
+            fn = lambda: E.op_dgemm(A, W, bias, cs, stats, 1e-12, 0, packed=True)
         try:
             line.append("dbg%d %.2f" % (dbg, graph_timeit(fn)))
         except Exception as exc:
@@ -72,14 +72,16 @@ xx = torch.randn(64, 768).cuda(); g1 = torch.ones(768).cuda(); b1 = torch.zeros(
 print("layernorm64 %.2f" % graph_timeit(lambda: E.op_layernorm(xx, g1, b1, 1e-5)))
 # vocabulary head
 V, K = 30522, 768
-A = torch.randn(R, K, generator=gen).bfloat16().cuda()
-W = (torch.randn(V, K, generator=gen) * K ** -0.5).bfloat16().cuda()
-bias = torch.randn(V, generator=gen).cuda()
+A = E.to_frag(torch.randn(R, K, generator=gen).bfloat16().cuda())
+W = E.to_frag((torch.randn(V, K, generator=gen) * K ** -0.5).bfloat16().cuda(), 128)
+Vp = W.shape[0]
+bias = torch.zeros(Vp).cuda(); bias[:V] = torch.randn(V, generator=gen).cuda()
 x = torch.randn(R, K, generator=gen).cuda()
-stats = E.strip_stats(x); cs = torch.randn(V, generator=gen).cuda()
-for cols in (64, 128, 256):
+stats = E.strip_stats(x); cs = torch.zeros(Vp).cuda(); cs[:V] = torch.randn(V, generator=gen).cuda()
+for cols in (64, 128):
     for mtop in (1, 8):
-        print("vocab cols=%d mtop=%d  %.2f us" % (cols, mtop, graph_timeit(lambda: E.op_vocab_topm(A, W, bias, mtop, cols, cs, stats), n=30)), flush=True)
+        print("vocab cols=%d mtop=%d  %.2f us" % (cols, mtop, graph_timeit(
+            lambda: E.op_vocab_topm(A, W, bias, mtop, cols, cs, stats, packed=True, rows=R, V=V), n=30)), flush=True)
 # decode attention, 64 images x 12 heads x 197 keys
 B, H, N_img, T = R, 12, 197, 20
 d = H * 64
