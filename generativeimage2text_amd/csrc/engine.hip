@@ -133,6 +133,7 @@ struct gitmi_engine {
     long long* start_dev = nullptr;     // [max_batch][max_text_len] start tokens of every sentence
     int *plen_dev = nullptr, *img_of_dev = nullptr;
     bool img_identity = true;           // sentence b attends to image b
+    int attn_dbg = 0;                   // timing experiments (GITMI_ATTN_DBG)
     bool use_temb = true;               // add img_temperal_embedding[i] to frame i (the reference does so only for a LIST of frames)
     std::vector<int> plen_host, img_of_host;
     const float* const* frames_dummy = nullptr;
@@ -264,6 +265,7 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     e->Kp_pad = round_up(e->Kp, 64);
     if (const char* env = getenv("GITMI_ATTN_IMPL")) e->attn_impl = e->f32 ? 0 : atoi(env);
     if (const char* env = getenv("GITMI_GRAPH")) e->use_graph = atoi(env) != 0;
+    if (const char* env = getenv("GITMI_ATTN_DBG")) e->attn_dbg = atoi(env);
     if (const char* env = getenv("GITMI_SKINNY")) e->skinny = atoi(env) != 0;
     if (const char* env = getenv("GITMI_GEMM_IMPL")) set_gemm_impl(atoi(env));
     if (attn_decode_configure() != hipSuccess) { delete e; return fail("hipFuncSetAttribute failed"); }
@@ -412,8 +414,10 @@ static int alloc_workspaces(gitmi_engine* e) {
     e->txt_v.resize(c.dec_layers);
     for (int l = 0; l < c.dec_layers; ++l) {
         RCK(dev_alloc(e, &e->img_kv[l], Mp * 3 * d * esz));
-        RCK(dev_alloc(e, &e->img_kh[l], Mp * d * esz));
-        RCK(dev_alloc(e, &e->img_vh[l], Mp * d * esz));
+        // decode layout; bf16: per (image, head) keys padded to a multiple of 32 (kernels_attn_decode.hip)
+        const size_t Mkv = (size_t)c.max_batch * round_up(c.max_frames * e->Nmax, 32);
+        RCK(dev_alloc(e, &e->img_kh[l], Mkv * d * esz));
+        RCK(dev_alloc(e, &e->img_vh[l], Mkv * d * esz));
         RCK(dev_alloc(e, &e->txt_k[l], R * T * d * esz));
         RCK(dev_alloc(e, &e->txt_v[l], R * T * d * esz));
     }
@@ -771,6 +775,14 @@ static int encode_frames_impl(gitmi_engine* e, const float* const* frames, int F
     return 0;
 }
 
+// image K/V of layer l into the decode layout: head-major (fp32 VALU kernel) or the MFMA operand layouts (bf16)
+static int kv_repack(gitmi_engine* e, int l, int B, int Nimg, hipStream_t s) {
+    const gitmi_config& c = e->cfg;
+    if (e->f32) HIPCK(launch_kv_repack(e->img_kv[l], e->img_kh[l], e->img_vh[l], B, Nimg, c.dec_heads, c.dec_hidden, true, s));
+    else HIPCK(launch_kv_repack_frag(e->img_kv[l], e->img_kh[l], e->img_vh[l], B, Nimg, round_up(Nimg, 32), c.dec_heads, c.dec_hidden, s));
+    return 0;
+}
+
 static int prefill_impl(gitmi_engine* e, hipStream_t s) {
     const gitmi_config& c = e->cfg;
     const int d = c.dec_hidden, ffn = c.dec_ffn, D = c.vit_width;
@@ -783,12 +795,12 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
         const bool last = l + 1 == c.dec_layers;
         if (!last) {
             RCK(gemm(e, s, e->p_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->img_kv[l], 3 * d, e->f32, M, 3 * d, d, 0, TAG_GEMM_OTHER));
-            HIPCK(launch_kv_repack(e->img_kv[l], e->img_kh[l], e->img_vh[l], B, Nimg, c.dec_heads, d, e->f32, s));
+            RCK(kv_repack(e, l, B, Nimg, s));
         } else {
             // the last layer's image-row outputs are never consumed: only its K and V are needed
             RCK(gemm(e, s, e->p_ht, d, (char*)L.wqkv + (size_t)d * d * e->esz, L.bqkv + d, nullptr, 0,
                      (char*)e->img_kv[l] + (size_t)d * e->esz, 3 * d, e->f32, M, 2 * d, d, 0, TAG_GEMM_OTHER));
-            HIPCK(launch_kv_repack(e->img_kv[l], e->img_kh[l], e->img_vh[l], B, Nimg, c.dec_heads, d, e->f32, s));
+            RCK(kv_repack(e, l, B, Nimg, s));
             break;
         }
         AttnFullArgs a{};
@@ -851,7 +863,10 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
         a.img_of = e->img_identity ? nullptr : e->img_of_dev;
         a.pos = pos; a.beams = beams; a.scale = 0.125f;
         a.out_frag = chain ? 1 : 0;
-        HIPCK(launch_attn_decode(a, B, c.dec_heads, e->f32, s));
+        a.N_pad = round_up(e->cur_Nimg, 32);
+        a.dbg = e->attn_dbg;
+        if (e->f32) HIPCK(launch_attn_decode(a, B, c.dec_heads, true, s));
+        else HIPCK(launch_attn_decode_mfma(a, B, c.dec_heads, s));
         if (chain) {
             DGemmArgs o{};
             o.A = (const unsigned short*)e->d_ctx; o.lda = d; o.W = (const unsigned short*)L.wo_p; o.bias = L.bo;
@@ -1438,8 +1453,19 @@ extern "C" int gitmi_op_attn_decode(const void* qkv, const void* img_k, const vo
     a.qkv = qkv; a.img_k = img_k; a.img_v = img_v; a.txt_k = txt_k; a.txt_v = txt_v; a.out = out;
     a.kv_src = kv_src; a.ld_src = T_max; a.d = H * 64; a.N_img = N_img; a.T_max = T_max; a.pos = pos; a.beams = beams;
     a.scale = 0.125f; a.dbg = dbg;
-    if (attn_decode_configure() != hipSuccess) return fail("configure failed");
-    HIPCK(launch_attn_decode(a, B, H, dtype == GITMI_DTYPE_F32, (hipStream_t)stream));
+    if (dtype == GITMI_DTYPE_F32) {
+        HIPCK(launch_attn_decode(a, B, H, true, (hipStream_t)stream));
+        return 0;
+    }
+    // bf16: img_k / img_v are the MFMA operand layouts written by gitmi_op_kv_repack (keys padded to 32)
+    a.N_pad = round_up(N_img, 32);
+    HIPCK(launch_attn_decode_mfma(a, B, H, (hipStream_t)stream));
+    return 0;
+}
+// image-row K/V of the prefill ([B*N, 3*H*64] packed q|k|v, bf16) -> the decode layouts of kernels_attn_decode.hip:
+// kf, vt: [B][H][round_up(N, 32)][64] each
+extern "C" int gitmi_op_kv_repack(const void* qkv_rows, void* kf, void* vt, int B, int N, int H, void* stream) {
+    HIPCK(launch_kv_repack_frag(qkv_rows, kf, vt, B, N, round_up(N, 32), H, H * 64, (hipStream_t)stream));
     return 0;
 }
 

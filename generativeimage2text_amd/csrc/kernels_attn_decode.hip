@@ -1,0 +1,382 @@
+// Decode attention on the matrix cores (bf16): one new text position per beam row against
+// [image K/V shared by all beams of a sentence | that beam's text K/V] -- BertSelfAttention for the appended row
+// (modeling_bert.py:41-47, 122-159) with the image rows' K/V cached once per image.
+//
+// The image part is the bulk (197 keys at 224 px, 1182 for 6 video frames) and identical for every beam, so it runs as
+// two tiny MFMA products per 32-key step,  S = Q K^T  (16 beam rows x 32 keys, K = 64 dims)  and  O += P V  (16 rows x
+// 64 dims, K = 32 keys), with the softmax in between in registers.  The scalar formulation this replaces spent
+// ~1500 VALU instructions per wave on dot products and shuffles: 6.6 of its 8.9 us per launch were arithmetic, not
+// memory (profiles/r02_a_decode_kernel_ablation.txt, dbg1).
+//
+// Cache layouts (written once per generate by kv_repack_frag_kernel), per (image, head), keys padded to 32 with zeros:
+//   K  : fragment-major [key tile of 16][dim step of 32][lane][8]: a wave's K operand of one MFMA is ONE contiguous
+//        1-KiB read (lane = (dim%32)/8*16 + key%16 holds 8 consecutive dims of its key);
+//   V^T: [key step of 32][dim tile of 16][lane][8], lane = lg*16 + dim%16; the 8 contraction slots of lane group lg hold
+//        keys  32s + lg*4 + {0,1,2,3}  and  32s + 16 + lg*4 + {0,1,2,3}  -- exactly the 8 scores that lane already holds
+//        in the accumulators of the two S tiles of the step, so P goes from the S accumulators into the P V operand
+//        WITHOUT any cross-lane movement or LDS round trip.
+// A workgroup serves two heads with two waves each; a wave keeps (max, sum, O) per beam row for its half of the keys.
+// The text keys differ per beam (histories are re-ordered by index, kv_src) and are few (<= max_text_len): they keep the
+// 8-lanes-per-key scalar path and are folded into the wave's partial before the two halves are combined.
+#include "gitmi_common.h"
+#include "launchers.h"
+
+namespace gitmi {
+
+static constexpr int HD = 64;
+
+// grid = (key steps, H, B); block = 256.  qkv: prefill layout [B*N, 3d] (q|k|v); one workgroup repacks the K and V of
+// one (image, head, 32-key step).
+__global__ __launch_bounds__(256) void kv_repack_frag_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kf,
+                                                             bf16_t* __restrict__ vt, int N, int Np, int H, int d) {
+    __shared__ bf16_t vs[32][HD + 8];          // the step's V tile [key][dim], padded rows
+    const int s = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int nsteps = Np >> 5;
+    bf16_t* kdst = kf + ((size_t)b * H + h) * Np * HD;
+    bf16_t* vdst = vt + ((size_t)b * H + h) * Np * HD;
+    // 32 keys x 64 dims = 256 chunks of 8: thread -> (key, chunk)
+    const int key = tid >> 3, ch = tid & 7;
+    const int n = s * 32 + key;
+    u32x4_t kv = {0u, 0u, 0u, 0u}, vv = kv;
+    if (n < N) {
+        const bf16_t* src = qkv + ((size_t)b * N + n) * 3 * d + d + h * HD + ch * 8;
+        kv = *reinterpret_cast<const u32x4_t*>(src);
+        vv = *reinterpret_cast<const u32x4_t*>(src + d);
+    }
+    // K: fragment-major, rows = keys, 2 dim steps: element (key n, dim c*8..) -> tile n/16, step c/4, lane (c%4)*16 + n%16
+    *reinterpret_cast<u32x4_t*>(kdst + frag_tile(n >> 4, ch >> 2, 2, (ch & 3) * 16 + (n & 15))) = kv;
+    *reinterpret_cast<u32x4_t*>(&vs[key][ch * 8]) = vv;
+    __syncthreads();
+    // V^T: 4 dim tiles x 64 lanes chunks of 8 keys (permuted slots, see header): thread -> (dim tile, lane)
+    const int dt = tid >> 6, lane = tid & 63, lg = lane >> 4, dim = dt * 16 + (lane & 15);
+    bf16_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = vs[(e >> 2) * 16 + lg * 4 + (e & 3)][dim];
+    u32x4_t ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = (uint32_t)o[2 * e] | ((uint32_t)o[2 * e + 1] << 16);
+    *reinterpret_cast<u32x4_t*>(vdst + (((size_t)s * 4 + dt) * 64 + lane) * 8) = ov;
+}
+
+__device__ __forceinline__ void ld8bf(const bf16_t* p, float (&v)[8]) {
+    const u32x4_t r = *reinterpret_cast<const u32x4_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(r[i] << 16);
+        v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+    }
+}
+
+// grid = (H, sentences); block = 128 = the 2 waves of one head (768 workgroups at B = 64: three per CU, evenly -- pairing
+// two heads per workgroup left half the CUs with twice the K/V to ingest).  The two waves split the key steps (even / odd)
+// and its text items; each wave requests ALL of its image K/V fragments (up to 4 steps = 32 sixteen-byte loads per
+// lane) in its first instructions, computes every score tile, does ONE max / exp pass and then the P V products; the two
+// halves meet once in LDS.  KB >= beams (1, 2, 4 or 8); TI: text items per 8-lane group loaded up front.
+constexpr int ACS = 4;          // key steps per chunk and wave
+
+template <int KB, int TI = 3>
+__global__ __launch_bounds__(128) void attn_decode_mfma_kernel(AttnDecodeArgs a) {
+    __shared__ float part[1][2][KB][HD + 2];      // [half][beam]: o[64], m, l
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int hp = 0, half = wave & 1;             // half of the head's keys
+    const int h = blockIdx.x, b = blockIdx.y, H = a.d / HD;
+    const bool head_on = true;
+    const int k = a.beams;                       // k <= KB <= 8 < 16 MFMA rows
+    const bf16_t* QKV = reinterpret_cast<const bf16_t*>(a.qkv);
+    bf16_t* TK = reinterpret_cast<bf16_t*>(a.txt_k);
+    bf16_t* TV = reinterpret_cast<bf16_t*>(a.txt_v);
+    bf16_t* O = reinterpret_cast<bf16_t*>(a.out);
+    const int ld3 = 3 * a.d;
+    const int row0 = b * k;
+    const int bi = a.img_of ? a.img_of[b] : b;   // sentence -> image (several questions per image)
+    const int Np = a.N_pad, nsteps = Np >> 5;
+    const int hh = head_on ? h : 0;
+    const bf16_t* Kf = reinterpret_cast<const bf16_t*>(a.img_k) + ((size_t)bi * H + hh) * Np * HD;
+    const bf16_t* Vt = reinterpret_cast<const bf16_t*>(a.img_v) + ((size_t)bi * H + hh) * Np * HD;
+
+    // ---- image K/V of this wave's first chunk: requested before anything else (the longest latency) ---------------
+    const int nimg_steps = (!head_on || (a.dbg & 1)) ? 0 : nsteps;
+    bf16x8_t kq[ACS][2][2], vq[ACS][4];
+    auto load_chunk = [&](int s0) {              // steps s0, s0 + 2, ... (this half's parity)
+#pragma unroll
+        for (int c = 0; c < ACS; ++c) {
+            const int s = s0 + 2 * c;
+            const bool on = s < nimg_steps && !(a.dbg & 8);
+            const bf16_t* kp = Kf + frag_tile(2 * s, 0, 2, lane);            // the step's 4 KiB of K, then of V^T: contiguous
+            const bf16_t* vp = Vt + ((size_t)s * 4 * 64 + lane) * 8;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ds = 0; ds < 2; ++ds) {
+                    const bf16x8_t* p = reinterpret_cast<const bf16x8_t*>(kp + (t * 2 + ds) * 512);
+                    kq[c][t][ds] = !on ? bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0} : (a.dbg & 16) ? *p : __builtin_nontemporal_load(p);
+                }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8_t* p = reinterpret_cast<const bf16x8_t*>(vp + dt * 512);
+                vq[c][dt] = !on ? bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0} : (a.dbg & 16) ? *p : __builtin_nontemporal_load(p);
+            }
+        }
+    };
+    load_chunk(half);
+
+    // ---- text items: the 16 eight-lane groups of the head's two waves share them ----------------------------------
+    const int grp = (tid & 127) >> 3, sub = tid & 7;
+    const int nt = a.pos + 1;
+    int t_j[TI], t_s[TI];
+    u32x4_t tkr[TI], tvr[TI];
+#pragma unroll
+    for (int u = 0; u < TI; ++u) {
+        const int it = grp + 16 * u;
+        t_j[u] = (head_on && it < k * nt) ? it / nt : -1;
+        t_s[u] = it < k * nt ? it % nt : 0;
+        tkr[u] = u32x4_t{0u, 0u, 0u, 0u};
+        tvr[u] = tkr[u];
+        if (t_j[u] >= 0) {
+            if (t_s[u] == a.pos) {
+                const bf16_t* src = QKV + (size_t)(row0 + t_j[u]) * ld3 + a.d + h * HD + sub * 8;
+                tkr[u] = *reinterpret_cast<const u32x4_t*>(src);
+                tvr[u] = *reinterpret_cast<const u32x4_t*>(src + a.d);
+            } else {
+                // one beam: histories are never re-ordered, the cache row is the row itself (no dependent index load)
+                const int srow = KB == 1 ? row0 : a.kv_src[(size_t)(row0 + t_j[u]) * a.ld_src + t_s[u]];
+                const size_t off = ((size_t)srow * a.T_max + t_s[u]) * a.d + h * HD + sub * 8;
+                tkr[u] = *reinterpret_cast<const u32x4_t*>(TK + off);
+                tvr[u] = *reinterpret_cast<const u32x4_t*>(TV + off);
+            }
+        }
+    }
+    // append this position's K/V of every beam to the text cache (16-byte copies by the first k*8 threads of the head)
+    if (head_on && (tid & 127) < k * 8) {
+        const int j = (tid & 127) >> 3;
+        const bf16_t* src = QKV + (size_t)(row0 + j) * ld3 + a.d + h * HD + sub * 8;
+        const size_t dst = ((size_t)(row0 + j) * a.T_max + a.pos) * a.d + h * HD + sub * 8;
+        *reinterpret_cast<u32x4_t*>(TK + dst) = *reinterpret_cast<const u32x4_t*>(src);
+        *reinterpret_cast<u32x4_t*>(TV + dst) = *reinterpret_cast<const u32x4_t*>(src + a.d);
+    }
+
+    // ---- image part on the matrix cores -------------------------------------------------------------------------
+    // Q operand: lane (row = l15, lg) holds dims ds*32 + lg*8 .. +8 of beam row l15, pre-scaled by 1/8 (exact in bf16)
+    bf16x8_t qf[2];
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+        float qv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (head_on && l15 < k) ld8bf(QKV + (size_t)(row0 + l15) * ld3 + h * HD + ds * 32 + lg * 8, qv);
+        u32x4_t t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = pack2bf(qv[2 * e] * a.scale, qv[2 * e + 1] * a.scale);
+        qf[ds] = __builtin_bit_cast(bf16x8_t, t);
+    }
+    float m_i = -INFINITY, l_i = 0.f;            // running max / (per-lane partial) sum of beam row l15
+    f32x4_t oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int s0 = half; s0 < nimg_steps; s0 += 2 * ACS) {
+        if (s0 != half) load_chunk(s0);                    // later chunks (long image sequences: video, VQA resolutions)
+        // every score tile of the chunk: lane (row l15, lg) holds keys 32s + t*16 + lg*4 + r
+        f32x4_t sc[ACS][2];
+        float cm = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < ACS; ++c) {
+            const int s = s0 + 2 * c;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                sc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kq[c][t][0], qf[0], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                sc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kq[c][t][1], qf[1], sc[c][t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (s * 32 + t * 16 + lg * 4 + r >= a.N_img || s >= nimg_steps) sc[c][t][r] = -INFINITY;   // padded keys / steps
+                    cm = fmaxf(cm, sc[c][t][r]);
+                }
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+        cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+        const float mn = fmaxf(m_i, cm);                   // the chunk's first step holds >= 1 real key: mn is finite
+        if (s0 != half) {
+            const float al = fast_exp(m_i - mn);
+            l_i *= al;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { oacc[dt][0] *= al; oacc[dt][1] *= al; oacc[dt][2] *= al; oacc[dt][3] *= al; }
+        }
+        m_i = mn;
+#pragma unroll
+        for (int c = 0; c < ACS; ++c) {
+            float p[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[t * 4 + r] = fast_exp(sc[c][t][r] - mn);    // exp(-inf) = 0 for padded keys
+                    l_i += p[t * 4 + r];
+                }
+            u32x4_t pp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pp[e] = pack2bf(p[2 * e], p[2 * e + 1]);
+            const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pp);
+            if (a.dbg & 4) {      // timing experiment: no P V product
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) asm volatile("" ::"v"(vq[c][dt]));
+                asm volatile("" ::"v"(pf));
+                continue;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vq[c][dt], pf, oacc[dt], 0, 0, 0);
+        }
+    }
+    l_i += __shfl_xor(l_i, 16, 64);
+    l_i += __shfl_xor(l_i, 32, 64);
+
+    // ---- text keys (beam-specific): 8 lanes per key, online update -------------------------------------------------
+    float q[KB][8], m[KB], l[KB], o[KB][8];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        m[j] = -INFINITY;
+        l[j] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { q[j][e] = 0.f; o[j][e] = 0.f; }
+        if (head_on && j < k) {
+            ld8bf(QKV + (size_t)(row0 + j) * ld3 + h * HD + sub * 8, q[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[j][e] *= a.scale;
+        }
+    }
+    auto dot8 = [&](const float (&x)[8], const float (&y)[8]) {
+        float p = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p += x[e] * y[e];
+        p += __shfl_xor(p, 1, 64);
+        p += __shfl_xor(p, 2, 64);
+        p += __shfl_xor(p, 4, 64);
+        return p;                                   // all 8 lanes of the group hold the 64-dim dot product
+    };
+    auto text_item = [&](int jj, const float (&kv)[8], const float (&vv)[8]) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            if (j == jj) {                              // uniform within the 8-lane group
+                const float sv = dot8(q[j], kv);
+                const float mn = fmaxf(m[j], sv);
+                const float al = fast_exp(m[j] - mn);
+                const float p = fast_exp(sv - mn);
+                l[j] = l[j] * al + p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[j][e] = o[j][e] * al + p * vv[e];
+                m[j] = mn;
+            }
+        }
+    };
+    auto unpack = [&](const u32x4_t& r, float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(r[i] << 16);
+            v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < TI; ++u) {
+        if (t_j[u] >= 0 && !(a.dbg & 2)) {
+            float kv[8], vv[8];
+            unpack(tkr[u], kv);
+            unpack(tvr[u], vv);
+            text_item(t_j[u], kv, vv);
+        }
+    }
+    if (head_on) {
+        for (int it = grp + 16 * TI; it < k * nt; it += 16) {   // long texts: dependent-load path
+            const int j = it / nt, sidx = it % nt;
+            float kv[8], vv[8];
+            if (sidx == a.pos) {
+                ld8bf(QKV + (size_t)(row0 + j) * ld3 + a.d + h * HD + sub * 8, kv);
+                ld8bf(QKV + (size_t)(row0 + j) * ld3 + 2 * a.d + h * HD + sub * 8, vv);
+            } else {
+                const int srow = KB == 1 ? row0 : a.kv_src[(size_t)(row0 + j) * a.ld_src + sidx];
+                ld8bf(TK + ((size_t)srow * a.T_max + sidx) * a.d + h * HD + sub * 8, kv);
+                ld8bf(TV + ((size_t)srow * a.T_max + sidx) * a.d + h * HD + sub * 8, vv);
+            }
+            text_item(j, kv, vv);
+        }
+    }
+    // merge the 8 groups of the wave (lanes with equal `sub`): lanes 0..7 end up with the wave's text partial (m, l, o[8])
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            const float m2 = __shfl_xor(m[j], off, 64);
+            const float l2 = __shfl_xor(l[j], off, 64);
+            const float mn = fmaxf(m[j], m2);
+            const float a1 = m[j] == -INFINITY ? 0.f : fast_exp(m[j] - mn);
+            const float a2 = m2 == -INFINITY ? 0.f : fast_exp(m2 - mn);
+            l[j] = l[j] * a1 + l2 * a2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float o2 = __shfl_xor(o[j][e], off, 64);
+                o[j][e] = o[j][e] * a1 + o2 * a2;
+            }
+            m[j] = mn;
+        }
+    }
+    // ---- this wave's partial per beam row = its image keys + its text items, published to LDS ----------------------
+    // image part: lane (row l15 < k, lg) holds dims dt*16 + lg*4 + r; text part: lanes 0..7 hold dims sub*8 + e of row j
+    if (l15 < k) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[hp][half][l15][dt * 16 + lg * 4 + r] = oacc[dt][r];
+        if (lg == 0) { part[hp][half][l15][HD] = m_i; part[hp][half][l15][HD + 1] = l_i; }
+    }
+    __syncthreads();
+    // fold the text partial of this wave into its slot (lanes 0..7, one beam row at a time), then combine the halves
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        if (lane < 8 && j < k) {
+            const float mi = part[hp][half][j][HD], li = part[hp][half][j][HD + 1];
+            const float mn = fmaxf(mi, m[j]);
+            const float a1 = mi == -INFINITY ? 0.f : fast_exp(mi - mn);
+            const float a2 = m[j] == -INFINITY ? 0.f : fast_exp(m[j] - mn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part[hp][half][j][sub * 8 + e] = part[hp][half][j][sub * 8 + e] * a1 + o[j][e] * a2;
+            if (sub == 0) { part[hp][half][j][HD] = mn; part[hp][half][j][HD + 1] = li * a1 + l[j] * a2; }
+        }
+    }
+    __syncthreads();
+    if (!head_on) return;
+    for (int i = tid & 127; i < k * HD; i += 128) {
+        const int j = i / HD, dd = i % HD;
+        const float m0 = part[hp][0][j][HD], m1 = part[hp][1][j][HD];
+        const float mm = fmaxf(m0, m1);
+        const float a0 = m0 == -INFINITY ? 0.f : fast_exp(m0 - mm);
+        const float a1 = m1 == -INFINITY ? 0.f : fast_exp(m1 - mm);
+        const float num = a0 * part[hp][0][j][dd] + a1 * part[hp][1][j][dd];
+        const float den = a0 * part[hp][0][j][HD + 1] + a1 * part[hp][1][j][HD + 1];
+        const float r = num / den;
+        if (a.out_frag) O[frag_offset(row0 + j, h * HD + dd, a.d >> 5)] = f2bf(r);
+        else O[(size_t)(row0 + j) * a.d + h * HD + dd] = f2bf(r);
+    }
+}
+
+// ---- host launchers ------------------------------------------------------------------
+hipError_t launch_kv_repack_frag(const void* qkv, void* kf, void* vt, int B, int N, int N_pad, int H, int d, hipStream_t s) {
+    if (B <= 0 || N <= 0) return hipSuccess;
+    if (N_pad % 32 || N_pad < N) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kv_repack_frag_kernel, dim3(N_pad / 32, H, B), dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)kf,
+                       (bf16_t*)vt, N, N_pad, H, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_decode_mfma(const AttnDecodeArgs& a, int B, int H, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (a.beams > 8 || a.N_pad % 32 || a.N_pad < a.N_img || a.N_img < 1) return hipErrorInvalidValue;
+    const dim3 grid(H, B);
+    if (a.beams <= 1) hipLaunchKernelGGL((attn_decode_mfma_kernel<1>), grid, dim3(128), 0, s, a);
+    else if (a.beams <= 2) hipLaunchKernelGGL((attn_decode_mfma_kernel<2>), grid, dim3(128), 0, s, a);
+    else if (a.beams <= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<4>), grid, dim3(128), 0, s, a);
+    else hipLaunchKernelGGL((attn_decode_mfma_kernel<8>), grid, dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace gitmi

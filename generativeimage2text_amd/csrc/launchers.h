@@ -89,6 +89,7 @@ struct AttnDecodeArgs {
     int ld_src;
     int d;
     int N_img, T_max, pos, beams;
+    int N_pad;           // MFMA kernel (bf16): image keys padded to a multiple of 32; img_k / img_v in the layouts of kv_repack_frag
     int out_frag;        // write `out` in the fragment-major operand layout of the decode chain (bf16)
     float scale;
     int dbg;             // timing experiments: 1 skip image K/V loads, 2 skip scores, 4 skip PV
@@ -96,6 +97,9 @@ struct AttnDecodeArgs {
 hipError_t launch_kv_repack(const void* qkv, void* kh, void* vh, int B, int N, int H, int d, bool is_f32, hipStream_t s);
 size_t attn_decode_lds_bytes(int beams, int N_img, int pos);
 hipError_t launch_attn_decode(const AttnDecodeArgs& a, int B, int H, bool is_f32, hipStream_t s);
+// bf16 decode attention on the matrix cores (kernels_attn_decode.hip) and its cache layouts
+hipError_t launch_kv_repack_frag(const void* qkv, void* kf, void* vt, int B, int N, int N_pad, int H, int d, hipStream_t s);
+hipError_t launch_attn_decode_mfma(const AttnDecodeArgs& a, int B, int H, hipStream_t s);
 hipError_t attn_decode_configure();
 
 struct SearchState {

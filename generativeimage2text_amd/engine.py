@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_search_finish", "gitmi_profile_enable", "gitmi_profile_read", "gitmi_set_graph",
     "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_dgemm", "gitmi_op_dgemm_res",
     "gitmi_op_vocab_topm", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
-    "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding",
+    "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack",
 ]
 
 
@@ -105,6 +105,7 @@ def load_library() -> C.CDLL:
     lib.gitmi_preprocess_image_to.argtypes = [vp, i32, i32, i32, i32, vp, C.c_size_t, vp, vp]
     lib.gitmi_set_image_shape.argtypes = [vp, i32, i32, vp]
     lib.gitmi_op_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.gitmi_op_kv_repack.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     for name in EXPORTED_SYMBOLS:
         if name not in ("gitmi_last_error", "gitmi_destroy"):
             getattr(lib, name).restype = C.c_int
@@ -496,10 +497,28 @@ def op_attn_decode(qkv, img_k, img_v, txt_k, txt_v, kv_src, B, H, N_img, T_max, 
     lib = load_library()
     R, d = B * beams, H * 64
     out = torch.empty(R, d, device=qkv.device, dtype=qkv.dtype)
+    if qkv.dtype == torch.bfloat16 and img_k.dim() == 4:
+        # head-major [B,H,N,64] given: build the prefill-layout rows and repack into the matrix-core layouts
+        img_k, img_v = kv_repack(img_k, img_v)
     _ck(lib.gitmi_op_attn_decode(qkv.data_ptr(), img_k.data_ptr(), img_v.data_ptr(), txt_k.data_ptr(), txt_v.data_ptr(),
                                  kv_src.data_ptr(), out.data_ptr(), B, H, N_img, T_max, pos, beams, _torch_dtype_code(qkv),
                                  dbg, _stream()))
     return out
+
+
+def kv_repack(img_k: torch.Tensor, img_v: torch.Tensor):
+    """Head-major bf16 image K/V [B,H,N,64] -> the decode layouts of kernels_attn_decode.hip (flat [B*H*Npad*64] each)."""
+    lib = load_library()
+    B, H, N, _ = img_k.shape
+    d = H * 64
+    rows = torch.zeros(B * N, 3 * d, device=img_k.device, dtype=torch.bfloat16)
+    rows[:, d:2 * d] = img_k.permute(0, 2, 1, 3).reshape(B * N, d)
+    rows[:, 2 * d:] = img_v.permute(0, 2, 1, 3).reshape(B * N, d)
+    Np = (N + 31) // 32 * 32
+    kf = torch.empty(B * H * Np * 64, device=img_k.device, dtype=torch.bfloat16)
+    vt = torch.empty(B * H * Np * 64, device=img_k.device, dtype=torch.bfloat16)
+    _ck(lib.gitmi_op_kv_repack(rows.data_ptr(), kf.data_ptr(), vt.data_ptr(), B, N, H, _stream()))
+    return kf, vt
 
 
 def preprocess_image(rgb_hwc: torch.Tensor, crop: int = 224) -> torch.Tensor:

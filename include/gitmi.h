@@ -248,12 +248,18 @@ int  gitmi_op_vocab_topm(const void* A, const void* W, const float* bias, const 
                          const int* suppress_tok, float* part_val, int* part_idx, float* part_lse,
                          float* logits_out, void* stream);
 
-/* decode attention for one new text position (unit parity / timing): qkv [R,3d] (R = B*beams), image K/V
- * head-major [B][H][N_img][64], text caches [R][T_max][d] (position `pos` is appended), kv_src int32 [R][T_max],
- * out [R,d].  dbg: 0, or timing-experiment bits (results undefined). */
+/* decode attention for one new text position (unit parity / timing): qkv [R,3d] (R = B*beams), text caches
+ * [R][T_max][d] (position `pos` is appended), kv_src int32 [R][T_max], out [R,d].
+ *   fp32 : image K/V head-major [B][H][N_img][64] (scalar kernel);
+ *   bf16 : image K/V in the matrix-core operand layouts written by gitmi_op_kv_repack (keys padded to 32).
+ * dbg: 0, or timing-experiment bits of the fp32 kernel (results undefined). */
 int  gitmi_op_attn_decode(const void* qkv, const void* img_k, const void* img_v, void* txt_k, void* txt_v,
                           const int* kv_src, void* out, int B, int H, int N_img, int T_max, int pos, int beams,
                           int dtype, int dbg, void* stream);
+/* bf16 image-row K/V of the decoder prefill ([B*N, 3*H*64] packed q|k|v) -> decode layouts kf / vt, each
+ * [B][H][round_up(N,32)][64]: K fragment-major (a wave's MFMA operand is one contiguous 1-KiB read), V transposed with
+ * the key slots ordered so that softmax probabilities feed the P V product without leaving their registers. */
+int  gitmi_op_kv_repack(const void* qkv_rows, void* kf, void* vt, int B, int N, int H, void* stream);
 
 /* GPU-side image transform == get_image_transform(param) of the reference (inference.py:111-132):
  * Resize(crop, BICUBIC) -> CenterCrop(crop) -> ToTensor -> Normalize(CLIP mean/std), bit-exact with the

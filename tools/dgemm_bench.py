@@ -89,5 +89,8 @@ qkv = torch.randn(B, 3 * d, generator=gen).bfloat16().cuda()
 ik = torch.randn(B, H, N_img, 64, generator=gen).bfloat16().cuda(); iv = torch.randn(B, H, N_img, 64, generator=gen).bfloat16().cuda()
 tk = torch.randn(B, T, d, generator=gen).bfloat16().cuda(); tv = torch.randn(B, T, d, generator=gen).bfloat16().cuda()
 src = torch.arange(B, dtype=torch.int32)[:, None].repeat(1, T).cuda()
-for dbg in (0, 1, 2, 4, 7):
-    print("attn_decode dbg%d %.2f us" % (dbg, graph_timeit(lambda: E.op_attn_decode(qkv, ik, iv, tk, tv, src, B, H, N_img, T, 9, 1, dbg), n=50)), flush=True)
+kf, vt = E.kv_repack(ik, iv)
+for dbg in (0, 0, 1, 2, 3, 4, 8, 12):
+    print("attn_decode (matrix cores, bf16) dbg%d %.2f us" % (dbg, graph_timeit(lambda: E.op_attn_decode(qkv, kf, vt, tk, tv, src, B, H, N_img, T, 9, 1, dbg), n=50)), flush=True)
+q32, ik32, iv32, tk32, tv32 = qkv.float(), ik.float(), iv.float(), tk.float(), tv.float()
+print("attn_decode (scalar, fp32)       %.2f us" % graph_timeit(lambda: E.op_attn_decode(q32, ik32, iv32, tk32, tv32, src, B, H, N_img, T, 9, 1), n=50), flush=True)
