@@ -133,7 +133,7 @@ struct gitmi_engine {
     long long* start_dev = nullptr;     // [max_batch][max_text_len] start tokens of every sentence
     int *plen_dev = nullptr, *img_of_dev = nullptr;
     bool img_identity = true;           // sentence b attends to image b
-    int attn_dbg = 0;                   // timing experiments (GITMI_ATTN_DBG)
+    int attn_dbg = 0, dgemm_dbg = 0;    // timing experiments (GITMI_ATTN_DBG, GITMI_DGEMM_DBG)
     bool use_temb = true;               // add img_temperal_embedding[i] to frame i (the reference does so only for a LIST of frames)
     std::vector<int> plen_host, img_of_host;
     const float* const* frames_dummy = nullptr;
@@ -151,6 +151,10 @@ struct gitmi_engine {
     hipGraphExec_t graph_exec_b = nullptr;
     bool graph_is_split = false;
     hipEvent_t gev[3] = {nullptr, nullptr, nullptr};
+    // serving schedule: this context's image encoder starts only after `enc_after`'s has finished (at most one encoder
+    // in flight on the device; decode chains of the other contexts fill in beside it)
+    gitmi_engine* enc_after = nullptr;
+    hipEvent_t enc_done = nullptr;
     double split_encode_ms = 0, split_decode_ms = 0;
     int split_calls = 0, split_steps = 0;
     std::vector<TimedSpan> spans;
@@ -266,6 +270,7 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     if (const char* env = getenv("GITMI_ATTN_IMPL")) e->attn_impl = e->f32 ? 0 : atoi(env);
     if (const char* env = getenv("GITMI_GRAPH")) e->use_graph = atoi(env) != 0;
     if (const char* env = getenv("GITMI_ATTN_DBG")) e->attn_dbg = atoi(env);
+    if (const char* env = getenv("GITMI_DGEMM_DBG")) e->dgemm_dbg = atoi(env);
     if (const char* env = getenv("GITMI_SKINNY")) e->skinny = atoi(env) != 0;
     if (const char* env = getenv("GITMI_GEMM_IMPL")) set_gemm_impl(atoi(env));
     if (attn_decode_configure() != hipSuccess) { delete e; return fail("hipFuncSetAttribute failed"); }
@@ -293,6 +298,7 @@ extern "C" void gitmi_destroy(gitmi_engine* e) {
     if (e->fence_out) hipEventDestroy(e->fence_out);
     for (auto ev : e->gev)
         if (ev) hipEventDestroy(ev);
+    if (e->enc_done) hipEventDestroy(e->enc_done);
     for (auto ev : e->event_pool) hipEventDestroy(ev);
     for (void* p : e->allocs) hipFree(p);
     delete e;
@@ -830,7 +836,9 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
 // f32 (parity mode): generic GEMM + LayerNorm launches, materialised logits, row_topm.
 // Input: the embedded token rows in d_hf (fp32) / d_ht (compute dtype), written by embed_ln or by the previous
 // search step.  logits_out != nullptr additionally materialises the logits [R, ldl] (teacher-forced parity hook).
-static int dgemm(gitmi_engine* e, hipStream_t s, const DGemmArgs& g) {
+static int dgemm(gitmi_engine* e, hipStream_t s, const DGemmArgs& g_in) {
+    DGemmArgs g = g_in;
+    g.dbg = e->dgemm_dbg;
     SpanGuard sp(e, s, TAG_GEMM_OTHER, 2.0 * (double)g.M * (double)g.N * (double)g.K);
     HIPCK(launch_dgemm(g, s));
     return 0;
@@ -1172,7 +1180,7 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     key.B = B; key.Q = Q; key.F = F_eff; key.P = minP; key.kind = sp->kind; key.k = sp->beam_size; key.pn = sp->per_node_beam_size;
     key.T = sp->max_steps; key.H = e->H; key.W = e->W; key.lp = sp->length_penalty;
     key.ragged = ragged ? 1 : 0; key.ident = e->img_identity ? 1 : 0; key.temb = e->use_temb ? 1 : 0;
-    const bool split = e->profile_mode == 2;
+    const bool split = e->profile_mode == 2 || e->enc_after != nullptr || e->enc_done != nullptr;
     if (!e->graph_valid || !(key == e->graph_key) || split != e->graph_is_split) {
         destroy_graph(e);
         std::vector<const float*> fp(F_eff);
@@ -1199,8 +1207,7 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
             HIPCK(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
             RCK(capture(2, &e->graph_b));
             HIPCK(hipGraphInstantiate(&e->graph_exec_b, e->graph_b, nullptr, nullptr, 0));
-            for (auto& ev : e->gev)
-                if (!ev) HIPCK(hipEventCreate(&ev));
+
         }
         e->graph_key = key;
         e->graph_valid = true;
@@ -1212,7 +1219,14 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     }
     if (!split) {
         HIPCK(hipGraphLaunch(e->graph_exec, x));
+    } else if (e->profile_mode != 2) {
+        if (e->enc_after && e->enc_after->enc_done) HIPCK(hipStreamWaitEvent(x, e->enc_after->enc_done, 0));
+        HIPCK(hipGraphLaunch(e->graph_exec, x));
+        if (e->enc_done) HIPCK(hipEventRecord(e->enc_done, x));
+        HIPCK(hipGraphLaunch(e->graph_exec_b, x));
     } else {
+        for (auto& ev : e->gev)
+            if (!ev) HIPCK(hipEventCreate(&ev));
         HIPCK(hipEventRecord(e->gev[0], x));
         HIPCK(hipGraphLaunch(e->graph_exec, x));
         HIPCK(hipEventRecord(e->gev[1], x));
@@ -1300,6 +1314,19 @@ extern "C" int gitmi_profile_enable(gitmi_engine* e, int on) {
     e->event_next = 0;
     return 0;
 }
+// Serving schedule for several contexts on one device: `e`'s image encoder (+ decoder prefill) of a gitmi_generate call
+// starts only after the encoder of `after`'s most recently submitted call has finished; the decode steps are not
+// ordered.  Chain the contexts in a ring in submission order: at most one MFMA-bound encoder runs at a time and the
+// latency-bound decode chains of the other contexts fill in beside it.  after == NULL removes the dependency.
+extern "C" int gitmi_set_encode_after(gitmi_engine* e, gitmi_engine* after) {
+    if (!e) return fail("null engine");
+    HIPCK(hipSetDevice(e->device));
+    e->enc_after = after;
+    if (!e->enc_done) HIPCK(hipEventCreateWithFlags(&e->enc_done, hipEventDisableTiming));
+    if (after && !after->enc_done) HIPCK(hipEventCreateWithFlags(&after->enc_done, hipEventDisableTiming));
+    return 0;
+}
+
 // CaptioningModel.forward_one adds img_temperal_embedding[i] only when batch['image'] is a LIST of frames
 // (decoder.py:845-857); a bare tensor goes through image_encoder alone, also on a video model.
 extern "C" int gitmi_set_temporal_embedding(gitmi_engine* e, int on) {

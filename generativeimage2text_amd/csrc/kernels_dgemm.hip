@@ -136,7 +136,8 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs g) {
         bf16x8_t wf[U], xf[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!(g.dbg & 2)) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)(k0 + u) * 512));
+            if (g.dbg & 16) wf[u] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)(k0 + u) * 512);      // A/B: cacheable weight loads
+            else if (!(g.dbg & 2)) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)(k0 + u) * 512));
             else wf[u] = bf16x8_t{1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
             for (int i = 0; i < MT; ++i) {

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_search_finish", "gitmi_profile_enable", "gitmi_profile_read", "gitmi_set_graph",
     "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_dgemm", "gitmi_op_dgemm_res",
     "gitmi_op_vocab_topm", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
-    "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack",
+    "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after",
 ]
 
 
@@ -91,6 +91,7 @@ def load_library() -> C.CDLL:
     lib.gitmi_profile_read.argtypes = [vp, C.POINTER(GitmiProfile)]
     lib.gitmi_set_graph.argtypes = [vp, i32]
     lib.gitmi_set_temporal_embedding.argtypes = [vp, i32]
+    lib.gitmi_set_encode_after.argtypes = [vp, vp]
     lib.gitmi_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_attention.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
@@ -343,6 +344,11 @@ class Engine:
         p = GitmiProfile()
         _ck(self.lib.gitmi_profile_read(self._h, C.byref(p)))
         return p.as_dict()
+
+    def set_encode_after(self, other: Optional["Engine"]) -> None:
+        """Serving schedule: this context's image encoder starts only after `other`'s (most recently submitted) has
+        finished; chain contexts in a ring in submission order (one encoder in flight, decode chains fill in)."""
+        _ck(self.lib.gitmi_set_encode_after(self._h, other._h if other is not None else None))
 
     def set_temporal_embedding(self, on: bool) -> None:
         """on (default): frames come as a list -> frame i gets img_temperal_embedding[i]; off: a bare image tensor

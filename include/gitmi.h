@@ -121,6 +121,12 @@ int  gitmi_finalize_weights(gitmi_engine* e);
  * `src` must outlive the clone; destroy clones with gitmi_destroy. */
 int  gitmi_clone(gitmi_engine* src, gitmi_engine** out);
 
+/* serving schedule for several contexts of one device: the image encoder (+ decoder prefill) of `e`'s gitmi_generate
+ * calls starts only after the encoder of `after`'s most recently submitted call has finished (decode steps are not
+ * ordered).  Chain contexts in a ring in submission order so that one MFMA-bound encoder runs at a time while the
+ * latency-bound decode chains of the other contexts fill in beside it.  after = NULL: no dependency. */
+int  gitmi_set_encode_after(gitmi_engine* e, gitmi_engine* after);
+
 /* ---- input resolution of the following encode/generate calls (default: image_size x image_size).
  * Replaces the run-time branch of VisualTransformer.forward for inputs that are not the native
  * resolution (CLIP/model.py:243-251): the token grid becomes (H / patch) x (W / patch) -- the stride-patch

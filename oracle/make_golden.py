@@ -194,7 +194,7 @@ def run_case(name: str):
 FULL_CASES = {
     "full_bench_b64_greedy": ("GIT_BASE", ("bench", 1234, -5.0), 64, 1, O.GREEDY),                           # cfg2 exactly as benchmarked
     "full_base_b64_greedy": ("GIT_BASE", dict(seed=1240, tie_output=False, successor=1.0), 64, 1, O.GREEDY),  # cfg2, perturbed LN affines / biases
-    "full_base_b64_beam4": ("GIT_BASE", dict(seed=1241, tie_output=False, successor=4.0, eos_bias=12.0), 64, 1, O.BEAM4),   # cfg3
+    "full_base_b64_beam4": ("GIT_BASE", dict(seed=1241, tie_output=False, successor=4.0, eos_bias=10.5), 64, 1, O.BEAM4),   # cfg3
     "full_large_b32_greedy": ("GIT_LARGE", ("bench", 1242, -5.0), 32, 1, O.GREEDY),                          # cfg4 per GPU
     "full_vatex_b16_greedy": ("GIT_BASE_VATEX", ("bench", 1243, -5.0), 16, 6, O.GREEDY),                     # cfg5
 }
