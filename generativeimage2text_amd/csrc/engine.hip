@@ -133,6 +133,7 @@ struct gitmi_engine {
     long long* start_dev = nullptr;     // [max_batch][max_text_len] start tokens of every sentence
     int *plen_dev = nullptr, *img_of_dev = nullptr;
     bool img_identity = true;           // sentence b attends to image b
+    gitmi_search sample{};              // sampling parameters of the current search (do_sample, top_k, top_p, temperature, seed)
     int attn_dbg = 0, dgemm_dbg = 0;    // timing experiments (GITMI_ATTN_DBG, GITMI_DGEMM_DBG)
     bool use_temb = true;               // add img_temperal_embedding[i] to frame i (the reference does so only for a LIST of frames)
     std::vector<int> plen_host, img_of_host;
@@ -166,8 +167,9 @@ struct gitmi_engine {
     // hipGraph cache for gitmi_generate
     struct GraphKey {
         int B, Q, F, P, kind, k, pn, T, H, W, ragged, ident, temb; double lp;
+        int smp, top_k; double top_p, temp; unsigned long long seed;
         bool operator==(const GraphKey& o) const {
-            return B == o.B && Q == o.Q && F == o.F && P == o.P && kind == o.kind && k == o.k && pn == o.pn && T == o.T &&
+            return smp == o.smp && top_k == o.top_k && top_p == o.top_p && temp == o.temp && seed == o.seed && B == o.B && Q == o.Q && F == o.F && P == o.P && kind == o.kind && k == o.k && pn == o.pn && T == o.T &&
                    H == o.H && W == o.W && ragged == o.ragged && ident == o.ident && temb == o.temb && lp == o.lp;
         }
     };
@@ -906,6 +908,8 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
     return 0;
 }
 
+static int sample_candidates(gitmi_engine* e, const float* logits, int ldl, int R, int step, hipStream_t s, StepCands* cands);
+
 // vocabulary head of the step: candidate lists for the search (and optionally the logits themselves)
 static int decode_head_impl(gitmi_engine* e, const int* ids, int ld_ids, int cur_len, int R, int beams, int suppress_kind,
                             int M, float* logits_out, int ldl, hipStream_t s, StepCands* cands) {
@@ -913,6 +917,8 @@ static int decode_head_impl(gitmi_engine* e, const int* ids, int ld_ids, int cur
     const int d = c.dec_hidden;
     const bool chain = e->skinny && !e->f32;
     cands->part_val = e->part_val; cands->part_idx = e->part_idx; cands->part_lse = e->part_lse;
+    const bool sampling = ids != nullptr && e->ss.sampled;
+    if (sampling && !logits_out) { logits_out = e->logits; ldl = e->ldl; }     // the filter needs the whole row
     if (chain) {
         const DecLayerW& L = e->dec[c.dec_layers - 1];
         (void)L;
@@ -928,13 +934,15 @@ static int decode_head_impl(gitmi_engine* e, const int* ids, int ld_ids, int cur
             HIPCK(launch_vocab_topm(v, M, s));
         }
         cands->nparts = e->vocab_nparts; cands->slots = vocab_mtop_slots(M);
+        if (sampling) RCK(sample_candidates(e, logits_out, ldl, R, cur_len, s, cands));
     } else {
         RCK(gemm(e, s, e->d_ht, d, e->out_w, e->out_b, nullptr, 0, e->logits, e->ldl, true, R, c.vocab, d, 0, TAG_GEMM_OTHER));
-        if (ids)
+        cands->nparts = 1; cands->slots = row_topm_slots(M);
+        if (sampling) RCK(sample_candidates(e, e->logits, e->ldl, R, cur_len, s, cands));
+        else if (ids)
             HIPCK(launch_row_topm(e->logits, e->ldl, c.vocab, ids, ld_ids, cur_len, e->plen_dev, beams, suppress_kind, M, R,
                                   e->part_val, e->part_idx, e->part_lse, s));
-        if (logits_out) HIPCK(launch_copy_f32(e->logits, e->ldl, logits_out, ldl, R, c.vocab, s));
-        cands->nparts = 1; cands->slots = row_topm_slots(M);
+        if (logits_out && logits_out != e->logits) HIPCK(launch_copy_f32(e->logits, e->ldl, logits_out, ldl, R, c.vocab, s));
     }
     return 0;
 }
@@ -1003,11 +1011,18 @@ static int search_begin_impl(gitmi_engine* e, const gitmi_search* sp, int B, int
     if (sp->max_steps > c.max_text_len) return fail("search: max_steps %d exceeds max_text_len %d", sp->max_steps, c.max_text_len);
     if (minP < 1 || maxP > sp->max_steps) return fail("search: prefix lengths [%d,%d] outside [1,max_steps]", minP, maxP);
     if (sp->kind == GITMI_SEARCH_GENERATOR && !(sp->length_penalty > 0)) return fail("search: length_penalty must be > 0");
+    if (sp->do_sample) {
+        if (sp->kind != GITMI_SEARCH_GENERATOR) return fail("search: do_sample is implemented for GeneratorWithBeamSearch (decoder.py:1146-1166) only");
+        if (sp->temperature < 0) return fail("search: temperature must be > 0");
+        if (V > 32768) return fail("search: sampling supports vocabularies up to 32768 tokens");
+    }
     SearchState& st = e->ss;
     st.B = B; st.k = sp->beam_size; st.pn = sp->per_node_beam_size;
     st.T = sp->max_steps;           // max_length of the search AND the row stride of ids/kv_src/hyp_tok
     st.V = V; st.eos = c.eos; st.kind = sp->kind; st.length_penalty = sp->length_penalty;
     st.ragged = ragged ? 1 : 0;
+    st.sampled = sp->do_sample ? 1 : 0;
+    e->sample = *sp;
     st.start = e->start_dev; st.ld_start = c.max_text_len; st.plen = e->plen_dev;
     e->ss_cur = 0; e->ss_len = minP; e->ss_minP = minP;
     HIPCK(launch_search_init(st, s));
@@ -1015,7 +1030,18 @@ static int search_begin_impl(gitmi_engine* e, const gitmi_search* sp, int B, int
 }
 
 static int search_mtop(const SearchState& st) {
+    if (st.sampled) return st.pn;
     return st.kind == GITMI_SEARCH_AUTOREGRESSIVE ? std::max(st.k, st.pn) : st.pn * st.k;
+}
+// sampling branch: filter + draws from the materialised logits of the step (decoder.py:1146-1166)
+static int sample_candidates(gitmi_engine* e, const float* logits, int ldl, int R, int step, hipStream_t s, StepCands* cands) {
+    const gitmi_search& sp = e->sample;
+    const float temp = sp.temperature > 0 ? (float)sp.temperature : 1.0f;
+    HIPCK(launch_sample_rows(logits, ldl, e->ss.V, R, temp, sp.top_k, (float)sp.top_p, e->ss.pn, sp.seed, step,
+                             e->part_val, e->part_idx, e->part_lse, nullptr, s));
+    cands->part_val = e->part_val; cands->part_idx = e->part_idx; cands->part_lse = e->part_lse;
+    cands->nparts = 1; cands->slots = e->ss.pn;
+    return 0;
 }
 
 static EmbedArgs embed_args(gitmi_engine* e, bool on) {
@@ -1076,9 +1102,11 @@ extern "C" int gitmi_search_advance(gitmi_engine* e, const float* logits, void* 
     const SearchState& st = e->ss;
     hipStream_t s = (hipStream_t)stream;
     const int M = search_mtop(st), R = st.B * st.k;
-    HIPCK(launch_row_topm(logits, st.V, st.V, st.ids[e->ss_cur], st.T, e->ss_len, e->plen_dev, st.k,
-                          st.kind == GITMI_SEARCH_AUTOREGRESSIVE ? 1 : 0, M, R, e->part_val, e->part_idx, e->part_lse, s));
     StepCands cands{e->part_val, e->part_idx, e->part_lse, 1, row_topm_slots(M)};
+    if (st.sampled) RCK(sample_candidates(e, logits, st.V, R, e->ss_len, s, &cands));
+    else
+        HIPCK(launch_row_topm(logits, st.V, st.V, st.ids[e->ss_cur], st.T, e->ss_len, e->plen_dev, st.k,
+                              st.kind == GITMI_SEARCH_AUTOREGRESSIVE ? 1 : 0, M, R, e->part_val, e->part_idx, e->part_lse, s));
     return search_step_impl(e, cands, false, s);
 }
 
@@ -1180,6 +1208,7 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     key.B = B; key.Q = Q; key.F = F_eff; key.P = minP; key.kind = sp->kind; key.k = sp->beam_size; key.pn = sp->per_node_beam_size;
     key.T = sp->max_steps; key.H = e->H; key.W = e->W; key.lp = sp->length_penalty;
     key.ragged = ragged ? 1 : 0; key.ident = e->img_identity ? 1 : 0; key.temb = e->use_temb ? 1 : 0;
+    key.smp = sp->do_sample; key.top_k = sp->top_k; key.top_p = sp->top_p; key.temp = sp->temperature; key.seed = sp->seed;
     const bool split = e->profile_mode == 2 || e->enc_after != nullptr || e->enc_done != nullptr;
     if (!e->graph_valid || !(key == e->graph_key) || split != e->graph_is_split) {
         destroy_graph(e);
@@ -1465,6 +1494,21 @@ extern "C" int gitmi_op_vocab_topm(const void* A, const void* W, const float* bi
     v.part_val = part_val; v.part_idx = part_idx; v.part_lse = (float2*)part_lse;
     v.logits_out = logits_out; v.ld_logits = V;
     HIPCK(launch_vocab_topm(v, mtop, (hipStream_t)stream));
+    return 0;
+}
+
+// one step of the sampling branch on caller-supplied logits [R, V] (decoder.py:1146-1166): filtered logits (optional),
+// ndraw draws per row in draw order and their log-probabilities under the filtered softmax
+extern "C" int gitmi_op_sample_rows(const float* logits, int R, int V, float temperature, int top_k, float top_p, int ndraw,
+                                    uint64_t seed, int step, float* draw_logprob, int* draw_token, float* filtered_out,
+                                    void* stream) {
+    float2* lse = nullptr;
+    HIPCK(hipMalloc((void**)&lse, (size_t)R * sizeof(float2)));
+    hipError_t err = launch_sample_rows(logits, V, V, R, temperature, top_k, top_p, ndraw, seed, step, draw_logprob, draw_token,
+                                        lse, filtered_out, (hipStream_t)stream);
+    if (err == hipSuccess) err = hipStreamSynchronize((hipStream_t)stream);
+    hipFree(lse);
+    HIPCK(err);
     return 0;
 }
 

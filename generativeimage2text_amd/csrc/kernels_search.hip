@@ -142,6 +142,191 @@ __global__ __launch_bounds__(NT) void row_topm_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
+// Sampling branch of GeneratorWithBeamSearch.search (decoder.py:1146-1166) for one row per workgroup:
+//   x = logits / temperature
+//   top_k_top_p_filtering(x, top_k, top_p, min_tokens_to_keep = 2)   (decoder.py:1343-1375)
+//       top-k : remove x < (k-th largest x), k = min(max(top_k, 2), V)
+//       top-p : in descending order, remove token i when the cumulative softmax mass of the tokens BEFORE it exceeds
+//               top_p (the first token that crosses the threshold is kept); the flags of the first two are cleared
+//               BEFORE the shift by one (decoder.py:1364-1369), so the first THREE positions always survive
+//   draws     : `ndraw` tokens without replacement from softmax(filtered) -- Gumbel-top-k: the ndraw largest
+//               log p_j + G_j, G_j = -log(-log u_j), u_j from a counter-based hash of (seed, step, row, j), in that order
+//   output    : log_softmax(filtered)[draw]
+// Both filters are thresholds on x, found by bit-wise bisection over an order-preserving integer image of the floats
+// (32 counting / mass passes over the row held in registers) -- no sort of the 30522 logits.
+constexpr int SMP_NT = 1024, SMP_PER = 32;          // up to 32768 tokens per row
+
+__device__ __forceinline__ unsigned int f2key(float f) {      // monotone: a < b  <=>  key(a) < key(b)
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ unsigned int mix32(unsigned int x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+template <typename T> __device__ __forceinline__ T block_sum_1024(T v, T* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    T t = 0;
+#pragma unroll
+    for (int w = 0; w < SMP_NT / 64; ++w) t += sh[w];
+    return t;
+}
+
+__global__ __launch_bounds__(SMP_NT) void sample_rows_kernel(const float* __restrict__ logits, int ldl, int V,
+                                                             float inv_temp, int top_k, float top_p, int ndraw,
+                                                             unsigned int seed_lo, unsigned int seed_hi, int step,
+                                                             float* __restrict__ part_val, int* __restrict__ part_idx,
+                                                             float2* __restrict__ part_lse, float* __restrict__ filtered_out) {
+    __shared__ float sh_f[SMP_NT / 64];
+    __shared__ int sh_i[SMP_NT / 64];
+    __shared__ float s_bv[SMP_NT / 64];
+    __shared__ int s_bi[SMP_NT / 64];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = logits + (size_t)r * ldl;
+    float xv[SMP_PER];
+    unsigned int key[SMP_PER];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SMP_PER; ++i) {
+        const int j = tid + i * SMP_NT;
+        xv[i] = j < V ? x[j] * inv_temp : -INFINITY;
+        key[i] = j < V ? f2key(xv[i]) : 0u;
+        mx = fmaxf(mx, xv[i]);
+    }
+    // ---- top-k threshold: the largest key T with count(key >= T) >= kk  (= key of the kk-th largest) ------------------
+    unsigned int thr = 0u;                           // keep key >= thr
+    const int kk = top_k > 0 ? min(max(top_k, 2), V) : 0;
+    if (kk > 0) {
+        unsigned int T = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned int cand = T | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < SMP_PER; ++i) c += (key[i] >= cand && key[i] != 0u) ? 1 : 0;
+            if (block_sum_1024<int>(c, sh_i) >= kk) T = cand;
+        }
+        thr = T;
+    }
+    // ---- softmax of what survived top-k ---------------------------------------------------------------------------
+    mx = wave_max(mx);
+    __syncthreads();
+    if (lane == 0) sh_f[wave] = mx;
+    __syncthreads();
+    float bmx = sh_f[0];
+#pragma unroll
+    for (int w = 1; w < SMP_NT / 64; ++w) bmx = fmaxf(bmx, sh_f[w]);
+    float ev[SMP_PER];
+    float es = 0.f;
+#pragma unroll
+    for (int i = 0; i < SMP_PER; ++i) {
+        ev[i] = (key[i] != 0u && key[i] >= thr) ? __expf(xv[i] - bmx) : 0.f;
+        es += ev[i];
+    }
+    const float tot_k = block_sum_1024<float>(es, sh_f);
+    // ---- top-p threshold: keep token i iff the mass of the tokens ranked strictly before it is <= top_p ---------------
+    // (plus the first two).  P(T) := mass(key > T) <= top_p * total is monotone in T; T* = largest T with P false; keep key > T*.
+    if (top_p > 0.f && top_p < 1.f) {
+        const float lim = top_p * tot_k;
+        unsigned int T = 0u;
+        bool any_false = false;
+        {
+            float m0 = 0.f;
+#pragma unroll
+            for (int i = 0; i < SMP_PER; ++i) m0 += key[i] > 0u ? ev[i] : 0.f;
+            any_false = block_sum_1024<float>(m0, sh_f) > lim;           // P(0) false?
+        }
+        if (any_false) {
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned int cand = T | (1u << bit);
+                float m = 0.f;
+#pragma unroll
+                for (int i = 0; i < SMP_PER; ++i) m += key[i] > cand ? ev[i] : 0.f;
+                if (block_sum_1024<float>(m, sh_f) > lim) T = cand;      // P(cand) false
+            }
+            unsigned int thr_p = T + 1u;                                   // keep key > T*
+            // min_tokens_to_keep = 2, cleared before the shift: never above the key of the THIRD largest survivor
+            unsigned int T2 = 0u;
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned int cand = T2 | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int i = 0; i < SMP_PER; ++i) c += (key[i] >= cand && key[i] >= thr && key[i] != 0u) ? 1 : 0;
+                if (block_sum_1024<int>(c, sh_i) >= 3) T2 = cand;
+            }
+            thr_p = min(thr_p, T2);
+            thr = max(thr, thr_p);
+        }
+    }
+    // ---- filtered distribution: log-sum-exp over the kept tokens ------------------------------------------------------
+    float ks = 0.f;
+#pragma unroll
+    for (int i = 0; i < SMP_PER; ++i) {
+        const bool keep = key[i] != 0u && key[i] >= thr;
+        if (!keep) ev[i] = 0.f;
+        ks += ev[i];
+        if (filtered_out) {
+            const int j = tid + i * SMP_NT;
+            if (j < V) filtered_out[(size_t)r * V + j] = keep ? xv[i] : -INFINITY;
+        }
+    }
+    const float lse = bmx + logf(block_sum_1024<float>(ks, sh_f));
+    // ---- ndraw draws without replacement: the largest (log p + Gumbel) keys, one block arg-max per draw ---------------
+    float gk[SMP_PER];
+#pragma unroll
+    for (int i = 0; i < SMP_PER; ++i) {
+        const int j = tid + i * SMP_NT;
+        if (ev[i] > 0.f) {
+            unsigned int h = mix32(seed_lo ^ mix32((unsigned int)j + 0x9e3779b9u * (unsigned int)(step + 1)));
+            h = mix32(h ^ seed_hi ^ (0x85ebca6bu * (unsigned int)(r + 1)));
+            const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);       // (0, 1)
+            gk[i] = (xv[i] - lse) - logf(-logf(u));
+        } else {
+            gk[i] = -INFINITY;
+        }
+    }
+    if (tid == 0) part_lse[r] = float2{0.f, 1.f};            // candidate values are log-probabilities already
+    for (int d = 0; d < ndraw; ++d) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < SMP_PER; ++i)
+            if (gk[i] > bv) { bv = gk[i]; bi = tid + i * SMP_NT; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { s_bv[wave] = bv; s_bi[wave] = bi; }
+        __syncthreads();
+        bv = s_bv[0]; bi = s_bi[0];
+#pragma unroll
+        for (int w = 1; w < SMP_NT / 64; ++w)
+            if (s_bv[w] > bv || (s_bv[w] == bv && s_bi[w] < bi)) { bv = s_bv[w]; bi = s_bi[w]; }
+        // the owner of the winner publishes its log-probability and retires the token
+#pragma unroll
+        for (int i = 0; i < SMP_PER; ++i) {
+            if (tid + i * SMP_NT == bi) {
+                part_val[(size_t)r * ndraw + d] = xv[i] - lse;
+                part_idx[(size_t)r * ndraw + d] = bi;
+                gk[i] = -INFINITY;
+            }
+        }
+        if (bi == 0x7fffffff && tid == 0) {       // fewer kept tokens than draws (cannot happen with min_tokens_to_keep = 2 <= ndraw ...)
+            part_val[(size_t)r * ndraw + d] = -INFINITY;
+            part_idx[(size_t)r * ndraw + d] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Host arithmetic of the reference is Python double -> double here (decoder.py:1310-1341).
 __device__ __forceinline__ double length_norm(int len, double alpha) {
     return pow(5.0 + (double)len, alpha) / pow(6.0, alpha);
@@ -176,7 +361,7 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
     const int P = st.plen[b];
     const bool forced = cur_len < P;                       // still inside this sentence's prefix
     const bool first = cur_len == P;                       // first search step of this sentence
-    const int M = st.kind == 0 ? (first ? k : pn) : pn * k;        // candidates needed per row
+    const int M = st.kind == 0 ? (first ? k : pn) : (st.sampled ? pn : pn * k);   // candidates needed per row
 
     if (tid == 0) s_hyp_row = -1;
 
@@ -291,21 +476,29 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
             int headp[SS_KMAX];
             for (int j = 0; j < k; ++j) headp[j] = 0;
             float n_score[SS_CMAX * 2]; int n_beam[SS_CMAX * 2], n_word[SS_CMAX * 2];
+            float n_max = -INFINITY;
             for (int c = 0; c < ncand; ++c) {
-                float best = 0.f; int bj = -1; long long bflat = 0;
-                for (int j = 0; j < k; ++j) {
-                    if (headp[j] >= M) continue;
-                    const float v = c_val[j][headp[j]] + st.score[src][b * k + j];
-                    const long long flat = (long long)j * V + c_idx[j][headp[j]];
-                    if (bj < 0 || v > best || (v == best && flat < bflat)) { best = v; bj = j; bflat = flat; }
+                if (st.sampled) {
+                    // sampling branch (decoder.py:1155-1166): the per_node draws of beam 0, then of beam 1, ... in draw order
+                    const int j = c / pn, d = c % pn;
+                    n_score[c] = c_val[j][d] + st.score[src][b * k + j]; n_beam[c] = j; n_word[c] = c_idx[j][d];
+                } else {
+                    float best = 0.f; int bj = -1; long long bflat = 0;
+                    for (int j = 0; j < k; ++j) {
+                        if (headp[j] >= M) continue;
+                        const float v = c_val[j][headp[j]] + st.score[src][b * k + j];
+                        const long long flat = (long long)j * V + c_idx[j][headp[j]];
+                        if (bj < 0 || v > best || (v == best && flat < bflat)) { best = v; bj = j; bflat = flat; }
+                    }
+                    n_score[c] = best; n_beam[c] = bj; n_word[c] = c_idx[bj][headp[bj]];
+                    headp[bj]++;
                 }
-                n_score[c] = best; n_beam[c] = bj; n_word[c] = c_idx[bj][headp[bj]];
-                headp[bj]++;
+                n_max = fmaxf(n_max, n_score[c]);
             }
             int is_done = st.done[b];
             if (!is_done && st.hyp_n[b] >= 1) {
                 // BeamHypotheses.is_done(max next score); self.max_length = max_length - 1
-                is_done = st.hyp_score[b] >= (double)n_score[0] / length_norm(T - 1, st.length_penalty);
+                is_done = st.hyp_score[b] >= (double)n_max / length_norm(T - 1, st.length_penalty);
             }
             if (is_done && !st.done[b]) atomicAdd(&st.info[0], 1);
             st.done[b] = is_done;
@@ -533,6 +726,17 @@ hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, 
     else if (M <= 8) GITMI_TOPM(8, 512);
     else GITMI_TOPM(16, 256);
 #undef GITMI_TOPM
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_rows(const float* logits, int ldl, int V, int R, float temperature, int top_k, float top_p,
+                              int ndraw, unsigned long long seed, int step, float* part_val, int* part_idx,
+                              float2* part_lse, float* filtered_out, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    if (V > SMP_NT * SMP_PER || V < 2 || ndraw < 1 || ndraw > SS_CMAX || !(temperature > 0.f)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sample_rows_kernel, dim3(R), dim3(SMP_NT), 0, s, logits, ldl, V, 1.0f / temperature, top_k, top_p, ndraw,
+                       (unsigned int)(seed & 0xffffffffu), (unsigned int)(seed >> 32), step, part_val, part_idx, part_lse,
+                       filtered_out);
     return hipGetLastError();
 }
 

@@ -105,6 +105,7 @@ hipError_t attn_decode_configure();
 struct SearchState {
     int B, k, pn, T, V, eos, kind;      // B sentences of k beams; T = max_steps = row stride of ids / kv_src / hyp_tok
     int ragged;                         // 1: every sentence stands for its own batch-1 reference call (own prefix)
+    int sampled;                        // GENERATOR sampling branch: candidates arrive as per_node draws per beam, in draw order
     double length_penalty;
     const long long* start;             // [B][ld_start] start tokens of every sentence (its prefix, or [CLS])
     int ld_start;
@@ -133,6 +134,13 @@ struct EmbedArgs {
     int frag;            // h_t in the fragment-major operand layout of the decode chain
 };
 int row_topm_slots(int M);
+// sampling branch (decoder.py:1146-1166, 1343-1375): per row scores / temperature -> top-k / top-p filter (min 2 tokens
+// kept) -> `ndraw` draws without replacement (Gumbel-top-k on a counter-based generator) -> their log-probabilities under
+// the filtered softmax, in draw order, as one candidate list per row (part_lse = (0, 1): values are log-probs already).
+// filtered_out (optional): the filtered logits [R, V] (-inf = removed) for parity checks.
+hipError_t launch_sample_rows(const float* logits, int ldl, int V, int R, float temperature, int top_k, float top_p,
+                              int ndraw, unsigned long long seed, int step, float* part_val, int* part_idx,
+                              float2* part_lse, float* filtered_out, hipStream_t s);
 hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, int ld_ids, int cur_len,
                            const int* plen, int beams, int suppress_kind, int M, int R, float* part_val,
                            int* part_idx, float2* part_lse, hipStream_t s);

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_search_finish", "gitmi_profile_enable", "gitmi_profile_read", "gitmi_set_graph",
     "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_dgemm", "gitmi_op_dgemm_res",
     "gitmi_op_vocab_topm", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
-    "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after",
+    "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after", "gitmi_op_sample_rows",
 ]
 
 
@@ -40,7 +40,9 @@ class GitmiConfig(C.Structure):
 
 class GitmiSearch(C.Structure):
     _fields_ = [("kind", C.c_int32), ("beam_size", C.c_int32), ("per_node_beam_size", C.c_int32),
-                ("max_steps", C.c_int32), ("length_penalty", C.c_double)]
+                ("max_steps", C.c_int32), ("length_penalty", C.c_double),
+                ("do_sample", C.c_int32), ("top_k", C.c_int32), ("top_p", C.c_double), ("temperature", C.c_double),
+                ("seed", C.c_uint64)]
 
 
 class GitmiProfile(C.Structure):
@@ -107,10 +109,11 @@ def load_library() -> C.CDLL:
     lib.gitmi_set_image_shape.argtypes = [vp, i32, i32, vp]
     lib.gitmi_op_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_kv_repack.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    lib.gitmi_op_sample_rows.argtypes = [vp, i32, i32, C.c_float, i32, C.c_float, i32, C.c_uint64, i32, vp, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:
         if name not in ("gitmi_last_error", "gitmi_destroy"):
             getattr(lib, name).restype = C.c_int
-    if lib.gitmi_abi_version() != 3:
+    if lib.gitmi_abi_version() != 4:
         raise GitmiError("libgitmi.so ABI version mismatch")
     _lib = lib
     return lib
@@ -249,11 +252,14 @@ class Engine:
 
     @staticmethod
     def make_search(kind: str, max_steps: int, beam_size: int, per_node_beam_size: int,
-                    length_penalty: float = 1.0) -> GitmiSearch:
+                    length_penalty: float = 1.0, do_sample: bool = False, top_k: int = 0, top_p: float = 1.0,
+                    temperature: float = 1.0, seed: int = 0) -> GitmiSearch:
         s = GitmiSearch()
         s.kind = SEARCH_AUTOREGRESSIVE if kind in ("greedy", "autoregressive") else SEARCH_GENERATOR
         s.beam_size, s.per_node_beam_size, s.max_steps = int(beam_size), int(per_node_beam_size), int(max_steps)
         s.length_penalty = float(length_penalty)
+        s.do_sample, s.top_k, s.top_p = int(bool(do_sample)), int(top_k or 0), float(1.0 if top_p is None else top_p)
+        s.temperature, s.seed = float(temperature), int(seed)
         return s
 
     def generate(self, frames: Sequence[torch.Tensor], search: GitmiSearch,
@@ -510,6 +516,21 @@ def op_attn_decode(qkv, img_k, img_v, txt_k, txt_v, kv_src, B, H, N_img, T_max, 
                                  kv_src.data_ptr(), out.data_ptr(), B, H, N_img, T_max, pos, beams, _torch_dtype_code(qkv),
                                  dbg, _stream()))
     return out
+
+
+def op_sample_rows(logits: torch.Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, ndraw: int = 2,
+                   seed: int = 0, step: int = 1, want_filtered: bool = True):
+    """One step of the sampling branch (decoder.py:1146-1166) on fp32 logits [R, V]:
+    -> (filtered logits [R, V] or None, draw tokens int32 [R, ndraw], their log-probs fp32 [R, ndraw])."""
+    lib = load_library()
+    logits = logits.float().contiguous()
+    R, V = logits.shape
+    lp = torch.empty(R, ndraw, device=logits.device, dtype=torch.float32)
+    tok = torch.empty(R, ndraw, device=logits.device, dtype=torch.int32)
+    filt = torch.empty(R, V, device=logits.device, dtype=torch.float32) if want_filtered else None
+    _ck(lib.gitmi_op_sample_rows(logits.data_ptr(), R, V, float(temperature), int(top_k), float(top_p), int(ndraw), int(seed),
+                                 int(step), lp.data_ptr(), tok.data_ptr(), _ptr(filt), _stream()))
+    return filt, tok, lp
 
 
 def kv_repack(img_k: torch.Tensor, img_v: torch.Tensor):

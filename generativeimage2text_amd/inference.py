@@ -86,12 +86,16 @@ def get_tokenizer():
     if op.isfile(vocab):
         return BertTokenizer(vocab, do_lower_case=True)
     os.environ.setdefault("HF_HUB_OFFLINE", "1")
+    why = "empty tokenizer"
     try:
-        return BertTokenizer.from_pretrained("bert-base-uncased", do_lower_case=True)
+        tok = BertTokenizer.from_pretrained("bert-base-uncased", do_lower_case=True)
+        if len(tok) >= 30522:          # (an offline from_pretrained may hand back a tokenizer with only the special tokens)
+            return tok
     except Exception as exc:
-        raise FileNotFoundError(
-            f"no bert-base-uncased vocabulary: {vocab} does not exist and the HF cache has none ({type(exc).__name__}). "
-            f"Set GIT_VOCAB=/path/to/vocab.txt, or GIT_VOCAB=ids to work with raw token ids.") from exc
+        why = type(exc).__name__
+    raise FileNotFoundError(
+        f"no bert-base-uncased vocabulary: {vocab} does not exist and the HF cache has none ({why}). "
+        f"Set GIT_VOCAB=/path/to/vocab.txt, or GIT_VOCAB=ids to work with raw token ids.")
 
 
 # ---- image transform (inference.py:111-132) ------------------------------------------------------

@@ -45,8 +45,10 @@ class GeneratorWithBeamSearch:
         self.length_penalty = length_penalty
         assert self.per_node_beam_size > 1
         assert self.length_penalty > 0, "`length_penalty` should be strictely positive."
-        if repetition_penalty != 1 or temperature != 1:
-            raise NotImplementedError("repetition_penalty / temperature (sampling branches) are out of scope")
+        if repetition_penalty != 1:
+            raise NotImplementedError("repetition_penalty (decoder.py:1135-1144) is not implemented")
+        assert temperature > 0, "`temperature` should be strictely positive."        # decoder.py:1081
+        self.temperature = temperature
         self.kind = "generator"
 
 
@@ -137,11 +139,21 @@ class CaptioningModel:
         self._loaded = True
         return self
 
-    def _search_struct(self):
+    def _search_struct(self, search_param: Optional[dict] = None):
+        """search_param: the keyword arguments CaptioningModel.infer forwards to decoder.search (decoder.py:1001-1003):
+        do_sample / top_k / top_p for GeneratorWithBeamSearch (decoder.py:1088-1090); `seed` selects the random stream."""
         d = self.decoder
-        return Engine.make_search(d.kind, d.max_steps, d.beam_size, d.per_node_beam_size, d.length_penalty)
+        sp = dict(search_param or {})
+        unknown = set(sp) - {"do_sample", "top_k", "top_p", "seed"}
+        if unknown:
+            raise NotImplementedError(f"search parameters {sorted(unknown)} are not implemented")
+        return Engine.make_search(d.kind, d.max_steps, d.beam_size, d.per_node_beam_size, d.length_penalty,
+                                  do_sample=bool(sp.get("do_sample", False)), top_k=sp.get("top_k") or 0,
+                                  top_p=sp.get("top_p"), temperature=getattr(d, "temperature", 1.0),
+                                  seed=int(sp.get("seed", 0)))
 
-    def forward(self, batch: Mapping[str, Union[torch.Tensor, Sequence[torch.Tensor]]]) -> Dict[str, torch.Tensor]:
+    def forward(self, batch: Mapping[str, Union[torch.Tensor, Sequence[torch.Tensor]]],
+                search_param: Optional[dict] = None) -> Dict[str, torch.Tensor]:
         if not self._loaded:
             raise RuntimeError("weights not loaded (call load_state_dict first)")
         image = batch["image"]
@@ -151,7 +163,7 @@ class CaptioningModel:
         prefix = batch.get("prefix")
         if prefix is not None:
             assert len(prefix) == 1, "not supported"                       # decoder.py:988
-        search = self._search_struct()
+        search = self._search_struct(search_param)
         tokens, logprobs, info = self.engine.generate(frames, search, prefix=prefix)
         seq_len, early, _, _ = info.tolist()
         P = 1 if prefix is None else int(prefix.numel())

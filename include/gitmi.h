@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GITMI_ABI_VERSION 3
+#define GITMI_ABI_VERSION 4
 
 /* compute precision of GEMM/attention operands (accumulation, LayerNorm statistics,
  * softmax, residual stream and logits are fp32 in both modes) */
@@ -82,6 +82,16 @@ typedef struct gitmi_search {
     int32_t per_node_beam_size;
     int32_t max_steps;            /* TOTAL length incl. [CLS]/prefix (decoder.py:313, 1111) */
     double  length_penalty;       /* GENERATOR only (double: the reference does this math in Python floats) */
+    /* sampling branch of GeneratorWithBeamSearch.search (decoder.py:1146-1166): scores / temperature ->
+     * top_k_top_p_filtering(min_tokens_to_keep = 2, decoder.py:1343-1375) -> per_node_beam_size draws WITHOUT replacement
+     * from the filtered softmax -> log-probabilities of the draws; the beam bookkeeping that follows is the same.
+     * torch.multinomial's random stream cannot be reproduced: draws come from a counter-based generator keyed by
+     * (seed, step, row, token) through the Gumbel-top-k construction (exactly that sampling distribution). */
+    int32_t do_sample;            /* 0 = greedy beam search (default); 1 = sample (GENERATOR only)     */
+    int32_t top_k;                /* <= 0: off                                                         */
+    double  top_p;                /* >= 1 or <= 0: off                                                 */
+    double  temperature;          /* > 0; 1 = unchanged (0 is read as 1)                               */
+    uint64_t seed;
 } gitmi_search;
 
 /* per-phase device timings (ms) of the last profiled gitmi_generate(), see gitmi_profile_enable */
@@ -278,6 +288,14 @@ int  gitmi_preprocess_image(const uint8_t* rgb_hwc, int H, int W, int crop, uint
  * tmp: uint8 workspace of H * out_w * 3 bytes. */
 int  gitmi_preprocess_image_to(const uint8_t* rgb_hwc, int H, int W, int out_h, int out_w, uint8_t* tmp,
                                size_t tmp_bytes, float* out_chw, void* stream);
+
+/* one step of the sampling branch of GeneratorWithBeamSearch.search on caller-supplied fp32 logits [R, V]
+ * (decoder.py:1146-1166, 1343-1375): filtered_out (optional) receives top_k_top_p_filtering(logits / temperature,
+ * min_tokens_to_keep = 2) with -inf for removed tokens; draw_token / draw_logprob [R, ndraw] the draws (without
+ * replacement, in draw order) and their log-probabilities under the filtered softmax.  Synchronises the stream. */
+int  gitmi_op_sample_rows(const float* logits, int R, int V, float temperature, int top_k, float top_p, int ndraw,
+                          uint64_t seed, int step, float* draw_logprob, int* draw_token, float* filtered_out,
+                          void* stream);
 
 /* kernel selection for A/B measurements: -1 auto (default), 0 first-generation GEMM only,
  * 1 force the direct-to-LDS GEMM wherever its constraints hold */

@@ -577,6 +577,39 @@ def search_generator(start: Tensor, step: Callable[[Tensor], Tensor], eos: int, 
 
 
 # ----------------------------------------------------------------------------
+# sampling branch helpers (decoder.py:1146-1166, 1343-1375)
+# ----------------------------------------------------------------------------
+def top_k_top_p_filtering(logits: Tensor, top_k: int = 0, top_p: Optional[float] = 1.0,
+                          min_tokens_to_keep: int = 1) -> Tensor:
+    """decoder.py:1343-1375 restated (returns a new tensor; removed entries are -inf).  Note the order of operations in
+    the nucleus part: the removal flags of the first `min_tokens_to_keep` sorted positions are cleared BEFORE the flags
+    are shifted right by one, so min_tokens_to_keep + 1 tokens always survive."""
+    logits = logits.clone()
+    if top_k and top_k > 0:
+        k = min(max(top_k, min_tokens_to_keep), logits.shape[-1])
+        kth = torch.topk(logits, k)[0][..., -1, None]
+        logits[logits < kth] = float("-inf")
+    if top_p and top_p < 1.0:
+        sorted_logits, sorted_idx = torch.sort(logits, descending=True)
+        cum = torch.cumsum(torch.softmax(sorted_logits, dim=-1), dim=-1)
+        remove = cum > top_p
+        if min_tokens_to_keep > 1:
+            remove[..., :min_tokens_to_keep] = False
+        remove[..., 1:] = remove[..., :-1].clone()
+        remove[..., 0] = False
+        logits[remove.scatter(1, sorted_idx, remove)] = float("-inf")
+    return logits
+
+
+def sampling_distribution(logits: Tensor, temperature: float = 1.0, top_k: int = 0,
+                          top_p: Optional[float] = 1.0) -> Tensor:
+    """What GeneratorWithBeamSearch.search samples from at one step (decoder.py:1146-1158):
+    softmax(top_k_top_p_filtering(scores / temperature, min_tokens_to_keep=2)); log-probabilities, -inf = removed."""
+    scores = logits / temperature if temperature != 1.0 else logits
+    return torch.log_softmax(top_k_top_p_filtering(scores, top_k=top_k, top_p=top_p, min_tokens_to_keep=2), dim=-1)
+
+
+# ----------------------------------------------------------------------------
 # CaptioningModel.forward / infer  (decoder.py:838-877, 977-1011)
 # ----------------------------------------------------------------------------
 @dataclasses.dataclass(frozen=True)

@@ -292,6 +292,22 @@ def write_minmax_fixture():
     print("[minmax_sizes] %d sizes x %d configs" % (len(wh), len(cfgs)))
 
 
+def write_sampling_filter_fixture():
+    """Outputs of the reference's top_k_top_p_filtering (decoder.py:1343-1375) on seeded logits: the kept masks."""
+    _, D = import_reference()
+    g = torch.Generator().manual_seed(3)
+    cases, out = [(0, 0.9), (50, 1.0), (20, 0.7), (5, 0.3), (0, 0.05), (3, 0.999), (1, 0.5), (0, 1.0)], {}
+    logits = torch.randn(6, 3000, generator=g) * 3.0
+    for i, (k, p) in enumerate(cases):
+        ref = D.top_k_top_p_filtering(logits.clone(), top_k=k, top_p=p, min_tokens_to_keep=2)
+        mine = O.top_k_top_p_filtering(logits, top_k=k, top_p=p, min_tokens_to_keep=2)
+        assert torch.equal(torch.isfinite(ref), torch.isfinite(mine)) and torch.equal(ref[torch.isfinite(ref)], mine[torch.isfinite(mine)]), (k, p)
+        out["mask%d" % i] = np.packbits(torch.isfinite(ref).numpy(), axis=1)
+        print("[sampling_filter] top_k=%d top_p=%g kept per row %s" % (k, p, torch.isfinite(ref).sum(1).tolist()))
+    np.savez_compressed(os.path.join(GOLD, "sampling_filter.npz"), seed=3, rows=6, vocab=3000, scale=3.0,
+                        cases=np.array(cases, dtype=np.float64), **out)
+
+
 def dataclass_tuple(s: O.SearchConfig):
     return (s.kind, s.max_steps, s.beam_size, s.per_node_beam_size, s.length_penalty)
 
@@ -370,6 +386,8 @@ def main():
         write_minmax_fixture()
     if args.only in (None, "scripted"):
         run_scripted()
+    if args.only in (None, "sampling_filter"):
+        write_sampling_filter_fixture()
     for name in CASES:
         if args.only is None or name in args.only.split(","):
             run_case(name)

@@ -291,3 +291,63 @@ def test_attention_decode(B, H, N_img, pos, beams, dtype):
             ref[r, h * 64:(h + 1) * 64] = p @ Vc
     tol = 3e-5 if dtype == torch.float32 else 3e-2
     assert (out - ref).abs().max().item() < tol
+
+
+# ---- sampling branch (decoder.py:1146-1166, 1343-1375) -------------------------------------------------------------
+@pytest.mark.parametrize("top_k,top_p,temp", [(0, 0.9, 1.0), (50, 1.0, 1.0), (20, 0.7, 1.3), (5, 0.3, 0.7), (0, 0.05, 1.0),
+                                              (3, 0.999, 1.0), (1, 0.5, 2.0), (0, 1.0, 1.0)])
+def test_sampling_filter_equals_reference_filter(top_k, top_p, temp):
+    """The device filter (thresholds found by bisection, no sort) keeps exactly the tokens top_k_top_p_filtering keeps
+    (the oracle restatement, pinned against the reference's function on the same seeded logits), except where a token
+    sits within fp32 rounding of the nucleus boundary; the draws come from the kept set with the filtered log-probs."""
+    from generativeimage2text_amd import engine as E
+    from oracle import git_oracle as O
+    logits = _rand(6, 3000, seed=3, scale=3.0)
+    want = O.sampling_distribution(logits, temp, top_k, top_p)
+    filt, tok, lp = E.op_sample_rows(logits.cuda(), temp, top_k, top_p, ndraw=2, seed=5, step=1)
+    filt, tok, lp = filt.cpu(), tok.cpu().long(), lp.cpu()
+    kept_ref, kept = torch.isfinite(want), torch.isfinite(filt)
+    diff = kept_ref != kept
+    if diff.any():
+        # only tokens whose "mass before me" is within rounding of top_p may differ
+        srt, idx = torch.sort(logits / temp, descending=True)
+        cum = torch.cumsum(torch.softmax(srt.double(), -1), -1)
+        before = torch.zeros_like(cum)
+        before[:, 1:] = cum[:, :-1]
+        pos = torch.argsort(idx, dim=1)
+        assert (torch.gather(before, 1, pos)[diff] - top_p).abs().max().item() < 1e-5
+        assert diff.sum().item() <= 2
+    same = kept & kept_ref
+    got_lp = torch.log_softmax(filt, -1)
+    assert (got_lp[same] - want[same]).abs().max().item() < (1e-4 if not diff.any() else 1e-2)
+    assert torch.equal(filt[kept], (logits / temp)[kept]) or torch.allclose(filt[kept], (logits / temp)[kept], rtol=1e-6)
+    # draws: distinct tokens of the kept set, log-probabilities of the filtered softmax
+    assert (tok[:, 0] != tok[:, 1]).all()
+    assert kept.gather(1, tok).all()
+    assert (got_lp.gather(1, tok) - lp).abs().max().item() < 1e-4
+
+
+def test_sampling_draws_follow_the_filtered_distribution():
+    """First draws over many independent steps: chi-square against the filtered softmax; second draw != first
+    (without replacement); same (seed, step) -> same draws."""
+    from generativeimage2text_amd import engine as E
+    from oracle import git_oracle as O
+    row = torch.tensor([[2.0, 1.5, 1.0, 0.5, 0.0, -0.5, -1.0, -3.0, 0.2, 0.7]])
+    R = 4096
+    logits = row.repeat(R, 1).cuda()
+    counts = torch.zeros(10)
+    for step in range(1, 6):
+        _, tok, _ = E.op_sample_rows(logits, 1.0, 8, 1.0, ndraw=2, seed=123, step=step, want_filtered=False)
+        assert (tok[:, 0] != tok[:, 1]).all()
+        counts += torch.bincount(tok[:, 0].cpu().long(), minlength=10).float()
+    p = torch.exp(O.sampling_distribution(row, 1.0, 8, 1.0))[0]
+    n = counts.sum().item()
+    exp = p * n
+    on = exp > 0
+    chi2 = (((counts - exp) ** 2)[on] / exp[on]).sum().item()
+    assert counts[~on].sum().item() == 0                     # filtered tokens are never drawn
+    assert chi2 < 30.0, (chi2, counts.tolist(), exp.tolist())     # 7 degrees of freedom: P(chi2 > 30) ~ 1e-4
+    _, a, _ = E.op_sample_rows(logits, 1.0, 8, 1.0, ndraw=2, seed=123, step=3, want_filtered=False)
+    _, b, _ = E.op_sample_rows(logits, 1.0, 8, 1.0, ndraw=2, seed=123, step=3, want_filtered=False)
+    _, c, _ = E.op_sample_rows(logits, 1.0, 8, 1.0, ndraw=2, seed=124, step=3, want_filtered=False)
+    assert torch.equal(a, b) and not torch.equal(a, c)

@@ -563,3 +563,65 @@ def test_single_rank_rccl_gather_path(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert "RCCL-1-RANK-OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_task_function_single_image_with_wordpiece_text(tmp_path, monkeypatch, caplog):
+    """test_git_inference_single_image end to end with REAL text in and out: BertTokenizer on a WordPiece vocabulary
+    (tests/data/vocab.txt, bert-base-uncased special-token ids), question text -> prefix ids (inference.py:93-101),
+    engine, ids -> decoded answer string (inference.py:108) -- against the oracle's ids decoded by the same tokenizer."""
+    import logging, os
+    from PIL import Image
+    from conftest import ROOT
+    from oracle import git_oracle as O
+    from generativeimage2text_amd import inference as I
+    from generativeimage2text_amd.model import GeneratorWithBeamSearch
+    monkeypatch.setenv("GIT_VOCAB", os.path.join(ROOT, "tests", "data", "vocab.txt"))
+    cfg = O.CONFIGS["TINY"]                                       # vocab 1000 = the synthetic vocabulary's size
+    w = O.make_weights(cfg, seed=61, tie_output=False, successor=2.0, eos_bias=1.5)
+    ckpt = tmp_path / "model.pt"
+    torch.save({"model": w}, str(ckpt))
+    rng = np.random.RandomState(9)
+    img_path = tmp_path / "img.png"
+    Image.fromarray(rng.randint(0, 255, (90, 120, 3), dtype=np.uint8)).save(str(img_path))
+    monkeypatch.setattr(I, "config_for_model", lambda name: cfg)
+    monkeypatch.setitem(I.MODEL_PARAMS, "TINY_TEXT", {"test_crop_size": cfg.image_size})
+    real_build = I.build_model
+    monkeypatch.setattr(I, "build_model", lambda name, tok, c, **kw: real_build(
+        name, tok, c, decoder=GeneratorWithBeamSearch(eos_index=tok.sep_token_id, max_steps=24, beam_size=4, length_penalty=0.6),
+        **kw))
+    question = "what color is the cat sitting on the table?"
+    with caplog.at_level(logging.INFO):
+        I.test_git_inference_single_image(str(img_path), "TINY_TEXT", question, checkpoint=str(ckpt))
+    got = I.test_git_inference_single_image.last_output
+    tok = I.get_tokenizer()
+    ids = I._prefix_ids(tok, question)
+    assert len(ids) > 8
+    x = I.image_transform(I.load_image_by_pil(str(img_path)), cfg.image_size)[None]
+    with torch.no_grad():
+        ref = O.caption(cfg, w, [x], O.SearchConfig("beam", 24, 4, 2, 0.6), prefix=torch.tensor([ids]), cached=True)
+    want = tok.decode(ref["predictions"][0].tolist(), skip_special_tokens=True)
+    assert got == want and len(want) > 0, (got, want)
+
+
+def test_generate_with_sampling_search():
+    """model(batch, search_param={'do_sample': True, ...}) (decoder.py:895-905 passes these to decoder.search): runs the
+    sampling branch of GeneratorWithBeamSearch end to end, is reproducible per seed, differs across seeds, and with
+    top_k = 1 (a single kept token... plus the min-keep rule) stays inside the two most likely tokens at every step."""
+    from oracle import git_oracle as O
+    from generativeimage2text_amd.model import CaptioningModel, GeneratorWithBeamSearch
+    cfg = O.CONFIGS["TINY"]
+    w = O.make_weights(cfg, seed=71, tie_output=False, successor=2.0, eos_bias=1.0)
+    frames = O.make_images(cfg, 3, 1, seed=2)
+    dec = GeneratorWithBeamSearch(eos_index=cfg.eos, max_steps=14, beam_size=2, length_penalty=0.6, temperature=1.2)
+    for prec in ("f32", "bf16"):
+        model = CaptioningModel(cfg, dec, precision=prec, max_batch=3)
+        model.load_state_dict(w)
+        img = frames[0].cuda()
+        a = model({"image": img}, {"do_sample": True, "top_k": 20, "top_p": 0.9, "seed": 7})
+        b = model({"image": img}, {"do_sample": True, "top_k": 20, "top_p": 0.9, "seed": 7})
+        c = model({"image": img}, {"do_sample": True, "top_k": 20, "top_p": 0.9, "seed": 8})
+        g = model({"image": img})
+        assert torch.equal(a["predictions"], b["predictions"]) and torch.equal(a["logprobs"], b["logprobs"])
+        assert not torch.equal(a["predictions"], c["predictions"])
+        assert a["predictions"].shape == g["predictions"].shape == (3, 14)
+        assert (a["predictions"][:, 0] == cfg.sos).all() and torch.isfinite(a["logprobs"]).all()

@@ -25,13 +25,20 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(engine.EXPORTED_SYMBOLS) == declared
-    assert lib.gitmi_abi_version() == 3
+    assert lib.gitmi_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
     assert engine.C.sizeof(engine.GitmiConfig) == 21 * 4
-    assert engine.C.sizeof(engine.GitmiSearch) == 24          # 4 x int32 + double
-    assert engine.GitmiSearch.length_penalty.offset == 16
+    assert engine.C.sizeof(engine.GitmiSearch) == 56          # 4 x int32, double, 2 x int32, 2 x double, uint64
+    assert engine.GitmiSearch.length_penalty.offset == 16 and engine.GitmiSearch.top_p.offset == 32
+    assert engine.GitmiSearch.seed.offset == 48
+    import re, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "gitmi.h")).read()
+    body = hdr[hdr.index("typedef struct gitmi_search {"):hdr.index("} gitmi_search;")]
+    fields = re.findall(r"^\s*(?:int32_t|double|uint64_t)\s+(\w+);", body, re.M)
+    assert fields == [n for n, _ in engine.GitmiSearch._fields_]
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")
@@ -119,6 +126,37 @@ def test_prefix_ids_and_id_tokenizer():
     ids = inference._prefix_ids(tok, long)
     assert len(ids) == 39 and ids[0] == 101 and ids[-1] == 1099          # keeps the LAST 38 (inference.py:99-100)
     assert tok.decode([101, 7, 8, 102, 102]) == "7 8"
+
+
+def test_wordpiece_tokenizer_text_io(monkeypatch):
+    """inference.py:72, 93-101, 108 with a real BertTokenizer on a (synthetic) WordPiece vocabulary that carries
+    bert-base-uncased's special-token ids: question -> [CLS] + ids (keep the LAST 38 of the truncated 40), ids -> text."""
+    import os
+    from conftest import ROOT
+    monkeypatch.setenv("GIT_VOCAB", os.path.join(ROOT, "tests", "data", "vocab.txt"))
+    tok = inference.get_tokenizer()
+    assert type(tok).__name__ == "BertTokenizer" and (tok.cls_token_id, tok.sep_token_id) == (101, 102)
+    ids = inference._prefix_ids(tok, "What color is the cat?")
+    assert ids[0] == 101 and tok.decode(ids, skip_special_tokens=True) == "what color is the cat?"
+    assert tok.decode([101] + ids[1:] + [102, 102], skip_special_tokens=True) == "what color is the cat?"
+    words = ("what is this " * 30).split()
+    long_ids = inference._prefix_ids(tok, " ".join(words))
+    full = tok(" ".join(words), add_special_tokens=False)["input_ids"]
+    assert len(long_ids) == 39 and long_ids[0] == 101 and long_ids[1:] == full[:40][-38:]
+    # unknown words fall back to word pieces / [UNK], never crash
+    assert len(inference._prefix_ids(tok, "zebras skateboarding")) > 1
+
+
+def test_missing_vocabulary_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setenv("GIT_VOCAB", str(tmp_path / "nope.txt"))
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf"))
+    monkeypatch.setenv("HF_HUB_OFFLINE", "1")
+    with pytest.raises(FileNotFoundError):
+        inference.get_tokenizer()
+    monkeypatch.setenv("GIT_VOCAB", "ids")
+    assert isinstance(inference.get_tokenizer(), inference.IdTokenizer)
+    with pytest.raises(ValueError):
+        inference.IdTokenizer()("what is this")
 
 
 def test_minmax_resize_sizes_match_reference():
