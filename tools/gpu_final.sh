@@ -1,20 +1,28 @@
 #!/bin/bash
-# Round-end verification: full GPU parity suite, smoke, default bench line, rocprofv3 kernel stats of the same command,
-# a solo (one context, eager) profile comparable with the roofline pass, and the other configs.
-set -u; mkdir -p gpurun_out; export PYTHONUNBUFFERED=1
+# Round-end verification and profile collection (one gpurun call): full GPU parity suite, smoke, the default bench
+# line, rocprofv3 kernel stats of the same command and of a solo (one context) graph-replay run, PMC passes, the other
+# BASELINE configs with their own kernel stats, CPU-baseline thread sweep.  Summaries land in gpurun_out/ (copy the
+# ones to keep into profiles/).
+set -u; mkdir -p gpurun_out; export PYTHONUNBUFFERED=1 HSA_ENABLE_IPC_MODE_LEGACY=0
 R=$PWD
-echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.txt 2>&1; echo "rc=$?"; tail -4 gpurun_out/pytest_gpu.txt
-echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-echo "== bench"; timeout 900 python bench.py > gpurun_out/bench.txt 2>&1; echo "rc=$?"; tail -1 gpurun_out/bench.txt | cut -c1-400
+TAG=${1:-final}
+echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.txt 2>&1; echo "rc=$?"; tail -n 3 gpurun_out/${TAG}_pytest_gpu.txt
+echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -n 2
+echo "== bench"; timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "rc=$?"; tail -n 1 gpurun_out/${TAG}_bench.json | cut -c1-300
 cd /tmp; export TMPDIR=/tmp
-echo "== rocprof (default bench command)"; timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o bench -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/rocprof.txt 2>&1; echo "rc=$?"
-echo "== rocprof solo eager"; timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_solo -o bench -- python $R/bench.py --steps 5 --warmup 2 --contexts 1 --no-graph --no-cpu-baseline > $R/gpurun_out/rocprof_solo.txt 2>&1; echo "rc=$?"
+prof() {  # name, bench args...
+  local name=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$name -o bench -- python $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_${name}_bench.json 2> $R/gpurun_out/${TAG}_${name}.err; echo "rocprof $name rc=$?"
+  python $R/tools/rocprof_summary.py $R/gpurun_out/prof_$name/bench_results.db $R/gpurun_out/${TAG}_${name}_kernel_stats.txt > /dev/null
+  rm -rf $R/gpurun_out/prof_$name
+  tail -n 1 $R/gpurun_out/${TAG}_${name}_bench.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['unit'], d['ms_per_step'], 'ms/step', d['config']['workload'], d['roofline']['achieved'], 'TF', d.get('roofline_decode',{}).get('avg_step_ms'))"
+}
+prof default
+prof solo_graph --contexts 1 --steps 8 --warmup 2
+prof beam4 --search beam --steps 12 --warmup 3
+prof large_b32 --model GIT_LARGE_COCO --batch 32 --steps 12 --warmup 3
+prof vatex_b16 --model GIT_BASE_VATEX --frames 6 --batch 16 --steps 12 --warmup 3
 cd $R
-python tools/rocprof_summary.py gpurun_out/prof/bench_results.db gpurun_out/kernel_stats.txt > /dev/null; head -8 gpurun_out/kernel_stats.txt | cut -c1-200
-python tools/rocprof_summary.py gpurun_out/prof_solo/bench_results.db gpurun_out/kernel_stats_solo.txt > /dev/null; head -8 gpurun_out/kernel_stats_solo.txt | cut -c1-200
-tail -1 gpurun_out/rocprof_solo.txt > gpurun_out/bench_solo_eager.txt
-run() { echo "== $*"; timeout 400 python bench.py --no-cpu-baseline --steps 12 --warmup 3 "$@" 2>&1 | grep -v amdgpu | tail -1 | tee -a gpurun_out/configs.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['unit'], d['ms_per_step'], 'ms/step', d['config']['workload'], d['roofline']['achieved'], 'TF', d['phases_ms'])"; }
-rm -f gpurun_out/configs.jsonl
-run --search beam
-run --model GIT_LARGE_COCO --batch 32
-run --model GIT_BASE_VATEX --frames 6 --batch 16
+echo "== pmc"; bash tools/gpu_pmc.sh > gpurun_out/${TAG}_pmc.log 2>&1; cp gpurun_out/pmc_summary.tsv gpurun_out/${TAG}_pmc_summary.tsv; head -n 12 gpurun_out/${TAG}_pmc_summary.tsv | cut -c1-240
+rm -rf gpurun_out/pmc
+echo "== cpu sweep"; timeout 900 python bench.py --cpu-sweep > gpurun_out/${TAG}_cpu_sweep.json 2>&1; tail -n 1 gpurun_out/${TAG}_cpu_sweep.json | cut -c1-600
