@@ -167,10 +167,6 @@ def main():
                     help="engine contexts (shared weights) kept in flight on separate HIP streams")
     ap.add_argument("--free-run", action="store_true",
                     help="do not chain the contexts' image encoders (default: one encoder in flight at a time)")
-    ap.add_argument("--decode-cus", type=int, default=0,
-                    help="CU partition: this many CUs (spread over the XCDs) run the decode chains, the rest the image "
-                         "encoder (0 = shared CUs)")
-    ap.add_argument("--decode-streams", type=int, default=1)
     ap.add_argument("--cpu-sweep", action="store_true",
                     help="only time the CPU port at several thread counts (median of 3, bs=8) and print JSON")
     args = ap.parse_args()
@@ -214,10 +210,7 @@ def main():
     for c in ctxs[1:]:
         if args.no_graph:
             c.set_graph(False)
-    if args.decode_cus > 0:
-        for c in ctxs:
-            c.set_cu_partition(args.decode_cus, args.decode_streams)
-    elif len(ctxs) > 1 and not args.free_run:
+    if len(ctxs) > 1 and not args.free_run:
         # serving schedule: encoders of consecutive submissions run one after the other, decode chains float
         for i, c in enumerate(ctxs):
             c.set_encode_after(ctxs[i - 1])
@@ -287,8 +280,7 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "decode_steps_per_caption": steps_run, "seq_len_returned": info_h[0],
                        "hip_graph": not args.no_graph, "contexts_in_flight": len(ctxs),
-                       "encoders_serialized": args.decode_cus > 0 or (len(ctxs) > 1 and not args.free_run),
-                       "decode_cus": args.decode_cus, "decode_streams": args.decode_streams if args.decode_cus else 0},
+                       "encoders_serialized": len(ctxs) > 1 and not args.free_run},
             # a batch's own latency (submit -> ids ready) while `contexts_in_flight` batches share the GPU
             "batch_latency_ms": {"median": round(lat[len(lat) // 2], 3), "max": round(lat[-1], 3)},
         }

@@ -70,13 +70,6 @@ struct DecLayerW {
 struct TimedSpan { hipEvent_t a, b; int tag; double flops; };
 enum { TAG_VIT = 0, TAG_PREFILL = 1, TAG_DECODE = 2, TAG_GEMM_VIT = 10, TAG_GEMM_OTHER = 11, TAG_STEP = 20 };
 
-// streams bound to disjoint CU sets, one set per device (gitmi_set_cu_partition)
-struct CuPartition {
-    hipStream_t enc = nullptr;
-    hipStream_t dec[4] = {nullptr, nullptr, nullptr, nullptr};
-    int n_dec = 0, decode_cus = 0, next_slot = 0;
-};
-
 struct gitmi_engine {
     gitmi_config cfg{};
     int device = 0;
@@ -163,12 +156,6 @@ struct gitmi_engine {
     // in flight on the device; decode chains of the other contexts fill in beside it)
     gitmi_engine* enc_after = nullptr;
     hipEvent_t enc_done = nullptr;
-    // CU partition (gitmi_set_cu_partition): encode + prefill graph on the device's encoder stream, decode graph on one
-    // of its decode streams; the two stream kinds are bound to disjoint CU sets
-    CuPartition* part = nullptr;
-    int gemm_reserve = 0;               // CUs per XCD the encoder GEMM grids leave free (GemmArgs::reserve)
-    int part_slot = 0;
-    hipEvent_t part_in = nullptr, part_enc = nullptr, part_dec = nullptr;
     double split_encode_ms = 0, split_decode_ms = 0;
     int split_calls = 0, split_steps = 0;
     std::vector<TimedSpan> spans;
@@ -236,7 +223,6 @@ static int gemm(gitmi_engine* e, hipStream_t s, const void* A, int lda, const vo
     GemmArgs g{};
     g.A = A; g.W = W; g.bias = bias; g.res = res; g.C = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldr; g.act = act;
-    g.reserve = e->gemm_reserve;
     SpanGuard sp(e, s, tag, 2.0 * (double)M * (double)N * (double)K);
     HIPCK(launch_gemm(g, e->f32, out_f32, s));
     return 0;
@@ -315,8 +301,6 @@ extern "C" void gitmi_destroy(gitmi_engine* e) {
     for (auto ev : e->gev)
         if (ev) hipEventDestroy(ev);
     if (e->enc_done) hipEventDestroy(e->enc_done);
-    for (hipEvent_t ev : {e->part_in, e->part_enc, e->part_dec})
-        if (ev) hipEventDestroy(ev);
     for (auto ev : e->event_pool) hipEventDestroy(ev);
     for (void* p : e->allocs) hipFree(p);
     delete e;
@@ -1225,7 +1209,7 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     key.T = sp->max_steps; key.H = e->H; key.W = e->W; key.lp = sp->length_penalty;
     key.ragged = ragged ? 1 : 0; key.ident = e->img_identity ? 1 : 0; key.temb = e->use_temb ? 1 : 0;
     key.smp = sp->do_sample; key.top_k = sp->top_k; key.top_p = sp->top_p; key.temp = sp->temperature; key.seed = sp->seed;
-    const bool split = e->profile_mode == 2 || e->enc_after != nullptr || e->enc_done != nullptr || e->part != nullptr;
+    const bool split = e->profile_mode == 2 || e->enc_after != nullptr || e->enc_done != nullptr;
     if (!e->graph_valid || !(key == e->graph_key) || split != e->graph_is_split) {
         destroy_graph(e);
         std::vector<const float*> fp(F_eff);
@@ -1264,17 +1248,6 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     }
     if (!split) {
         HIPCK(hipGraphLaunch(e->graph_exec, x));
-    } else if (e->profile_mode != 2 && e->part) {
-        CuPartition* p = e->part;
-        hipStream_t d = p->dec[e->part_slot % p->n_dec];
-        HIPCK(hipEventRecord(e->part_in, x));
-        HIPCK(hipStreamWaitEvent(p->enc, e->part_in, 0));
-        HIPCK(hipGraphLaunch(e->graph_exec, p->enc));
-        HIPCK(hipEventRecord(e->part_enc, p->enc));
-        HIPCK(hipStreamWaitEvent(d, e->part_enc, 0));
-        HIPCK(hipGraphLaunch(e->graph_exec_b, d));
-        HIPCK(hipEventRecord(e->part_dec, d));
-        HIPCK(hipStreamWaitEvent(x, e->part_dec, 0));
     } else if (e->profile_mode != 2) {
         if (e->enc_after && e->enc_after->enc_done) HIPCK(hipStreamWaitEvent(x, e->enc_after->enc_done, 0));
         HIPCK(hipGraphLaunch(e->graph_exec, x));
@@ -1370,66 +1343,6 @@ extern "C" int gitmi_profile_enable(gitmi_engine* e, int on) {
     e->event_next = 0;
     return 0;
 }
-// ---- CU partition ------------------------------------------------------------------------
-// One device, two kinds of work with opposite needs: the image encoder is MFMA-bound and fills whole CUs (2 waves x 226
-// registers per SIMD, 128 KiB LDS: nothing else fits beside a GEMM workgroup); a decode step is a chain of 32 short
-// dependent launches that needs few CUs but needs them NOW.  Sharing all 256 CUs makes every decode launch wait for a
-// GEMM tile boundary.  The partition binds the encoder stream to all but `decode_cus` CUs and the decode stream(s) to
-// the rest (hipExtStreamCreateWithCUMask; mask bit i = CU i/8 of XCD i%8, so a contiguous bit range is spread evenly over
-// the eight XCDs).  The encoder GEMM grids (450 / 600 / 150-198 tiles) need the same number of rounds on 232 CUs as on
-// 256, so the encoder loses little; the decode chain gets CUs of its own.
-static CuPartition g_part[16];
-
-extern "C" int gitmi_set_cu_partition(gitmi_engine* e, int decode_cus, int decode_streams) {
-    if (!e) return fail("null engine");
-    HIPCK(hipSetDevice(e->device));
-    if (decode_cus <= 0) { e->part = nullptr; e->gemm_reserve = 0; e->graph_valid = false; return 0; }
-    if (decode_streams == 0) {          // reserve mode: persistent encoder GEMM grids, plain streams
-        if (decode_cus % 8 || decode_cus > 128) return fail("cu_partition: decode_cus must be a multiple of 8 (<= 128)");
-        e->part = nullptr; e->gemm_reserve = decode_cus / 8; e->graph_valid = false;
-        return 0;
-    }
-    if (e->device < 0 || e->device >= 16) return fail("cu_partition: device %d", e->device);
-    hipDeviceProp_t prop;
-    HIPCK(hipGetDeviceProperties(&prop, e->device));
-    const int ncu = prop.multiProcessorCount;
-    if (decode_cus >= ncu) return fail("cu_partition: %d decode CUs of %d", decode_cus, ncu);
-    if (decode_streams < 1 || decode_streams > 4) return fail("cu_partition: %d decode streams outside [1,4]", decode_streams);
-    CuPartition& p = g_part[e->device];
-    if (p.enc && (p.decode_cus != decode_cus || p.n_dec != decode_streams)) {
-        HIPCK(hipDeviceSynchronize());
-        hipStreamDestroy(p.enc);
-        for (int i = 0; i < p.n_dec; ++i) hipStreamDestroy(p.dec[i]);
-        p = CuPartition{};
-    }
-    if (!p.enc) {
-        const int words = (ncu + 31) / 32;
-        std::vector<uint32_t> m_enc(words, 0), m_dec(words, 0);
-        for (int i = 0; i < ncu; ++i) (i < ncu - decode_cus ? m_enc : m_dec)[i / 32] |= 1u << (i % 32);
-        const char* dbg = getenv("GITMI_PART_DBG");          // experiment knob: 1 plain streams, 2 full masks, 3 only decode masked
-        const int mode = dbg ? atoi(dbg) : 0;
-        if (mode == 2) for (int i = 0; i < ncu; ++i) { m_enc[i / 32] |= 1u << (i % 32); m_dec[i / 32] |= 1u << (i % 32); }
-        int pr_lo = 0, pr_hi = 0;
-        HIPCK(hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
-        if (mode == 4) HIPCK(hipStreamCreateWithPriority(&p.enc, hipStreamNonBlocking, pr_hi));
-        else if (mode == 5) HIPCK(hipStreamCreateWithPriority(&p.enc, hipStreamNonBlocking, pr_lo));
-        else if (mode == 1 || mode == 3) HIPCK(hipStreamCreateWithFlags(&p.enc, hipStreamNonBlocking));
-        else HIPCK(hipExtStreamCreateWithCUMask(&p.enc, words, m_enc.data()));
-        for (int i = 0; i < decode_streams; ++i) {
-            if (mode == 4) HIPCK(hipStreamCreateWithPriority(&p.dec[i], hipStreamNonBlocking, pr_lo));
-            else if (mode == 5) HIPCK(hipStreamCreateWithPriority(&p.dec[i], hipStreamNonBlocking, pr_hi));
-            else if (mode == 1) HIPCK(hipStreamCreateWithFlags(&p.dec[i], hipStreamNonBlocking));
-            else HIPCK(hipExtStreamCreateWithCUMask(&p.dec[i], words, m_dec.data()));
-        }
-        p.n_dec = decode_streams; p.decode_cus = decode_cus; p.next_slot = 0;
-    }
-    e->part = &p;
-    e->part_slot = p.next_slot++;
-    for (hipEvent_t* ev : {&e->part_in, &e->part_enc, &e->part_dec})
-        if (!*ev) HIPCK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-    return 0;
-}
-
 // Serving schedule for several contexts on one device: `e`'s image encoder (+ decoder prefill) of a gitmi_generate call
 // starts only after the encoder of `after`'s most recently submitted call has finished; the decode steps are not
 // ordered.  Chain the contexts in a ring in submission order: at most one MFMA-bound encoder runs at a time and the
@@ -1534,11 +1447,6 @@ extern "C" int gitmi_op_attention(const void* qkv, void* out, int B, int N, int 
 // ---- decode-chain kernels (kernels_dgemm.hip), one launch each -----------------------------------------------
 static int g_dgemm_dbg = 0;
 extern "C" int gitmi_debug_set_dgemm(int dbg) { g_dgemm_dbg = dbg; return 0; }
-// measurement aid: occupy `blocks` workgroups of `threads` threads for `cycles` ticks of the 100 MHz wall clock
-extern "C" int gitmi_debug_spin(int blocks, int threads, long long cycles, void* stream) {
-    HIPCK(launch_spin(blocks, threads, cycles, nullptr, (hipStream_t)stream));
-    return 0;
-}
 extern "C" int gitmi_op_dgemm(const void* A, const void* W, const float* bias, const float* colsum, const float* stats,
                               int strips, float eps, void* C, int c_frag, int M, int N, int K, int act, void* stream) {
     DGemmArgs g{};

@@ -271,8 +271,7 @@ void set_gemm_impl(int impl) {
 // in_f32/out_f32: element types of A,W and of C
 hipError_t launch_gemm(const GemmArgs& g_in, bool in_f32, bool out_f32, hipStream_t s) {
     GemmArgs g = g_in;
-    g.dbg = g_gemm_dbg & 0xff;
-    if (g_gemm_dbg >> 8) g.reserve = (g_gemm_dbg >> 8) & 31;      // tests / A-B: impl | reserve << 16
+    g.dbg = g_gemm_dbg;
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     // impl: -1 auto | 0 register-staged (also fp32, odd shapes) | 1 direct-to-LDS 128x128 | 2 256x128 3-stage ring |
     //       6 256x256x32 4-stage ring | 9 256x256x64 half-tile pipeline (kernels_gemm10.hip)

@@ -76,23 +76,21 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     // are cut into ng groups; the 8/ng XCDs of a group share its (M-major, N-fastest) tile list in contiguous,
     // equally long chunks, so that no XCD needs an extra round of its 32 CUs because of an uneven rectangular split
     // (450 tiles: 57 per XCD instead of 65 on one of them) while its tiles still share activation / weight panels.
-    // With a CU reserve (GemmArgs::reserve) the grid holds only as many workgroups per XCD as CUs the encoder may use
-    // and each one walks its XCD's list with that stride: the remaining CUs never see a GEMM workgroup.
-    const int xcd = blockIdx.x & 7, wgx = gridDim.x >> 3;
-    int n_lo, nn, lo_t, cnt;
+    int tile_m, tile_n;
     {
+        const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
         const int ng = g.ng, mg = 8 / ng;
-        const int gn = xcd % ng, gm = xcd / ng;
+        const int gn = x % ng, gm = x / ng;
         const int tiles_m = (g.M + BM - 1) / BM;
-        n_lo = gn * g.tiles_n / ng;
-        nn = (gn + 1) * g.tiles_n / ng - n_lo;
+        const int n_lo = gn * g.tiles_n / ng, n_hi = (gn + 1) * g.tiles_n / ng;
+        const int nn = n_hi - n_lo;
         const int tg = tiles_m * nn;
-        lo_t = gm * tg / mg;
-        cnt = (gm + 1) * tg / mg - lo_t;
+        const int lo_t = gm * tg / mg, hi_t = (gm + 1) * tg / mg;
+        if (idx >= hi_t - lo_t) return;                         // surplus workgroup
+        const int L = lo_t + idx;
+        tile_m = L / nn;
+        tile_n = n_lo + L % nn;
     }
-    for (int idx = blockIdx.x >> 3; idx < cnt; idx += wgx) {    // one pass unless the grid is persistent
-    const int L = lo_t + idx;
-    const int tile_m = L / nn, tile_n = n_lo + L % nn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const char* __restrict__ Ab = reinterpret_cast<const char*>(g.A);
@@ -312,7 +310,6 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
             }
             __syncthreads();
         }
-    }   // tiles of this workgroup
 }
 
 }  // namespace
@@ -352,7 +349,6 @@ bool gemm_p8_supports(const GemmArgs& g) {
 // weight panels for a group nn tiles wide -- i.e. the best L2 sharing (8192^3: ng = 8 -> 12 panels, 1.49 PFLOP/s;
 // ng = 1 -> 33 panels, 1.05 PFLOP/s).
 static int p8_plan(const GemmArgs& g, int mh, int* ng_out, int* max_cnt_out) {
-    const int cu = 32 - (g.reserve > 0 && g.reserve < 32 ? g.reserve : 0);      // CUs of an XCD the grid may occupy
     const int tiles_m = (g.M + 2 * mh - 1) / (2 * mh), tiles_n = g.N / BN;
     int best_ng = 1, best_rounds = 1 << 30, best_cnt = 0, best_panels = 1 << 30;
     for (int ng = 1; ng <= 8 && ng <= tiles_n; ng *= 2) {
@@ -366,8 +362,8 @@ static int p8_plan(const GemmArgs& g, int mh, int* ng_out, int* max_cnt_out) {
             max_cnt = cnt > max_cnt ? cnt : max_cnt;
             max_nn = nn > max_nn ? nn : max_nn;
         }
-        const int rounds = (max_cnt + cu - 1) / cu;
-        const int panels = (cu + max_nn - 1) / max_nn + (max_nn < cu ? max_nn : cu);
+        const int rounds = (max_cnt + 31) / 32;
+        const int panels = (32 + max_nn - 1) / max_nn + (max_nn < 32 ? max_nn : 32);
         if (rounds < best_rounds || (rounds == best_rounds && panels < best_panels)) {
             best_ng = ng; best_rounds = rounds; best_cnt = max_cnt; best_panels = panels;
         }
@@ -390,7 +386,6 @@ hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s) {
     int max_cnt = 0;
     p8_plan(g, mh, &g.ng, &max_cnt);
     g.nwg = 8 * max_cnt;
-    if (g.reserve > 0 && g.reserve < 32 && max_cnt > 32 - g.reserve) g.nwg = 8 * (32 - g.reserve);     // persistent grid
     if (mh == 96) {
         if (out_f32) launch_p8_t<float, 96>(g, s);
         else launch_p8_t<bf16_t, 96>(g, s);

@@ -384,16 +384,4 @@ hipError_t launch_copy_f32(const float* src, int lds, float* dst, int ldd, int r
     return hipGetLastError();
 }
 
-// measurement aid (tools/overlap_probe2.py): a kernel that only occupies `blocks` workgroups for `cycles` clocks
-__global__ void spin_kernel(long long cycles, int* sink) {
-    const long long t0 = wall_clock64();
-    long long t = t0;
-    while (t - t0 < cycles) t = wall_clock64();
-    if (cycles < 0) *sink = (int)t;
-}
-hipError_t launch_spin(int blocks, int threads, long long cycles, int* sink, hipStream_t s) {
-    hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(threads), 0, s, cycles, sink);
-    return hipGetLastError();
-}
-
 }  // namespace gitmi

@@ -13,7 +13,6 @@ struct GemmArgs {
     int tiles_n, nwg;
     int ng;     // XCD tile partition: N split into ng groups, M into 8/ng (kernels_gemm3.hip)
     int dbg;    // timing experiments only (gemm_ring_kernel): 1 no C stores, 2 no epilogue, 4 no MFMA, 8 no loads in loop
-    int reserve;  // gemm_p8: CUs per XCD the grid must leave free (persistent grid of 32 - reserve workgroups per XCD); 0 = none
 };
 hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t s);
 // second-generation bf16 kernel (direct-to-LDS staging, swizzled LDS, LDS-staged epilogue)
@@ -160,5 +159,4 @@ hipError_t launch_preprocess(const unsigned char* rgb, int H, int W, int crop, u
 hipError_t launch_resize_crop_norm(const uint8_t* rgb, int H, int W, int nh, int nw, int top, int left, int ch, int cw,
                                    uint8_t* tmp, float* out, hipStream_t s);
 
-hipError_t launch_spin(int blocks, int threads, long long cycles, int* sink, hipStream_t s);   // measurement aid
 }  // namespace gitmi

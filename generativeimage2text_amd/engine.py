@@ -28,7 +28,6 @@ EXPORTED_SYMBOLS = [
     "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_dgemm", "gitmi_op_dgemm_res",
     "gitmi_op_vocab_topm", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
     "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after", "gitmi_op_sample_rows",
-    "gitmi_set_cu_partition",
 ]
 
 
@@ -95,7 +94,6 @@ def load_library() -> C.CDLL:
     lib.gitmi_set_graph.argtypes = [vp, i32]
     lib.gitmi_set_temporal_embedding.argtypes = [vp, i32]
     lib.gitmi_set_encode_after.argtypes = [vp, vp]
-    lib.gitmi_set_cu_partition.argtypes = [vp, i32, i32]
     lib.gitmi_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_attention.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
@@ -357,12 +355,6 @@ class Engine:
         """Serving schedule: this context's image encoder starts only after `other`'s (most recently submitted) has
         finished; chain contexts in a ring in submission order (one encoder in flight, decode chains fill in)."""
         _ck(self.lib.gitmi_set_encode_after(self._h, other._h if other is not None else None))
-
-    def set_cu_partition(self, decode_cus: int, decode_streams: int = 1) -> None:
-        """Serving schedule: run this context's image encoder (+ prefill) on the device's encoder stream and its decode
-        steps on a decode stream, the two bound to disjoint CU sets (`decode_cus` CUs, spread evenly over the XCDs, for
-        decoding; the rest for the encoder).  All contexts of a device share the streams.  0 turns it off."""
-        _ck(self.lib.gitmi_set_cu_partition(self._h, int(decode_cus), int(decode_streams)))
 
     def set_temporal_embedding(self, on: bool) -> None:
         """on (default): frames come as a list -> frame i gets img_temperal_embedding[i]; off: a bare image tensor

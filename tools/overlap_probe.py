@@ -16,12 +16,11 @@ ctxs = [eng] + [eng.clone() for _ in range(7)]
 streams = [torch.cuda.Stream() for _ in ctxs]
 frames = random_frames(cfg, B, 1, seed=0)
 
-def run(n_ctx, steps_T, reserve, n=40, ring=True):
+def run(n_ctx, steps_T, n=40, ring=True):
     search = Engine.make_search("greedy", steps_T, 1, 1)
     use = ctxs[:n_ctx]
     for i, c in enumerate(use):
         c.set_encode_after(None)
-        c.set_cu_partition(reserve, 0)
     if ring and n_ctx > 1:
         for i, c in enumerate(use):
             c.set_encode_after(use[i - 1])
@@ -34,8 +33,6 @@ def run(n_ctx, steps_T, reserve, n=40, ring=True):
     t0 = time.perf_counter(); go(n); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
-for reserve in (0, 24, 40, 56, 64, 96):
-    for T_ in (20, 1):
-        for n_ctx in ((2, 4) if T_ == 20 else (4,)):
-            print("reserve=%2d %s contexts=%d: %.3f ms/batch" % (reserve, "full call   " if T_ == 20 else "encoder only", n_ctx,
-                                                                  run(n_ctx, T_, reserve)), flush=True)
+for T_ in (20, 1):
+    for n_ctx in (1, 2, 4, 8):
+        print("%s contexts=%d: %.3f ms/batch" % ("full call   " if T_ == 20 else "encoder only", n_ctx, run(n_ctx, T_)), flush=True)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Does a chain of EMPTY-ish dependent launches on another stream slow the image encoder?  (kernel-boundary effects:
-cache write-back / invalidate, dispatcher) -- encoder-only ring throughput with and without a background chain."""
+cache write-back / invalidate, dispatcher) -- encoder-only ring throughput with and without a background chain.
+The footprint variants (a spin kernel of W workgroups x T microseconds) need the `gitmi_debug_spin` hook of commit
+514a2f0; on the current tree only the one-workgroup chain runs."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,7 +24,9 @@ x = torch.zeros(64, device="cuda")
 import ctypes
 from generativeimage2text_amd import engine as E
 lib = E.load_library()
-lib.gitmi_debug_spin.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
+HAVE_SPIN = hasattr(lib, "gitmi_debug_spin")
+if HAVE_SPIN:
+    lib.gitmi_debug_spin.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
 
 def make_bg(n_nodes, blocks=0, threads=0, ticks=0):
     g = torch.cuda.CUDAGraph()
@@ -53,6 +57,8 @@ def run(bg, n=40):
 print("encoder only, no background chain: %.3f ms/batch" % run(None), flush=True)
 for nodes, blocks, threads, ticks in ((600, 0, 0, 0), (600, 768, 128, 600), (600, 144, 256, 400), (600, 256, 256, 400),
                                       (600, 48, 256, 400), (600, 24, 256, 400), (600, 48, 256, 1200), (600, 768, 128, 100)):
+    if blocks and not HAVE_SPIN:
+        continue
     g = make_bg(nodes, blocks, threads, ticks)
     print("  background kernel: %d workgroups x %d threads x %.1f us" % (blocks, threads, ticks / 100.0))
     with torch.cuda.stream(bg_stream):
