@@ -159,6 +159,10 @@ class CaptioningModel:
         image = batch["image"]
         is_list = isinstance(image, (list, tuple))
         frames = list(image) if is_list else [image]
+        if self.cfg.num_frames == 0 and len(frames) > self.engine.c.max_frames:
+            # the reference concatenates the features of every frame of a list, also on an image model
+            raise ValueError(f"{len(frames)} frames on an image model: construct CaptioningModel(..., max_frames="
+                             f"{len(frames)}) (workspaces are sized at construction; now max_frames={self.engine.c.max_frames})")
         self.engine.set_temporal_embedding(is_list)                       # decoder.py:845-857: list branch only
         prefix = batch.get("prefix")
         if prefix is not None:

@@ -95,6 +95,8 @@ CASES = {
     "tiny_prefix_beam4": ("TINY", dict(seed=18, eos_bias=1.5, **_LONG), 1, 1, O.BEAM4, [101, 300, 2]),
     "tiny_video_greedy": ("TINY_VIDEO", dict(seed=19, **_LONG), 2, 3, O.GREEDY, None),
     "tiny_video_beam4": ("TINY_VIDEO", dict(seed=20, eos_bias=0.3, **_LONG), 2, 3, O.BEAM4, None),
+    # an IMAGE model (no temporal embedding) given a LIST of two frames: features concatenated (decoder.py:845-855)
+    "tiny_image_two_frames": ("TINY", dict(seed=35, **_LONG), 2, 2, O.GREEDY, None),
     "tinyl_greedy": ("TINY_L", dict(seed=21, eos_bias=1.0), 3, 1, O.GREEDY, None),
     "base_greedy": ("GIT_BASE", dict(seed=1234), 2, 1, O.GREEDY, None),
     "base_greedy_eos": ("GIT_BASE", dict(seed=1235, tie_output=False, eos_bias=0.25), 2, 1, O.GREEDY, None),
@@ -134,7 +136,8 @@ def run_case(name: str):
         # reference internals for tighter pins
         ref_feat = (torch.cat([f + e for f, e in zip([model.image_encoder(im) for im in frames],
                                                      model.img_temperal_embedding)], dim=1)
-                    if cfg.num_frames else model.image_encoder(frames[0]))
+                    if cfg.num_frames else
+                    torch.cat([model.image_encoder(im) for im in frames], dim=1) if F > 1 else model.image_encoder(frames[0]))
         # teacher-forced logits on a fixed token sequence (exercises `textual` directly)
         g = torch.Generator().manual_seed(5)
         tf_tokens = torch.randint(0, cfg.vocab, (B, 5), generator=g)

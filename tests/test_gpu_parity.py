@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 TINY_CASES = ["tiny_greedy_early_return", "tiny_greedy_untied", "tiny_greedy_long", "tiny_beam4", "tiny_beam4_noeos",
               "tiny_beam4_early_done", "tiny_beam3_pn3", "tiny_ar_beam3", "tiny_prefix_greedy", "tiny_prefix_beam4",
-              "tiny_video_greedy", "tiny_video_beam4", "tinyl_greedy",
+              "tiny_video_greedy", "tiny_video_beam4", "tiny_image_two_frames", "tinyl_greedy",
               "tiny_varres_up", "tiny_varres_down_beam4", "tiny_varres_prefix", "tinyl_varres"]
 BIG_CASES = ["base_greedy", "base_greedy_eos", "base_beam4", "base_prefix_beam4", "large_greedy", "vatex_greedy",
              "vqa_base_480x640"]
