@@ -165,8 +165,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--contexts", type=int, default=4,
                     help="engine contexts (shared weights) kept in flight on separate HIP streams")
-    ap.add_argument("--free-run", action="store_true",
-                    help="do not chain the contexts' image encoders (default: one encoder in flight at a time)")
+    ap.add_argument("--free-run", action="store_true", help="do not chain the contexts' image encoders at all")
+    ap.add_argument("--encoder-chains", type=int, default=2,
+                    help="image encoders of the contexts in flight are chained (context i starts its encoder after "
+                         "context i - chains has finished its own): at most this many encoders run at a time")
     ap.add_argument("--cpu-sweep", action="store_true",
                     help="only time the CPU port at several thread counts (median of 3, bs=8) and print JSON")
     args = ap.parse_args()
@@ -210,10 +212,11 @@ def main():
     for c in ctxs[1:]:
         if args.no_graph:
             c.set_graph(False)
-    if len(ctxs) > 1 and not args.free_run:
-        # serving schedule: encoders of consecutive submissions run one after the other, decode chains float
+    chains = max(1, args.encoder_chains)
+    if len(ctxs) > chains and not args.free_run:
+        # serving schedule: at most `chains` encoders of consecutive submissions in flight, decode chains float
         for i, c in enumerate(ctxs):
-            c.set_encode_after(ctxs[i - 1])
+            c.set_encode_after(ctxs[i - chains])
     # one HIP stream per context.  (BENCH_STREAM_STRIDE: experiment knob -- take every n-th stream of a larger pool, to see
     # how the runtime's stream -> hardware-queue assignment affects the overlap of contexts)
     stride = int(os.environ.get("BENCH_STREAM_STRIDE", "1"))
@@ -280,7 +283,7 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "decode_steps_per_caption": steps_run, "seq_len_returned": info_h[0],
                        "hip_graph": not args.no_graph, "contexts_in_flight": len(ctxs),
-                       "encoders_serialized": len(ctxs) > 1 and not args.free_run},
+                       "encoder_chains": 0 if (args.free_run or len(ctxs) <= chains) else chains},
             # a batch's own latency (submit -> ids ready) while `contexts_in_flight` batches share the GPU
             "batch_latency_ms": {"median": round(lat[len(lat) // 2], 3), "max": round(lat[-1], 3)},
         }

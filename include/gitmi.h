@@ -133,8 +133,9 @@ int  gitmi_clone(gitmi_engine* src, gitmi_engine** out);
 
 /* serving schedule for several contexts of one device: the image encoder (+ decoder prefill) of `e`'s gitmi_generate
  * calls starts only after the encoder of `after`'s most recently submitted call has finished (decode steps are not
- * ordered).  Chain contexts in a ring in submission order so that one MFMA-bound encoder runs at a time while the
- * latency-bound decode chains of the other contexts fill in beside it.  after = NULL: no dependency. */
+ * ordered).  Chain context i (in submission order) after context i - c: at most c MFMA-bound encoders run at a time while
+ * the latency-bound decode chains of the other contexts fill in beside them (measured best on MI355X: 4 contexts, c = 2;
+ * bench.py --encoder-chains).  after = NULL: no dependency. */
 int  gitmi_set_encode_after(gitmi_engine* e, gitmi_engine* after);
 
 /* ---- input resolution of the following encode/generate calls (default: image_size x image_size).

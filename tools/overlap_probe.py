@@ -16,23 +16,26 @@ ctxs = [eng] + [eng.clone() for _ in range(7)]
 streams = [torch.cuda.Stream() for _ in ctxs]
 frames = random_frames(cfg, B, 1, seed=0)
 
-def run(n_ctx, steps_T, n=40, ring=True):
+def run(n_ctx, steps_T, n=48, ring=True, stride=1):
     search = Engine.make_search("greedy", steps_T, 1, 1)
     use = ctxs[:n_ctx]
     for i, c in enumerate(use):
         c.set_encode_after(None)
-    if ring and n_ctx > 1:
+    if ring and n_ctx > stride:
         for i, c in enumerate(use):
-            c.set_encode_after(use[i - 1])
+            c.set_encode_after(use[i - stride])        # stride 1: one encoder at a time; stride s: s interleaved chains
     def go(k):
         for j in range(k):
             i = j % n_ctx
             with torch.cuda.stream(streams[i]):
                 use[i].generate(frames, search, sync=False)
     go(2 * n_ctx); torch.cuda.synchronize()
-    t0 = time.perf_counter(); go(n); torch.cuda.synchronize()
+    t0 = time.perf_counter(); go(n); t_sub = time.perf_counter() - t0; torch.cuda.synchronize()
+    run.submit_ms = t_sub / n * 1e3
     return (time.perf_counter() - t0) / n * 1e3
 
-for T_ in (20, 1):
-    for n_ctx in (1, 2, 4, 8):
-        print("%s contexts=%d: %.3f ms/batch" % ("full call   " if T_ == 20 else "encoder only", n_ctx, run(n_ctx, T_)), flush=True)
+for n_ctx, stride in ((4, 1), (4, 2), (6, 2), (6, 3), (8, 2), (8, 4), (3, 1), (6, 1)):
+    ms = run(n_ctx, 20, ring=True, stride=stride)
+    print("contexts=%d encoder chains=%d: %.3f ms/batch" % (n_ctx, stride, ms), flush=True)
+for n_ctx in (2, 3, 4, 6, 8):
+    print("contexts=%d free-running: %.3f ms/batch" % (n_ctx, run(n_ctx, 20, ring=False)), flush=True)
