@@ -206,6 +206,9 @@ def main():
     eng.load_state_dict(random_state_dict(cfg, seed=1234))
     if args.no_graph:
         eng.set_graph(False)
+    if os.environ.get("BENCH_GEMM_IMPL"):       # experiment knob (A/B of GEMM variants in situ, tools/gpu_epi.sh)
+        from generativeimage2text_amd.engine import set_gemm_impl
+        set_gemm_impl(int(os.environ["BENCH_GEMM_IMPL"]))
     # several batches in flight: context i%C runs on its own stream, so the latency-bound decode steps of
     # one batch overlap the MFMA-bound encoder of the next (weights are shared, workspaces are not)
     ctxs = [eng] + [eng.clone() for _ in range(max(1, args.contexts) - 1)]

@@ -24,7 +24,13 @@
 //     runs one barrier behind), and `s_waitcnt vmcnt(8)` at the end of a read segment confirms the half tile
 //     issued four phases ago -- the one the NEXT phase reads.  Group 1 executes one extra barrier up front:
 //     while one group issues MFMAs (s_setprio 1) the other one's ds_reads and LDS-DMA issues are in flight.
-//   * epilogue through LDS, one 128-row slab at a time; 16-byte row-contiguous stores / residual reads.
+//   * epilogue: bf16 outputs go through LDS, one 128-row slab at a time (16-byte row-contiguous stores); fp32
+//     outputs (the N = 768 GEMMs with the fp32 residual stream) leave the accumulators directly: a lane holds four
+//     consecutive columns of one row, so its residual read and its store are 16-byte accesses and a wave instruction
+//     covers 16 rows x 64 B; every residual load of an MH-row half of the tile is requested before the first is consumed.
+//     No LDS round trip and no barriers, so the waves of a tile drain independently.  Measured (profiles/r02_g_epi_ab.txt):
+//     isolated launches are not faster (a quarter wave touches 16 rows: 4x the requests of the staged copy loop; the
+//     phase is bound by the chip-wide read-modify-write of the residual stream anyway), the whole pass in situ is 1.4 %.
 #include "gitmi_common.h"
 #include "launchers.h"
 #include <type_traits>
@@ -49,6 +55,13 @@ typedef __attribute__((address_space(3))) void lds_void_t;
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
 
+// a + b rounded on its own: never fused with the multiply that produced `a` (keeps act(x) + residual bitwise equal to
+// the kernels that pass act(x) through memory first)
+__device__ __forceinline__ float add_unfused(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+
 template <int N> __device__ __forceinline__ void wait_vm() {
     if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -61,7 +74,8 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // quadrant), used when it fills more CUs in a single round (N = 768: 198 instead of 150 workgroups).  The A slots keep
 // their 16 KiB; with MH = 96 the last four 1-KiB pieces of a slot are loaded (clamped rows) but never read, so every
 // wave still issues two loads per half tile and the vmcnt arithmetic is unchanged.
-template <typename TOut, int ACT, int DBG = 0, int MH = 128>
+// EPI (fp32 outputs only): 1 direct epilogue from the accumulators, 0 the LDS-staged one (A/B: dbg bit 256)
+template <typename TOut, int ACT, int DBG = 0, int MH = 128, int EPI = 1>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     constexpr int BM = 2 * MH, MI = MH / 32;            // row fragments of a 64/48-row quadrant
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
@@ -245,6 +259,54 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
             bias4[qn][j] = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + n0 + qn * 128 + wc * 32 + j * 16 + lg * 4)
                                   : f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (sizeof(TOut) == 4 && EPI == 1) {
+        // ---- direct fp32 epilogue.  acc[qm][qn][j][i][r] is C[m0 + qm*MH + grp*MH/2 + i*16 + l15][n0 + qn*128 +
+        // wc*32 + j*16 + lg*4 + r]; same arithmetic order as the staged path (act(acc + bias), then + residual), so
+        // the two are bitwise equal.  res may alias C (in-place residual stream): every element is read and written
+        // by the same lane, the read first.
+        float* Cf = reinterpret_cast<float*>(g.C);
+        const float* R = g.res;
+        const int col0 = n0 + wc * 32 + lg * 4;
+        const bool has_res = R != nullptr && !(DBG & 1);
+#pragma unroll
+        for (int qm = 0; qm < 2; ++qm) {
+            f32x4_t rr[MI][2][2];
+            if (has_res) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int m = m0 + qm * MH + grp * (MH / 2) + i * 16 + l15;
+                    const int mc = m < g.M ? m : g.M - 1;                      // clamped rows are loaded, never stored
+                    const float* rp = R + (size_t)mc * g.ldr + col0;
+#pragma unroll
+                    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            rr[i][qn][j] = *reinterpret_cast<const f32x4_t*>(rp + qn * 128 + j * 16);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + qm * MH + grp * (MH / 2) + i * 16 + l15;
+                float* cp = Cf + (size_t)m * g.ldc + col0;
+                const bool ok = m < g.M && !(DBG & 1);
+#pragma unroll
+                for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4_t v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = apply_act_t<ACT>(acc[qm][qn][j][i][r] + bias4[qn][j][r]);
+                        if (has_res) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = add_unfused(v[r], rr[i][qn][j][r]);
+                        }
+                        if (ok) *reinterpret_cast<f32x4_t*>(cp + qn * 128 + j * 16) = v;
+                    }
+            }
+        }
+        return;
+    }
+
 #pragma unroll
     for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
@@ -314,7 +376,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 
 }  // namespace
 
-template <typename TOut, int MH>
+template <typename TOut, int MH, int EPI = 1>
 static void launch_p8_t(const GemmArgs& g, hipStream_t s) {
     if (g.dbg) {      // measurement builds (tools/gemm_dbg.py); act is ignored
         if constexpr (MH == 128) {
@@ -329,11 +391,11 @@ static void launch_p8_t(const GemmArgs& g, hipStream_t s) {
     }
     switch (g.act) {
         case GITMI_ACT_QUICKGELU:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_QUICKGELU, 0, MH>), dim3(g.nwg), dim3(512), 0, s, g); break;
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_QUICKGELU, 0, MH, EPI>), dim3(g.nwg), dim3(512), 0, s, g); break;
         case GITMI_ACT_GELU_ERF:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_GELU_ERF, 0, MH>), dim3(g.nwg), dim3(512), 0, s, g); break;
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_GELU_ERF, 0, MH, EPI>), dim3(g.nwg), dim3(512), 0, s, g); break;
         default:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_NONE, 0, MH>), dim3(g.nwg), dim3(512), 0, s, g); break;
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_NONE, 0, MH, EPI>), dim3(g.nwg), dim3(512), 0, s, g); break;
     }
 }
 
@@ -386,12 +448,16 @@ hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s) {
     int max_cnt = 0;
     p8_plan(g, mh, &g.ng, &max_cnt);
     g.nwg = 8 * max_cnt;
+    const bool staged = (g.dbg & 256) != 0;              // A/B: fp32 outputs through the LDS-staged epilogue
+    g.dbg &= ~256;
     if (mh == 96) {
-        if (out_f32) launch_p8_t<float, 96>(g, s);
-        else launch_p8_t<bf16_t, 96>(g, s);
+        if (!out_f32) launch_p8_t<bf16_t, 96>(g, s);
+        else if (staged) launch_p8_t<float, 96, 0>(g, s);
+        else launch_p8_t<float, 96>(g, s);
     } else {
-        if (out_f32) launch_p8_t<float, 128>(g, s);
-        else launch_p8_t<bf16_t, 128>(g, s);
+        if (!out_f32) launch_p8_t<bf16_t, 128>(g, s);
+        else if (staged) launch_p8_t<float, 128, 0>(g, s);
+        else launch_p8_t<float, 128>(g, s);
     }
     return hipGetLastError();
 }

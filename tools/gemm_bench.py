@@ -31,7 +31,10 @@ def bench(fn, reps=20):
 def main():
     impls = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["2", "6", "9"])]
     g = torch.Generator().manual_seed(0)
+    only = os.environ.get("GEMM_BENCH_SHAPES")         # comma-separated shape names
     for name, M, N, K, odt, act, use_res in SHAPES:
+        if only and name not in only.split(","):
+            continue
         A = (torch.randn(M, K, generator=g)).bfloat16().cuda()
         W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
         bias = torch.randn(N, generator=g).cuda()
