@@ -29,7 +29,8 @@ import torch
 
 from .configs import MODEL_PARAMS, config_for_model
 from .model import GeneratorWithBeamSearch, CaptioningModel
-from .tsv_io import TSVFile, tsv_writer, concat_tsv_files
+from .tsv_io import (TSVFile, tsv_writer, concat_tsv_files, json_dump,                 # noqa: F401  (re-exported:
+                     convert_tsv_to_vqa_json, convert_tsv_to_coco_format)                    #  the reference has them here)
 
 MAX_VQA_QUESTIONS = 16      # questions of one image answered in one engine call (batched ragged prefixes)
 
@@ -245,11 +246,6 @@ def test_git_inference_single_image(image_path, model_name, prefix, *, checkpoin
     cap = tokenizer.decode(result["predictions"][0].tolist(), skip_special_tokens=True)
     logging.info("output: {}".format(cap))
     test_git_inference_single_image.last_output = cap
-
-
-def json_dump(obj) -> str:
-    """common.py:223-226: sorted keys, compact separators -- what the reference writes into every TSV row."""
-    return json.dumps(obj, sort_keys=True, separators=(",", ":"))
 
 
 def ensure_process_group(rank: int, world: int) -> bool:

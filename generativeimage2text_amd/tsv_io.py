@@ -2,9 +2,12 @@
 `TSVFile` / `tsv_writer` / `concat_tsv_files` (generativeimage2text/tsv_io.py:22-31, 121-374):
 
   <name>.tsv           rows of tab separated fields, '\\n' terminated
+  <name>.lineidx       the byte offset of every row as decimal text, one per line
   <name>.lineidx.8b    one little-endian uint64 byte offset per row
 
-Only what `test_git_inference_single_tsv` needs (random row access, streaming write, concat).
+Only what `test_git_inference_single_tsv` and the converters of its outputs need (random row access, streaming
+write, concat).  The format is pinned against the reference's own writer / reader / concat by
+oracle/make_tsv_golden.py -> tests/golden/tsv_wire.npz (tests/test_host.py).
 """
 from __future__ import annotations
 
@@ -61,7 +64,17 @@ class TSVFile:
         if self._fp is None:
             self._fp = open(self.tsv_file, "rb")
         self._fp.seek(self._offsets[idx])
-        return self._fp.readline().decode("utf-8").rstrip("\n").split("\t")
+        # fields are whitespace-stripped like the reference's TSVFile.seek / __iter__ (tsv_io.py:199-212, 233-238)
+        return [x.strip() for x in self._fp.readline().decode("utf-8").split("\t")]
+
+    def get_key(self, idx: int) -> str:
+        """First column of row idx (reference tsv_io.py:223-224, 264-268: read up to the first tab, not stripped)."""
+        if self._fp is None:
+            self._fp = open(self.tsv_file, "rb")
+        self._fp.seek(self._offsets[idx])
+        line = self._fp.readline()
+        assert b"\t" in line, "get_key needs a second column (the reference reads up to the first tab)"
+        return line[:line.index(b"\t")].decode("utf-8")
 
     def __iter__(self) -> Iterator[List[str]]:
         for i in range(len(self)):
@@ -73,33 +86,41 @@ class TSVFile:
             self._fp = None
 
 
-def tsv_reader(tsv_file: str) -> Iterator[List[str]]:
+def tsv_reader(tsv_file: str, sep: str = "\t") -> Iterator[List[str]]:
+    """Sequential rows, fields stripped (reference tsv_io.py:87-90)."""
     with open(tsv_file, "r", encoding="utf-8") as f:
         for line in f:
-            yield line.rstrip("\n").split("\t")
+            yield [x.strip() for x in line.split(sep)]
 
 
 def tsv_writer(rows: Iterable[Sequence], tsv_file: str) -> None:
-    """Stream rows to <tsv_file> and its .lineidx.8b, via temporary names then rename
-    (reference tsv_io.py:356-374)."""
+    """Stream rows to <tsv_file>, its .lineidx and its .lineidx.8b -- byte for byte what the reference's
+    tsv_writer produces (tsv_io.py:356-374: fields are str()-ed unless bytes).  Written under temporary names and
+    renamed into place, the data file last: a reader polling for the .tsv (the multi-rank hand-off of
+    inference.py:214-225) never sees a partial shard."""
     d = os.path.dirname(tsv_file)
     if d:
         os.makedirs(d, exist_ok=True)
-    tmp, tmp_idx = tsv_file + ".tmp", _idx8b(tsv_file) + ".tmp"
+    tmp, tmp_txt, tmp_idx = tsv_file + ".tmp", _idx_txt(tsv_file) + ".tmp", _idx8b(tsv_file) + ".tmp"
     pos = 0
-    with open(tmp, "wb") as f, open(tmp_idx, "wb") as fi:
+    with open(tmp, "wb") as f, open(tmp_txt, "w") as ft, open(tmp_idx, "wb") as fi:
         for row in rows:
             assert row is not None
-            line = ("\t".join(x if isinstance(x, str) else str(x) for x in row) + "\n").encode("utf-8")
+            line = b"\t".join(x if isinstance(x, bytes) else str(x).encode("utf-8") for x in row) + b"\n"
             f.write(line)
+            ft.write(str(pos) + "\n")
             fi.write(struct.pack("<Q", pos))
             pos += len(line)
-    os.replace(tmp, tsv_file)
+    os.replace(tmp_txt, _idx_txt(tsv_file))
     os.replace(tmp_idx, _idx8b(tsv_file))
+    os.replace(tmp, tsv_file)
 
 
 def concat_tsv_files(tsvs: Sequence[str], out_tsv: str) -> None:
-    """Byte-concatenate shard files and rebase their offsets (reference tsv_io.py:22-31, 57-85)."""
+    """Byte-concatenate shard files and rebase their .lineidx.8b offsets (reference tsv_io.py:22-31, 57-85; like
+    the reference, no text .lineidx is produced for the concatenation)."""
+    if len(tsvs) == 1 and tsvs[0] == out_tsv:
+        return
     base = 0
     with open(out_tsv + ".tmp", "wb") as fo, open(_idx8b(out_tsv) + ".tmp", "wb") as fi:
         for t in tsvs:
@@ -112,3 +133,43 @@ def concat_tsv_files(tsvs: Sequence[str], out_tsv: str) -> None:
             base += len(data)
     os.replace(out_tsv + ".tmp", out_tsv)
     os.replace(_idx8b(out_tsv) + ".tmp", _idx8b(out_tsv))
+
+
+# ---- consumers of the task outputs (inference.py:227-252) ------------------------------------------------
+def json_dump(obj) -> str:
+    """common.py:223-226: sorted keys, compact separators -- what the reference writes into every TSV row."""
+    import json
+    return json.dumps(obj, sort_keys=True, separators=(",", ":"))
+
+
+def convert_tsv_to_vqa_json(predict_file: str, out_json: str) -> None:
+    """One-column VQA rows `{"answer":..,"question_id":..}` -> one JSON list (inference.py:227-229)."""
+    import json
+    result = [json.loads(s) for s, in tsv_reader(predict_file)]
+    d = os.path.dirname(out_json)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    with open(out_json, "wb") as f:
+        f.write(json_dump(result).encode())
+
+
+def convert_tsv_to_coco_format(res_tsv: str, outfile: str, sep: str = "\t", key_col: int = 0, cap_col: int = 1) -> None:
+    """Caption rows `key \\t [{"caption": ..}]` -> COCO result JSON `[{"image_id", "caption"}]` (inference.py:231-252;
+    a row without a caption column, or with an empty list, counts as the empty caption)."""
+    import json
+    results = []
+    with open(res_tsv) as fp:
+        for line in fp:
+            parts = line.strip().split(sep)
+            key = parts[key_col]
+            if cap_col < len(parts):
+                caps = json.loads(parts[cap_col])
+                if len(caps) == 0:
+                    caps = [{"caption": ""}]
+                assert len(caps) == 1, "cannot evaluate multiple captions per image"
+                cap = caps[0]["caption"]
+            else:
+                cap = ""
+            results.append({"image_id": key, "caption": cap})
+    with open(outfile, "w") as fp:
+        json.dump(results, fp)

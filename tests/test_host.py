@@ -1,6 +1,7 @@
 """CPU: the C-ABI library loads and exports every symbol include/gitmi.h declares; host-side logic."""
 import base64
 import io
+import json
 import os
 import re
 
@@ -104,6 +105,79 @@ def test_tsv_roundtrip_and_concat(tmp_path):
     t = tsv_io.TSVFile(out)
     assert len(t) == 8 and t[6] == ["q1", "wé1"] and t[0] == ["k0", "v0"]
     assert list(tsv_io.tsv_reader(out))[7] == ["q2", "wé2"]
+
+
+def _gold_tsv():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "tsv_wire.npz"))
+
+
+def _rows_fixture():
+    # the rows oracle/make_tsv_golden.py fed to the REFERENCE's tsv_writer
+    jpeg_like = base64.b64encode(bytes(range(256)) * 3).decode()
+    return [["img_0", jpeg_like], ["img 1 with spaces", "café 中文"], ["k2", ""],
+            ["k3", "  padded field  ", "third"], [4, 5.5, "mixed"], ["only_one_column"]]
+
+
+def test_tsv_writer_bytes_equal_reference(tmp_path):
+    """.tsv, .lineidx and .lineidx.8b byte for byte what the reference's tsv_writer wrote for the same rows
+    (tests/golden/tsv_wire.npz, frozen by oracle/make_tsv_golden.py from /root/reference)."""
+    g = _gold_tsv()
+    a = str(tmp_path / "a.tsv")
+    tsv_io.tsv_writer(_rows_fixture(), a)
+    for ext in (".tsv", ".lineidx", ".lineidx.8b"):
+        got = open(os.path.splitext(a)[0] + ext, "rb").read()
+        assert got == g["a" + ext].tobytes(), ext
+
+
+def test_tsv_reads_equal_reference(tmp_path):
+    """Files written by the reference, read back here: TSVFile[i], iteration, tsv_reader, get_key."""
+    g = _gold_tsv()
+    a = str(tmp_path / "a.tsv")
+    for ext in (".tsv", ".lineidx", ".lineidx.8b"):
+        open(os.path.splitext(a)[0] + ext, "wb").write(g["a" + ext].tobytes())
+    t = tsv_io.TSVFile(a)
+    assert len(t) == int(g["a_len"]) == t.num_rows()
+    assert [t[i] for i in range(len(t))] == json.loads(str(g["a_rows_getitem"]))
+    assert [r for r in tsv_io.TSVFile(a)] == json.loads(str(g["a_rows_iter"]))
+    assert [r for r in tsv_io.tsv_reader(a)] == json.loads(str(g["a_rows_reader"]))
+    assert [t.get_key(i) for i in (0, 1, 3)] == json.loads(str(g["a_keys"]))
+    # the reference requires the .8b index; here the text index or the data alone are enough as well
+    os.remove(os.path.splitext(a)[0] + ".lineidx.8b")
+    assert [r for r in tsv_io.TSVFile(a)] == json.loads(str(g["a_rows_iter"]))
+    os.remove(os.path.splitext(a)[0] + ".lineidx")
+    assert [r for r in tsv_io.TSVFile(a)] == json.loads(str(g["a_rows_iter"]))
+
+
+def test_tsv_concat_and_task_rows_equal_reference(tmp_path):
+    """Caption rows / one-column VQA rows as inference.py:199, 212 writes them, the two-shard concat of the
+    multi-rank hand-off, and the two converters of the outputs."""
+    g = _gold_tsv()
+    caps = ["a dog on a couch", 'café "quoted"', ""]
+    cap_rows = [["img_%d" % i, inference.json_dump([{"caption": c}])] for i, c in enumerate(caps)]
+    b, c, allp = str(tmp_path / "caps.0.2.tsv"), str(tmp_path / "caps.1.2.tsv"), str(tmp_path / "caps.tsv")
+    tsv_io.tsv_writer(cap_rows[:2], b)
+    tsv_io.tsv_writer(cap_rows[2:], c)
+    tsv_io.concat_tsv_files([b, c], allp)
+    for name, p in (("caps0", b), ("caps1", c), ("caps_all", allp)):
+        assert open(p, "rb").read() == g[name + ".tsv"].tobytes(), name
+        assert open(os.path.splitext(p)[0] + ".lineidx.8b", "rb").read() == g[name + ".lineidx.8b"].tobytes(), name
+    assert [r for r in tsv_io.TSVFile(allp)] == json.loads(str(g["caps_all_rows"]))
+    tsv_io.concat_tsv_files([allp], allp)                 # the reference's no-op case (tsv_io.py:23-24)
+    assert open(allp, "rb").read() == g["caps_all.tsv"].tobytes()
+    v = str(tmp_path / "vqa.tsv")
+    tsv_io.tsv_writer([[inference.json_dump({"answer": a_, "question_id": q})] for a_, q in
+                       [("yes", 17), ("two", 4), ("café", 900001)]], v)
+    assert open(v, "rb").read() == g["vqa.tsv"].tobytes()
+    out_json = str(tmp_path / "sub" / "vqa.json")
+    inference.convert_tsv_to_vqa_json(v, out_json)
+    assert open(out_json).read() == str(g["vqa_json"])
+    assert [inference.json_dump({"b": 1, "a": [1, 2, {"z": None, "y": True}], "c": "café 中"}),
+            inference.json_dump([{"caption": "x"}]),
+            inference.json_dump({"answer": "no", "question_id": 3})] == json.loads(str(g["json_dump_cases"]))
+    coco = str(tmp_path / "coco.json")
+    inference.convert_tsv_to_coco_format(allp, coco)
+    # (the empty caption is kept as a real, empty string: the row's JSON column is `[{"caption":""}]`)
+    assert json.load(open(coco)) == [{"image_id": "img_%d" % i, "caption": c_} for i, c_ in enumerate(caps)]
 
 
 def test_image_transform_shape_and_normalisation():
