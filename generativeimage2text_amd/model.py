@@ -53,11 +53,15 @@ class GeneratorWithBeamSearch:
 
 
 def load_state_dict_by_suffix(model_keys: Sequence[str], loaded: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-    """Key alignment of torch_common.py:93-145: strip 'module.' prefixes, then give every model key the
-    loaded key that is its LONGEST suffix."""
+    """Key alignment of torch_common.py:45-54, 93-145: strip EVERY leading 'module.' (DataParallel wrapped any number
+    of times), then give every model key the loaded key that is its LONGEST (purely textual) suffix; model keys that
+    nothing matches are left out.  Pinned against the reference's align_and_update_state_dicts by
+    tests/golden/state_dict_align.json (oracle/make_host_golden.py)."""
     stripped = {}
     for k, v in loaded.items():
-        stripped[k[len("module."):] if k.startswith("module.") else k] = v
+        while k.startswith("module."):
+            k = k[len("module."):]
+        stripped[k] = v
     out: Dict[str, torch.Tensor] = {}
     for key in model_keys:
         best = None

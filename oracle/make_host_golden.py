@@ -1,4 +1,5 @@
-"""Pin the TSV wire format against the REAL reference and freeze it as a fixture.
+"""Pin the host-side formats (SURVEY.md 8f-2 TSV wire format, 8f-4 checkpoint key alignment) against the REAL
+reference and freeze them as fixtures.
 
 Runs only in the build container (needs /root/reference).  The reference's tsv_io.py imports `azfuse.File`
 (absent here, tsv_io.py:8) and, inside concate_lineidx_8b, `pathos` (tsv_io.py:40); both only wrap local file
@@ -15,7 +16,12 @@ json_dump of common.py) is the reference's own code.  What is frozen into tests/
   * the caption / VQA rows of inference.py:199, 212 written by the reference's writer and what
     convert_tsv_to_vqa_json / convert_tsv_to_coco_format-style readers see.
 
-Usage:  python oracle/make_tsv_golden.py
+Second fixture, tests/golden/state_dict_align.json: torch_common.load_state_dict's key handling
+(torch_common.py:45-54, 93-145: strip every leading 'module.', give each model key the loaded key that is its longest
+suffix, drop model keys nothing matches) run on synthetic key sets: plain, DataParallel-wrapped once and twice,
+checkpoints saved from a sub-module (shorter keys), ambiguous suffixes, unmatched keys on both sides.
+
+Usage:  python oracle/make_host_golden.py
 """
 from __future__ import annotations
 
@@ -86,7 +92,59 @@ def read_bytes(path):
         return np.frombuffer(f.read(), dtype=np.uint8).copy()
 
 
+def align_cases():
+    model_keys = ["image_encoder.conv1.weight", "image_encoder.ln_pre.weight", "image_encoder.ln_pre.bias",
+                  "image_encoder.transformer.resblocks.0.ln_1.weight", "image_encoder.transformer.resblocks.0.ln_2.weight",
+                  "image_encoder.transformer.resblocks.10.ln_1.weight", "image_encoder.transformer.resblocks.1.ln_1.weight",
+                  "textual.embedding.words.weight", "textual.output.weight", "textual.output.bias",
+                  "textual.transformer.encoder.layer.0.output.dense.weight",
+                  "textual.transformer.encoder.layer.0.attention.output.dense.weight",
+                  "textual.transformer.encoder.layer.0.output.LayerNorm.weight",
+                  "textual.transformer.encoder.layer.0.attention.output.LayerNorm.weight",
+                  "img_temperal_embedding.0", "textual.visual_projection.0.weight"]
+    cases = {
+        "plain": list(model_keys) + ["image_encoder.proj", "extra.unused.key"],
+        "module_once": ["module." + k for k in model_keys],
+        "module_twice": ["module.module." + k for k in model_keys[:6]] + model_keys[6:],
+        # saved from sub-modules: shorter keys that are suffixes of the model's
+        "submodule": ["conv1.weight", "ln_pre.weight", "ln_pre.bias", "resblocks.0.ln_1.weight", "0.ln_2.weight",
+                      "resblocks.10.ln_1.weight", "1.ln_1.weight", "words.weight", "output.weight", "output.bias",
+                      "layer.0.output.dense.weight", "attention.output.dense.weight", "output.LayerNorm.weight",
+                      "attention.output.LayerNorm.weight", "img_temperal_embedding.0", "visual_projection.0.weight"],
+        # several loaded keys are suffixes of one model key: the longest wins
+        "ambiguous": ["weight", "dense.weight", "output.dense.weight", "attention.output.dense.weight", "bias",
+                      "output.bias", "ln_1.weight", "0.ln_1.weight", "resblocks.0.ln_1.weight"],
+        "nothing_matches": ["foo.bar", "baz"],
+    }
+    return model_keys, cases
+
+
+def make_align_fixture():
+    import torch
+    az = types.ModuleType("azfuse")
+    az.File = _LocalFile
+    sys.modules.setdefault("azfuse", az)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from generativeimage2text import torch_common as T
+    model_keys, cases = align_cases()
+    out = {"model_keys": model_keys, "cases": {}}
+    for name, loaded_keys in cases.items():
+        # tensors carry an id so that the mapping model key -> loaded key can be read back
+        loaded = {k: torch.tensor([float(i)]) for i, k in enumerate(loaded_keys)}
+        model_sd = {k: torch.tensor([-1.0]) for k in model_keys}
+        stripped = T.strip_prefix_if_present(loaded, prefix="module.")            # torch_common.py:94
+        T.align_and_update_state_dicts(model_sd, stripped)                        # torch_common.py:95
+        out["cases"][name] = {"loaded_keys": loaded_keys,
+                              "mapping": {k: loaded_keys[int(v.item())] for k, v in model_sd.items()}}
+    path = os.path.join(ROOT, "tests", "golden", "state_dict_align.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote", path, {n: len(c["mapping"]) for n, c in out["cases"].items()})
+
+
 def main():
+    make_align_fixture()
     R, C = import_reference_tsv()
     tmp = tempfile.mkdtemp(prefix="tsvgold_")
     old_tmp = os.environ.get("GIT_TMP_FOLDER")

@@ -107,6 +107,17 @@ def test_tsv_roundtrip_and_concat(tmp_path):
     assert list(tsv_io.tsv_reader(out))[7] == ["q2", "wé2"]
 
 
+def test_state_dict_key_alignment_equals_reference():
+    """model key -> checkpoint key exactly as the reference's load_state_dict pairs them (torch_common.py:93-145),
+    on the synthetic key sets frozen in tests/golden/state_dict_align.json."""
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_align.json")))
+    for name, case in g["cases"].items():
+        loaded = {k: k for k in case["loaded_keys"]}                 # the "tensor" is the loaded key's own name
+        got = model.load_state_dict_by_suffix(g["model_keys"], loaded)
+        # the fixture names loaded keys as given (with their 'module.' prefixes)
+        assert got == case["mapping"], name
+
+
 def _gold_tsv():
     return np.load(os.path.join(os.path.dirname(__file__), "golden", "tsv_wire.npz"))
 
