@@ -7,6 +7,7 @@ Mirrors what the reference spreads over `model.py:9-61` (decoder: always 768 hid
 from __future__ import annotations
 
 import dataclasses
+import os
 from typing import Dict, Optional
 
 
@@ -74,6 +75,44 @@ MODEL_PARAMS: Dict[str, dict] = {
     "GIT_LARGE_MSRVTT_QA": {"image_encoder_type": "CLIPViT_L_14", "visual_feature_size": 1024,
                             "num_image_with_embedding": 6},
 }
+
+
+def _merge_into(base: dict, over: dict) -> dict:
+    """`over`'s leaves written into `base`, nested dicts merged key by key (what the reference's path-wise update of
+    tsv_io.py:102-106 amounts to)."""
+    for k, v in over.items():
+        if isinstance(v, dict) and isinstance(base.get(k), dict):
+            _merge_into(base[k], v)
+        else:
+            base[k] = v
+    return base
+
+
+def load_from_yaml_file(file_name: str) -> dict:
+    """A parameter.yaml with the reference's `_base_` include chain resolved (tsv_io.py:92-107): the file named by
+    `_base_` (relative to the including file) is loaded first and this file's values are written over it."""
+    import yaml
+    with open(file_name, "r") as fp:
+        data = yaml.safe_load(fp)
+    while isinstance(data, dict) and "_base_" in data:
+        base = load_from_yaml_file(os.path.join(os.path.dirname(file_name), data["_base_"]))
+        assert isinstance(base, dict)
+        del data["_base_"]
+        data = _merge_into(base, data)
+    return data if data is not None else {}
+
+
+def load_model_param(model_name: str, yaml_dir: str = "aux_data/models") -> dict:
+    """The `param` dict of a model: `<yaml_dir>/<model_name>/parameter.yaml` when that file exists -- the reference
+    reads aux_data/models/<name>/parameter.yaml in the single-image task (inference.py:68-70) and
+    output/<name>/parameter.yaml in the TSV task (inference.py:135-137) --, else the built-in restatement of the
+    shipped yaml files (MODEL_PARAMS; the reference would silently fall back to GIT_BASE defaults there)."""
+    path = os.path.join(yaml_dir, model_name, "parameter.yaml")
+    if os.path.isfile(path):
+        return load_from_yaml_file(path)
+    if model_name not in MODEL_PARAMS:
+        raise KeyError(f"unknown GIT model '{model_name}': no {path} and not one of {sorted(MODEL_PARAMS)}")
+    return dict(MODEL_PARAMS[model_name])
 
 
 def config_from_param(param: Optional[dict], name: str = "GIT") -> GitModelConfig:

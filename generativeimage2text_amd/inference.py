@@ -27,7 +27,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 import torch
 
-from .configs import MODEL_PARAMS, config_for_model
+from .configs import MODEL_PARAMS, config_for_model, config_from_param, load_model_param      # noqa: F401
 from .model import GeneratorWithBeamSearch, CaptioningModel
 from .tsv_io import (TSVFile, tsv_writer, concat_tsv_files, json_dump,                 # noqa: F401  (re-exported:
                      convert_tsv_to_vqa_json, convert_tsv_to_coco_format)                    #  the reference has them here)
@@ -206,8 +206,10 @@ def load_checkpoint(model_name: str, checkpoint: Optional[str] = None):
 
 
 def build_model(model_name: str, tokenizer, checkpoint=None, max_batch: int = 64, precision: str = "bf16",
-                decoder=None) -> CaptioningModel:
-    cfg = config_for_model(model_name)
+                decoder=None, param: Optional[dict] = None) -> CaptioningModel:
+    """param: the model's parameter dict when the caller already read it (a parameter.yaml); default: the built-in
+    table entry of `model_name`."""
+    cfg = config_for_model(model_name) if param is None else config_from_param(param, name=model_name)
     if decoder is None:
         decoder = GeneratorWithBeamSearch(eos_index=tokenizer.sep_token_id, max_steps=1024, beam_size=4,
                                           length_penalty=0.6)               # model.py:34-40
@@ -227,16 +229,28 @@ def _prefix_ids(tokenizer, prefix: str, max_text_len: int = 40) -> List[int]:
 
 
 # ---- tasks --------------------------------------------------------------------------------------
+def _task_param(model_name: str, yaml_dir: str):
+    """-> (param, from_file): `<yaml_dir>/<model_name>/parameter.yaml` if present (the file the reference task
+    reads), else the built-in table entry; a name in neither -> KeyError."""
+    if op.isfile(op.join(yaml_dir, model_name, "parameter.yaml")):
+        return load_model_param(model_name, yaml_dir), True
+    if model_name not in MODEL_PARAMS:
+        raise KeyError(f"unknown GIT model '{model_name}': no {yaml_dir}/{model_name}/parameter.yaml and not one of "
+                       f"{sorted(MODEL_PARAMS)}")
+    return dict(MODEL_PARAMS[model_name]), False
+
+
 def test_git_inference_single_image(image_path, model_name, prefix, *, checkpoint=None, precision="f32"):
     """inference.py:67-109.  image_path: str or list of str (video frames); logs 'output: <caption>'.
     precision "f32" (default) = the reference's arithmetic (ids bit-identical); "bf16" = throughput mode."""
-    param = MODEL_PARAMS.get(model_name, {})
+    param, from_file = _task_param(model_name, "aux_data/models")           # inference.py:68-70
     tokenizer = get_tokenizer()
     if isinstance(image_path, str):
         image_path = [image_path]
     transforms = get_image_transform(param, gpu=True)
     img = [transforms(load_image_by_pil(p)) for p in image_path]
-    model = build_model(model_name, tokenizer, checkpoint, max_batch=1, precision=precision)
+    model = build_model(model_name, tokenizer, checkpoint, max_batch=1, precision=precision,
+                        **({"param": param} if from_file else {}))
     model.cuda()
     model.eval()
     img = [i.unsqueeze(0).cuda() for i in img]
@@ -356,14 +370,14 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
 
     precision: "f32" (default) reproduces the reference's fp32 token ids bit for bit; "bf16" is the
     throughput mode (ids may leave the reference's at near-ties, DESIGN.md "parity budget")."""
-    param = MODEL_PARAMS.get(model_name, {})
+    param, from_file = _task_param(model_name, "output")                    # inference.py:135-137
     tokenizer = get_tokenizer()
     torch.cuda.set_device(get_mpi_local_rank())                             # inference.py:152
     is_vqa = bool(question_tsv)
     if "test_respect_ratio_max" in param:
         batch_size = 1            # aspect-preserving resize: every image has its own resolution (as in the reference)
     model = build_model(model_name, tokenizer, checkpoint, max_batch=MAX_VQA_QUESTIONS if is_vqa else batch_size,
-                        precision=precision)
+                        precision=precision, **({"param": param} if from_file else {}))
     transforms = get_image_transform(param, gpu=True)
 
     def caption_batch(imgs: Sequence[torch.Tensor]) -> List[str]:

@@ -21,6 +21,10 @@ Second fixture, tests/golden/state_dict_align.json: torch_common.load_state_dict
 suffix, drop model keys nothing matches) run on synthetic key sets: plain, DataParallel-wrapped once and twice,
 checkpoints saved from a sub-module (shorter keys), ambiguous suffixes, unmatched keys on both sides.
 
+Third fixture, tests/golden/model_params.json: every aux_data/models/*/parameter.yaml of the reference read with the
+reference's own load_from_yaml_file (tsv_io.py:92-107) -- the table generativeimage2text_amd/configs.py restates --
+plus a `_base_` chain resolved by that loader (the include mechanism of tsv_io.py:97-106).
+
 Usage:  python oracle/make_host_golden.py
 """
 from __future__ import annotations
@@ -143,8 +147,33 @@ def make_align_fixture():
     print("wrote", path, {n: len(c["mapping"]) for n, c in out["cases"].items()})
 
 
+def make_param_fixture(R):
+    import glob
+    out = {"models": {}, "base_chain": {}}
+    for p in sorted(glob.glob(os.path.join(REF, "aux_data", "models", "*", "parameter.yaml"))):
+        out["models"][os.path.basename(os.path.dirname(p))] = R.load_from_yaml_file(p)
+    tmp = tempfile.mkdtemp(prefix="yamlgold_")
+    try:
+        files = {
+            "root.yaml": "image_encoder_type: CLIPViT_L_14\nvisual_feature_size: 1024\nnested:\n  a: 1\n  b: 2\n",
+            "mid.yaml": "_base_: root.yaml\ntest_crop_size: 420\nnested:\n  b: 3\n",
+            "leaf.yaml": "_base_: mid.yaml\ntest_respect_ratio_max: 560\nnested:\n  c: 4\n",
+        }
+        for n, txt in files.items():
+            with open(os.path.join(tmp, n), "w") as f:
+                f.write(txt)
+        out["base_chain"] = {"files": files, "leaf": R.load_from_yaml_file(os.path.join(tmp, "leaf.yaml"))}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    path = os.path.join(ROOT, "tests", "golden", "model_params.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote", path, sorted(out["models"]), out["base_chain"]["leaf"])
+
+
 def main():
     make_align_fixture()
+    make_param_fixture(import_reference_tsv()[0])
     R, C = import_reference_tsv()
     tmp = tempfile.mkdtemp(prefix="tsvgold_")
     old_tmp = os.environ.get("GIT_TMP_FOLDER")

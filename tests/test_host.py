@@ -118,6 +118,35 @@ def test_state_dict_key_alignment_equals_reference():
         assert got == case["mapping"], name
 
 
+def test_model_params_equal_reference_yaml(tmp_path):
+    """configs.MODEL_PARAMS against every aux_data/models/*/parameter.yaml of the reference as its own loader reads
+    them (tests/golden/model_params.json); the `_base_` include chain; the run-time lookup order of the tasks."""
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "model_params.json")))
+    for name, param in g["models"].items():
+        assert configs.MODEL_PARAMS[name] == param, name
+    for name in set(configs.MODEL_PARAMS) - set(g["models"]):
+        assert configs.MODEL_PARAMS[name] == {}, name          # GIT_BASE, GIT_BASE_COCO, GIT_BASE_TEXTCAPS: no yaml
+    d = tmp_path / "models" / "MY_MODEL"
+    d.mkdir(parents=True)
+    for n, txt in g["base_chain"]["files"].items():
+        (d / n).write_text(txt)
+    assert configs.load_from_yaml_file(str(d / "leaf.yaml")) == g["base_chain"]["leaf"]
+    (d / "parameter.yaml").write_text("_base_: leaf.yaml\nnum_image_with_embedding: 6\n")
+    p = configs.load_model_param("MY_MODEL", str(tmp_path / "models"))
+    assert p["num_image_with_embedding"] == 6 and p["test_crop_size"] == 420
+    cfg = configs.config_from_param(p, name="MY_MODEL")
+    assert (cfg.patch, cfg.vit_width, cfg.num_frames, cfg.image_size, cfg.max_image_hw) == (14, 1024, 6, 420, (420, 560))
+    assert configs.load_model_param("GIT_BASE_VATEX", str(tmp_path / "models")) == {"num_image_with_embedding": 6}
+    with pytest.raises(KeyError):
+        configs.load_model_param("NOT_A_MODEL", str(tmp_path / "models"))
+    p, from_file = inference._task_param("GIT_LARGE_VQAv2", str(tmp_path / "models"))
+    assert p["test_respect_ratio_max"] == 560 and not from_file
+    p, from_file = inference._task_param("MY_MODEL", str(tmp_path / "models"))
+    assert p["visual_feature_size"] == 1024 and from_file
+    with pytest.raises(KeyError):
+        inference._task_param("NOT_A_MODEL", str(tmp_path / "models"))
+
+
 def _gold_tsv():
     return np.load(os.path.join(os.path.dirname(__file__), "golden", "tsv_wire.npz"))
 
