@@ -169,6 +169,11 @@ def main():
     ap.add_argument("--encoder-chains", type=int, default=2,
                     help="image encoders of the contexts in flight are chained (context i starts its encoder after "
                          "context i - chains has finished its own): at most this many encoders run at a time")
+    ap.add_argument("--phased", type=int, default=0,
+                    help="G > 0: schedule the contexts in groups of G batches -- the image encoders (+ prefill) of a group "
+                         "first (at most --encoder-chains at a time), then its G decode chains side by side with no "
+                         "encoder running (gitmi_generate_encode / gitmi_generate_decode); 0: every context submits "
+                         "whole calls and the phases of different batches mix freely")
     ap.add_argument("--cpu-sweep", action="store_true",
                     help="only time the CPU port at several thread counts (median of 3, bs=8) and print JSON")
     args = ap.parse_args()
@@ -211,6 +216,8 @@ def main():
         set_gemm_impl(int(os.environ["BENCH_GEMM_IMPL"]))
     # several batches in flight: context i%C runs on its own stream, so the latency-bound decode steps of
     # one batch overlap the MFMA-bound encoder of the next (weights are shared, workspaces are not)
+    if args.phased > 0:
+        args.contexts = args.phased
     ctxs = [eng] + [eng.clone() for _ in range(max(1, args.contexts) - 1)]
     for c in ctxs[1:]:
         if args.no_graph:
@@ -254,12 +261,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    # phased schedule: one group = up to G batches; all encoders (+ prefill) of the group, then all its decode chains.
+    # Stream i carries batch i of every group; events make every decode wait for the group's LAST encoder and every
+    # encoder of the next group for the group's decodes, so that no encoder ever runs next to a decode chain.
+    group_dec_done = []
+
+    def run_group(n, record_latency=False):
+        enc_done, outs, starts = [], [], []
+        for i in range(n):
+            with torch.cuda.stream(streams[i]):
+                for ev in group_dec_done:
+                    streams[i].wait_event(ev)
+                if record_latency:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    starts.append(e0)
+                ctxs[i].generate_encode(frames, search)
+                ev = torch.cuda.Event()
+                ev.record()
+                enc_done.append(ev)
+        group_dec_done.clear()
+        for i in range(n):
+            with torch.cuda.stream(streams[i]):
+                for ev in enc_done:
+                    streams[i].wait_event(ev)
+                tokens, logprobs, info = ctxs[i].generate_decode(search, sync=False)
+                if world > 1:
+                    gather_results(tokens, logprobs)
+                ev = torch.cuda.Event(enable_timing=record_latency)
+                ev.record()
+                group_dec_done.append(ev)
+                if record_latency:
+                    lat_events.append((starts[i], ev))
+                outs.append((tokens, info))
+        return outs[-1]
+
+    def run_steps(k, record_latency=False):
+        out = None
+        if args.phased > 0:
+            done = 0
+            while done < k:
+                n = min(args.phased, k - done)
+                out = run_group(n, record_latency)
+                done += n
+        else:
+            for _ in range(k):
+                out = step(record_latency)
+        return out
+
+    # every context captures its hipGraph before anything is timed (a context's first call captures and instantiates)
+    run_steps(len(ctxs))
+    fence()
+    run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tokens, info = step(record_latency=True)
+    tokens, info = run_steps(args.steps, record_latency=True)
     fence()
     elapsed = time.perf_counter() - t0
     lat = sorted(a.elapsed_time(b) for a, b in lat_events)
@@ -286,7 +342,9 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "decode_steps_per_caption": steps_run, "seq_len_returned": info_h[0],
                        "hip_graph": not args.no_graph, "contexts_in_flight": len(ctxs),
-                       "encoder_chains": 0 if (args.free_run or len(ctxs) <= chains) else chains},
+                       "encoder_chains": 0 if (args.free_run or len(ctxs) <= chains) else chains,
+                       "schedule": "mixed" if args.phased <= 0 else f"phased: groups of {args.phased} batches, "
+                                   f"encoders first, then the decode chains side by side"},
             # a batch's own latency (submit -> ids ready) while `contexts_in_flight` batches share the GPU
             "batch_latency_ms": {"median": round(lat[len(lat) // 2], 3), "max": round(lat[-1], 3)},
         }
@@ -350,6 +408,8 @@ def main():
         result["phases_ms"]["graph_encode_prefill_ms"] = round(gprof["vit_ms"], 3)
         result["phases_ms"]["graph_decode_ms"] = round(gprof["decode_ms"], 3)
         result["parity"] = bench_parity(eng, tokens_solo, info_solo, args)
+        # the ids of the timed schedule's last batch are the ids of the solo pass (same images, same weights)
+        result["timed_ids_equal_solo"] = bool(torch.equal(tokens.cpu(), tokens_solo.cpu()))
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.max_steps, args.cpu_threads)
 

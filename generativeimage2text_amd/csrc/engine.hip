@@ -151,6 +151,7 @@ struct gitmi_engine {
     hipGraph_t graph_b = nullptr;
     hipGraphExec_t graph_exec_b = nullptr;
     bool graph_is_split = false;
+    bool half_submitted = false;        // gitmi_generate_encode submitted, its gitmi_generate_decode not yet
     hipEvent_t gev[3] = {nullptr, nullptr, nullptr};
     // serving schedule: this context's image encoder starts only after `enc_after`'s has finished (at most one encoder
     // in flight on the device; decode chains of the other contexts fill in beside it)
@@ -1182,15 +1183,23 @@ static int generate_body(gitmi_engine* e, const float* const* frames, int F, int
 }
 
 // common tail of gitmi_generate / gitmi_generate_prefixed: start_dev / plen_dev / img_of_dev are already enqueued on `s`
+// phase 0: the whole call.  phase 1 / 2: its two halves as separate submissions (gitmi_generate_encode /
+// gitmi_generate_decode) -- 1 = stage the frames, image encoder + decoder prefill; 2 = search over the text positions +
+// results -- for schedules that order the halves of several contexts themselves.
 static int generate_run(gitmi_engine* e, const float* const* frames, int F, int B, int Q, int minP, int maxP, bool ragged,
                         const gitmi_search* sp, int64_t* tokens_out, float* logprob_out, int32_t* info_out,
-                        int32_t* sent_out, hipStream_t s) {
+                        int32_t* sent_out, hipStream_t s, int phase = 0) {
     const gitmi_config& c = e->cfg;
     const bool long_budget = sp->max_steps - minP > 32;
     const bool graph = e->use_graph && !e->profiling && !long_budget;
-    if (!graph)
+    if (!graph) {
+        if (phase == 1) return generate_encode(e, frames, F, B, s);
+        if (phase == 2)
+            return generate_decode(e, Q, minP, maxP, ragged, sp, (long long*)tokens_out, logprob_out, info_out,
+                                   sent_out ? sent_out : e->out_sent, s, long_budget && !e->profiling);
         return generate_body(e, frames, F, B, Q, minP, maxP, ragged, sp, (long long*)tokens_out, logprob_out, info_out,
                              sent_out ? sent_out : e->out_sent, s, long_budget && !e->profiling);
+    }
 
     // ---- hipGraph path: the launch sequence only depends on (B,Q,F,minP,search); inputs and outputs are
     // staged through engine-owned buffers so the captured pointers stay valid across calls.
@@ -1202,14 +1211,17 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     }
     const size_t frame_bytes = (size_t)B * 3 * e->H * e->W * sizeof(float);
     const int F_eff = c.num_frames > 0 ? std::min(F, c.num_frames) : F;
-    for (int f = 0; f < F_eff; ++f)
-        HIPCK(hipMemcpyAsync(e->frame_stage[f], frames[f], frame_bytes, hipMemcpyDeviceToDevice, x));
+    if (phase != 2)
+        for (int f = 0; f < F_eff; ++f)
+            HIPCK(hipMemcpyAsync(e->frame_stage[f], frames[f], frame_bytes, hipMemcpyDeviceToDevice, x));
     gitmi_engine::GraphKey key{};
     key.B = B; key.Q = Q; key.F = F_eff; key.P = minP; key.kind = sp->kind; key.k = sp->beam_size; key.pn = sp->per_node_beam_size;
     key.T = sp->max_steps; key.H = e->H; key.W = e->W; key.lp = sp->length_penalty;
     key.ragged = ragged ? 1 : 0; key.ident = e->img_identity ? 1 : 0; key.temb = e->use_temb ? 1 : 0;
     key.smp = sp->do_sample; key.top_k = sp->top_k; key.top_p = sp->top_p; key.temp = sp->temperature; key.seed = sp->seed;
-    const bool split = e->profile_mode == 2 || e->enc_after != nullptr || e->enc_done != nullptr;
+    const bool split = e->profile_mode == 2 || e->enc_after != nullptr || e->enc_done != nullptr || phase != 0;
+    if (phase == 2 && !(e->graph_valid && key == e->graph_key && e->graph_is_split && e->half_submitted))
+        return fail("generate_decode: no matching gitmi_generate_encode was submitted on this context");
     if (!e->graph_valid || !(key == e->graph_key) || split != e->graph_is_split) {
         destroy_graph(e);
         std::vector<const float*> fp(F_eff);
@@ -1248,11 +1260,14 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     }
     if (!split) {
         HIPCK(hipGraphLaunch(e->graph_exec, x));
-    } else if (e->profile_mode != 2) {
-        if (e->enc_after && e->enc_after->enc_done) HIPCK(hipStreamWaitEvent(x, e->enc_after->enc_done, 0));
-        HIPCK(hipGraphLaunch(e->graph_exec, x));
-        if (e->enc_done) HIPCK(hipEventRecord(e->enc_done, x));
-        HIPCK(hipGraphLaunch(e->graph_exec_b, x));
+    } else if (e->profile_mode != 2 || phase != 0) {
+        if (phase != 2) {
+            if (e->enc_after && e->enc_after->enc_done) HIPCK(hipStreamWaitEvent(x, e->enc_after->enc_done, 0));
+            HIPCK(hipGraphLaunch(e->graph_exec, x));
+            if (e->enc_done) HIPCK(hipEventRecord(e->enc_done, x));
+        }
+        if (phase != 1) HIPCK(hipGraphLaunch(e->graph_exec_b, x));
+        e->half_submitted = phase == 1;
     } else {
         for (auto& ev : e->gev)
             if (!ev) HIPCK(hipEventCreate(&ev));
@@ -1267,10 +1282,12 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
         HIPCK(hipEventElapsedTime(&b, e->gev[1], e->gev[2]));
         e->split_encode_ms += a; e->split_decode_ms += b; e->split_calls += 1; e->split_steps += sp->max_steps - 1;
     }
-    HIPCK(hipMemcpyAsync(tokens_out, e->out_tokens, (size_t)Q * sp->max_steps * sizeof(long long), hipMemcpyDeviceToDevice, x));
-    HIPCK(hipMemcpyAsync(logprob_out, e->out_lp, (size_t)Q * sizeof(float), hipMemcpyDeviceToDevice, x));
-    HIPCK(hipMemcpyAsync(info_out, e->out_info, 4 * sizeof(int), hipMemcpyDeviceToDevice, x));
-    if (sent_out) HIPCK(hipMemcpyAsync(sent_out, e->out_sent, (size_t)Q * 2 * sizeof(int), hipMemcpyDeviceToDevice, x));
+    if (phase != 1) {
+        HIPCK(hipMemcpyAsync(tokens_out, e->out_tokens, (size_t)Q * sp->max_steps * sizeof(long long), hipMemcpyDeviceToDevice, x));
+        HIPCK(hipMemcpyAsync(logprob_out, e->out_lp, (size_t)Q * sizeof(float), hipMemcpyDeviceToDevice, x));
+        HIPCK(hipMemcpyAsync(info_out, e->out_info, 4 * sizeof(int), hipMemcpyDeviceToDevice, x));
+        if (sent_out) HIPCK(hipMemcpyAsync(sent_out, e->out_sent, (size_t)Q * 2 * sizeof(int), hipMemcpyDeviceToDevice, x));
+    }
     if (x != s) {
         HIPCK(hipEventRecord(e->fence_out, x));
         HIPCK(hipStreamWaitEvent(s, e->fence_out, 0));
@@ -1293,6 +1310,39 @@ extern "C" int gitmi_generate(gitmi_engine* e, const float* const* frames, int F
     // start tokens [B, P] on device (shared prefix, or [CLS]) -- filled by a kernel, no host copy
     RCK(fill_uniform_sentences(e, B, (const long long*)prefix, P, s));
     return generate_run(e, frames, F, B, B, P, P, false, sp, tokens_out, logprob_out, info_out, nullptr, s);
+}
+
+// gitmi_generate as two submissions (same arguments; the decode half must follow the encode half of the same call on
+// the same context).  Lets a server order the halves of several contexts itself, e.g. run the MFMA-bound encoders of a
+// group of batches first and their latency-bound decode chains side by side afterwards (bench.py --phased).
+static int check_generate_args(gitmi_engine* e, int F, int B, const int64_t* prefix, int* P, const gitmi_search* sp) {
+    const gitmi_config& c = e->cfg;
+    if (!sp) return fail("generate: null argument");
+    if (F < 1 || F > c.max_frames) return fail("generate: F=%d outside [1,%d]", F, c.max_frames);
+    if (B < 1 || B > c.max_batch) return fail("generate: B=%d outside [1,%d]", B, c.max_batch);
+    if (!prefix) *P = 1;
+    if (*P < 1 || *P > c.max_text_len) return fail("generate: prefix length %d outside [1,%d]", *P, c.max_text_len);
+    if (sp->max_steps < *P || sp->max_steps > c.max_text_len) return fail("generate: max_steps %d outside [P,%d]", sp->max_steps, c.max_text_len);
+    return 0;
+}
+
+extern "C" int gitmi_generate_encode(gitmi_engine* e, const float* const* frames, int F, int B, const int64_t* prefix, int P,
+                                     const gitmi_search* sp, void* stream) {
+    RCK(check_ready(e));
+    if (!frames) return fail("generate_encode: null argument");
+    RCK(check_generate_args(e, F, B, prefix, &P, sp));
+    e->img_identity = true;
+    return generate_run(e, frames, F, B, B, P, P, false, sp, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream, 1);
+}
+
+extern "C" int gitmi_generate_decode(gitmi_engine* e, int F, int B, const int64_t* prefix, int P, const gitmi_search* sp,
+                                     int64_t* tokens_out, float* logprob_out, int32_t* info_out, void* stream) {
+    RCK(check_ready(e));
+    if (!tokens_out || !logprob_out || !info_out) return fail("generate_decode: null argument");
+    RCK(check_generate_args(e, F, B, prefix, &P, sp));
+    hipStream_t s = (hipStream_t)stream;
+    RCK(fill_uniform_sentences(e, B, (const long long*)prefix, P, s));
+    return generate_run(e, nullptr, F, B, B, P, P, false, sp, tokens_out, logprob_out, info_out, nullptr, s, 2);
 }
 
 // Q sentences with their own prefixes over B encoded images (batched VQA: the questions of one image share its K/V).

@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_dgemm", "gitmi_op_dgemm_res",
     "gitmi_op_vocab_topm", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
     "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after", "gitmi_op_sample_rows",
+    "gitmi_generate_encode", "gitmi_generate_decode",
 ]
 
 
@@ -85,6 +86,8 @@ def load_library() -> C.CDLL:
     lib.gitmi_prefill.argtypes = [vp, vp]
     lib.gitmi_step_logits.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.gitmi_generate.argtypes = [vp, C.POINTER(vp), i32, i32, vp, i32, C.POINTER(GitmiSearch), vp, vp, vp, vp]
+    lib.gitmi_generate_encode.argtypes = [vp, C.POINTER(vp), i32, i32, vp, i32, C.POINTER(GitmiSearch), vp]
+    lib.gitmi_generate_decode.argtypes = [vp, i32, i32, vp, i32, C.POINTER(GitmiSearch), vp, vp, vp, vp]
     lib.gitmi_search_begin.argtypes = [vp, C.POINTER(GitmiSearch), i32, vp, i32, i32, vp]
     lib.gitmi_search_rows.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
     lib.gitmi_search_advance.argtypes = [vp, vp, vp]
@@ -277,6 +280,31 @@ class Engine:
         _ck(self.lib.gitmi_generate(self._h, arr, len(keep), B, _ptr(pfx), P, C.byref(search), tokens.data_ptr(),
                                     logprobs.data_ptr(), info.data_ptr(), _stream()))
         self._cur_B = B
+        if sync:
+            torch.cuda.current_stream().synchronize()
+        return tokens, logprobs, info
+
+    def generate_encode(self, frames: Sequence[torch.Tensor], search: GitmiSearch,
+                        prefix: Optional[torch.Tensor] = None) -> None:
+        """First half of generate() as its own submission (image encoder + decoder prefill) on the current stream;
+        generate_decode() with the same search / prefix must follow on this context."""
+        arr, keep, B = self._frames_arg(frames)
+        P, pfx = 1, None
+        if prefix is not None:
+            pfx = prefix.to(device=keep[0].device, dtype=torch.int64).reshape(-1).contiguous()
+            P = int(pfx.numel())
+        _ck(self.lib.gitmi_generate_encode(self._h, arr, len(keep), B, _ptr(pfx), P, C.byref(search), _stream()))
+        self._cur_B, self._half = B, (len(keep), B, pfx, P)
+
+    def generate_decode(self, search: GitmiSearch, sync: bool = True):
+        """Second half: the search over the text positions.  -> (tokens, logprobs, info) exactly as generate()."""
+        F, B, pfx, P = self._half
+        dev = f"cuda:{self.device}"
+        tokens = torch.empty(B, search.max_steps, device=dev, dtype=torch.int64)
+        logprobs = torch.empty(B, device=dev, dtype=torch.float32)
+        info = torch.empty(4, device=dev, dtype=torch.int32)
+        _ck(self.lib.gitmi_generate_decode(self._h, F, B, _ptr(pfx), P, C.byref(search), tokens.data_ptr(),
+                                           logprobs.data_ptr(), info.data_ptr(), _stream()))
         if sync:
             torch.cuda.current_stream().synchronize()
         return tokens, logprobs, info

@@ -185,6 +185,17 @@ int  gitmi_generate(gitmi_engine* e, const float* const* frames, int F, int B,
                     const int64_t* prefix, int P, const gitmi_search* search,
                     int64_t* tokens_out, float* logprob_out, int32_t* info_out, void* stream);
 
+/* gitmi_generate as TWO submissions with the same arguments: the image encoder + decoder prefill of the call, then its
+ * search over the text positions + results.  The reference has no such seam (one model(batch) call does both,
+ * decoder.py:838-877, 977-1011); it exists for servers that order the halves of several contexts themselves -- e.g. the
+ * MFMA-bound encoders of a group of batches first, their latency-bound decode chains side by side afterwards
+ * (bench.py --phased).  gitmi_generate_decode must follow the gitmi_generate_encode of the same call on the same context;
+ * results are identical to one gitmi_generate call. */
+int  gitmi_generate_encode(gitmi_engine* e, const float* const* frames, int F, int B,
+                           const int64_t* prefix, int P, const gitmi_search* search, void* stream);
+int  gitmi_generate_decode(gitmi_engine* e, int F, int B, const int64_t* prefix, int P, const gitmi_search* search,
+                           int64_t* tokens_out, float* logprob_out, int32_t* info_out, void* stream);
+
 /* ---- batched VQA: Q sentences with their OWN prefixes over B images.  The reference answers one question per
  * model call (decoder.py:984-989 asserts a single prefix; inference.py:172-199 loops); here the questions of one
  * image share its encoded K/V and questions of different lengths share every decode step (all sentences sit at the
