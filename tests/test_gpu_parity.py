@@ -625,3 +625,37 @@ def test_generate_with_sampling_search():
         assert not torch.equal(a["predictions"], c["predictions"])
         assert a["predictions"].shape == g["predictions"].shape == (3, 14)
         assert (a["predictions"][:, 0] == cfg.sos).all() and torch.isfinite(a["logprobs"]).all()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_generate_as_two_submissions_equals_one_call(precision):
+    """gitmi_generate_encode + gitmi_generate_decode (a call split into image encoder + prefill and search + results, for
+    schedules that order the halves of several contexts) return bit for bit what the single gitmi_generate call returns:
+    greedy, beam 4 with a shared prefix, eager launches as well as hipGraph replays; a decode half without its encode
+    half is refused."""
+    from oracle import git_oracle as O
+    from generativeimage2text_amd.engine import Engine, GitmiError
+    cfg = O.CONFIGS["TINY"]
+    w = O.make_weights(cfg, seed=81, tie_output=False, successor=2.0, eos_bias=1.0)
+    frames = [f.cuda() for f in O.make_images(cfg, 3, 1, seed=4)]
+    eng = Engine(cfg, precision=precision, max_batch=3, max_beams=4, max_frames=1, max_text_len=16)
+    eng.load_state_dict(w)
+    prefix = torch.tensor([cfg.sos, 7, 9])
+    for graph in (True, False):
+        eng.set_graph(graph)
+        for search, pfx in ((Engine.make_search("greedy", 16, 1, 1), None),
+                            (Engine.make_search("beam", 16, 4, 2, 0.6), prefix)):
+            t1, l1, i1 = eng.generate(frames, search, prefix=pfx)
+            for _ in range(2):                              # second round: replay of the split graphs
+                eng.generate_encode(frames, search, prefix=pfx)
+                t2, l2, i2 = eng.generate_decode(search)
+                assert torch.equal(t1, t2) and torch.equal(l1, l2) and torch.equal(i1, i2)
+            t3, l3, _ = eng.generate(frames, search, prefix=pfx)      # and back to the single call
+            assert torch.equal(t1, t3) and torch.equal(l1, l3)
+    eng.set_graph(True)
+    search = Engine.make_search("greedy", 16, 1, 1)
+    eng.generate(frames, search)
+    eng._half = (1, 3, None, 1)
+    with pytest.raises(GitmiError):
+        eng.generate_decode(search)
+    eng.close()
