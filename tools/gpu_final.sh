@@ -14,11 +14,15 @@ prof() {  # name, bench args...
   local name=$1; shift
   timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$name -o bench -- python $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_${name}_bench.json 2> $R/gpurun_out/${TAG}_${name}.err; echo "rocprof $name rc=$?"
   python $R/tools/rocprof_summary.py $R/gpurun_out/prof_$name/bench_results.db $R/gpurun_out/${TAG}_${name}_kernel_stats.txt > /dev/null
+  if [ "$name" = solo_graph ]; then cp $R/gpurun_out/prof_$name/bench_results.db /tmp/solo_results.db; fi
+  if [ "$name" = default ]; then   # where the wall time of the mixed schedule goes (concurrency, start delays, GEMM inflation vs solo)
+    python $R/tools/mix_timeline.py $R/gpurun_out/prof_$name/bench_results.db --solo /tmp/solo_results.db --out $R/gpurun_out/${TAG}_mix_timeline.txt > /dev/null
+  fi
   rm -rf $R/gpurun_out/prof_$name
   tail -n 1 $R/gpurun_out/${TAG}_${name}_bench.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['unit'], d['ms_per_step'], 'ms/step', d['config']['workload'], d['roofline']['achieved'], 'TF', d.get('roofline_decode',{}).get('avg_step_ms'))"
 }
-prof default
 prof solo_graph --contexts 1 --steps 8 --warmup 2
+prof default --steps 40 --warmup 8
 prof beam4 --search beam --steps 12 --warmup 3
 prof large_b32 --model GIT_LARGE_COCO --batch 32 --steps 12 --warmup 3
 prof vatex_b16 --model GIT_BASE_VATEX --frames 6 --batch 16 --steps 12 --warmup 3
