@@ -6,7 +6,8 @@ Differences forced by the environment, not by design:
     Resize/CenterCrop on PIL images call PIL themselves), checkpoints are read with torch.load.
   * the WordPiece vocabulary is looked up offline ($GIT_VOCAB or aux_data/vocab.txt, then the HF cache);
     without one the tasks fail loudly unless GIT_VOCAB=ids asks for raw token ids.
-  * images are batched (the reference runs batch 1, one host sync per image; models with test_respect_ratio_max
+  * images are decoded on a few host threads ahead of the GPU (order kept; GIT_DECODE_THREADS=0 restores the serial loop)
+    and batched (the reference runs batch 1, one host sync per image; models with test_respect_ratio_max
     keep batch 1 because every image has its own resolution) and ranks return
     their results through one RCCL gather (the task forms the process group itself from the launcher's
     RANK/WORLD_SIZE/MASTER_* variables) and fall back to the shared-filesystem poll + concat of
@@ -308,9 +309,30 @@ def _wait_and_concat_shards(out_tsv: str, world: int, poll_s: float = 0.2, timeo
     concat_tsv_files(shards, out_tsv)
 
 
+def prefetch_ordered(n: int, load, threads: int, window: int):
+    """load(i) for i in range(n), computed by `threads` host threads up to `window` items ahead of the consumer and
+    yielded IN ORDER.  threads <= 0: plain serial calls.  Used to keep JPEG decoding (PIL releases the GIL while it
+    decodes) off the critical path of the GPU: the reference decodes, transforms and runs the model strictly one image
+    after the other (inference.py:171-212)."""
+    if threads <= 0 or n <= 1:
+        for i in range(n):
+            yield load(i)
+        return
+    import collections
+    from concurrent.futures import ThreadPoolExecutor
+    pending = collections.deque()
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        nxt = 0
+        while nxt < n or pending:
+            while nxt < n and len(pending) < max(1, window):
+                pending.append(pool.submit(load, nxt))
+                nxt += 1
+            yield pending.popleft().result()
+
+
 def run_tsv_inference(image_tsv: str, question_tsv: Optional[str], out_tsv: str, *, transform, caption_batch,
                       answer_questions, batch_size: int, rank: Optional[int] = None, world: Optional[int] = None,
-                      poll_s: float = 0.2) -> None:
+                      poll_s: float = 0.2, decode=None, decode_threads: int = 0) -> None:
     """Everything of test_git_inference_single_tsv (inference.py:134-225) except the model: shard the rows by
     rank (:165-169), write this rank's rows, and deliver the complete, ordered `out_tsv` on rank 0 --
     through ONE RCCL gather when a process group exists or can be formed, else through the reference's
@@ -318,6 +340,9 @@ def run_tsv_inference(image_tsv: str, question_tsv: Optional[str], out_tsv: str,
 
       transform(bytes) -> image tensor;  caption_batch(list of images) -> list of caption strings;
       answer_questions(image, list of question strings) -> list of answer strings.
+      decode (optional): bytes -> decoded image, run on `decode_threads` host threads ahead of the loop (order kept);
+      `transform` then receives the decoded image instead of the bytes and stays on the calling thread (it may launch
+      GPU work on the caller's device and stream).
     Row formats are the reference's: `key \t json_dump([{"caption": ...}])` (:212) and the ONE-column
     `json_dump({"answer": ..., "question_id": ...})` (:199) that convert_tsv_to_vqa_json (:227-229) reads."""
     rank = get_mpi_rank() if rank is None else rank
@@ -332,10 +357,20 @@ def run_tsv_inference(image_tsv: str, question_tsv: Optional[str], out_tsv: str,
         for key, cap in zip(keys, caption_batch(imgs)):
             rows.append([key, json_dump([{"caption": cap}])])
 
+    import threading
+    lock = threading.Lock()
+
+    def load(j):
+        with lock:                      # TSVFile keeps ONE file handle: row reads are serialised, the decoding is not
+            row = tsv[start + j]
+        raw = base64.b64decode(row[1])
+        return row[0], (decode(raw) if decode is not None else raw)
+
     keys, imgs = [], []
-    for i in range(start, end):
-        key, b64 = tsv[i][0], tsv[i][1]
-        img = transform(base64.b64decode(b64))
+    for j, (key, item) in enumerate(prefetch_ordered(end - start, load, decode_threads if decode is not None else 0,
+                                                     window=max(2 * batch_size, 8))):
+        i = start + j
+        img = transform(item)
         if questions is None:
             keys.append(key)
             imgs.append(img)
@@ -394,5 +429,9 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
             out += [tokenizer.decode(p, skip_special_tokens=True) for p in preds]
         return out
 
-    run_tsv_inference(image_tsv, question_tsv, out_tsv, transform=lambda b: transforms(load_image_by_pil(b)),
-                      caption_batch=caption_batch, answer_questions=answer_questions, batch_size=batch_size)
+    # JPEG decoding on a few host threads ahead of the GPU (GIT_DECODE_THREADS, default min(8, cores); 0 = serial as in
+    # the reference); the transform itself (upload + resize kernels) stays on this thread and this device
+    threads = int(os.environ.get("GIT_DECODE_THREADS", str(min(8, os.cpu_count() or 1))))
+    run_tsv_inference(image_tsv, question_tsv, out_tsv, decode=load_image_by_pil, decode_threads=threads,
+                      transform=transforms, caption_batch=caption_batch, answer_questions=answer_questions,
+                      batch_size=batch_size)

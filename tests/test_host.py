@@ -338,3 +338,107 @@ def test_config_struct_fields_agree_across_header_binding_and_integration_doc():
     stub = doc[doc.index("class Cfg(C.Structure):"):doc.index("class Search(C.Structure):")]
     doc_fields = " ".join(re.findall(r'"([^"]+)"', stub)).split()
     assert doc_fields == header_fields
+
+
+def test_prefetch_ordered_keeps_order_and_bounds_the_window():
+    import threading, time
+    started, lock = [], threading.Lock()
+
+    def load(i):
+        with lock:
+            started.append(i)
+        time.sleep(0.002 * ((7 * i) % 5))            # uneven durations: completion order != submission order
+        return i * i
+
+    got = []
+    for v in inference.prefetch_ordered(40, load, threads=4, window=6):
+        with lock:
+            ahead = len(started) - len(got)
+        assert ahead <= 6 + 1                       # never more than the window (+ the one being consumed) in flight
+        got.append(v)
+    assert got == [i * i for i in range(40)]
+    assert list(inference.prefetch_ordered(5, lambda i: -i, threads=0, window=3)) == [0, -1, -2, -3, -4]
+    assert list(inference.prefetch_ordered(0, load, threads=4, window=3)) == []
+
+    def boom(i):
+        if i == 3:
+            raise ValueError("bad row 3")
+        return i
+    with pytest.raises(ValueError):
+        list(inference.prefetch_ordered(8, boom, threads=3, window=4))
+
+
+def test_run_tsv_inference_with_decode_threads_matches_serial(tmp_path):
+    """The TSV task's loop with the decode stage on host threads: same rows, same order as the serial loop, captions and VQA."""
+    rows = [["key%d" % i, base64.b64encode(b"image-bytes-%03d" % i).decode()] for i in range(23)]
+    tsv_io.tsv_writer(rows, str(tmp_path / "img.tsv"))
+    q = [["key%d" % i, json.dumps([{"question": "q%d-%d" % (i, j), "question_id": 100 * i + j} for j in range(1 + i % 3)])]
+         for i in range(23)]
+    tsv_io.tsv_writer(q, str(tmp_path / "q.tsv"))
+    outs = {}
+    for threads in (0, 5):
+        for with_q in (False, True):
+            out = str(tmp_path / ("out_%d_%d.tsv" % (threads, with_q)))
+            seen = []
+            inference.run_tsv_inference(
+                str(tmp_path / "img.tsv"), str(tmp_path / "q.tsv") if with_q else None, out,
+                decode=lambda b: ("decoded", b.decode()), decode_threads=threads,
+                transform=lambda d: (seen.append(d[1]), d[1])[1],
+                caption_batch=lambda imgs: ["cap<%s>" % im for im in imgs],
+                answer_questions=lambda img, qs: ["ans<%s|%s>" % (img, qq) for qq in qs],
+                batch_size=4, rank=0, world=1)
+            assert seen == ["image-bytes-%03d" % i for i in range(23)]          # transform runs in row order, on this thread
+            outs[(threads, with_q)] = open(out, "rb").read()
+    assert outs[(0, False)] == outs[(5, False)] and outs[(0, True)] == outs[(5, True)]
+    assert outs[(0, False)].count(b"\n") == 23 and outs[(0, True)].count(b"\n") == sum(1 + i % 3 for i in range(23))
+
+
+def test_tsv_task_function_plumbing_without_a_gpu(tmp_path, monkeypatch):
+    """test_git_inference_single_tsv end to end on the CPU with the engine replaced by a stand-in model: real PNG rows,
+    base64, PIL decoding on the host thread pool, the (CPU) image transform, batching, caption / VQA row formats, the
+    parameter lookup.  The stand-in "captions" an image by the rounded mean of its pixels, which also checks that every
+    key is paired with its own image."""
+    from PIL import Image
+    rng = np.random.RandomState(11)
+    img_rows, q_rows, means = [], [], []
+    for i in range(9):
+        arr = rng.randint(0, 255, (60 + 5 * i, 80, 3), dtype=np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(arr).save(buf, format="PNG")
+        img_rows.append(["img%d" % i, base64.b64encode(buf.getvalue()).decode()])
+        q_rows.append(["img%d" % i, json.dumps([{"question": "%d %d" % (2000 + i, 3000 + j), "question_id": 10 * i + j}
+                                                for j in range(1 + i % 2)])])
+        means.append(int(round(float(inference.image_transform(Image.fromarray(arr), 224).mean()) * 1000)))
+    tsv_io.tsv_writer(img_rows, str(tmp_path / "img.tsv"))
+    tsv_io.tsv_writer(q_rows, str(tmp_path / "q.tsv"))
+
+    class FakeModel:
+        def __call__(self, batch):
+            x = batch["image"]
+            return {"predictions": torch.tensor([[101, int(round(float(im.mean()) * 1000)) % 30000 + 1000, 102] for im in x])}
+
+        def answer(self, image, prefixes):
+            m = int(round(float(image.mean()) * 1000)) % 30000 + 1000
+            return [[m] + list(p[1:]) for p in prefixes]
+
+    monkeypatch.setattr(inference, "get_tokenizer", lambda: inference.IdTokenizer())
+    monkeypatch.setattr(inference, "build_model", lambda *a, **k: FakeModel())
+    monkeypatch.setattr(inference, "get_image_transform", lambda param, gpu=False: (lambda im: inference.image_transform(im, 224)))
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    for k in ("RANK", "WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    want = [m % 30000 + 1000 for m in means]
+    for threads in ("0", "4"):
+        monkeypatch.setenv("GIT_DECODE_THREADS", threads)
+        out = str(tmp_path / ("cap%s.tsv" % threads))
+        inference.test_git_inference_single_tsv(str(tmp_path / "img.tsv"), "GIT_BASE", None, out, batch_size=4)
+        rows = list(tsv_io.tsv_reader(out))
+        assert [r[0] for r in rows] == ["img%d" % i for i in range(9)]
+        assert [json.loads(r[1])[0]["caption"] for r in rows] == [str(w) for w in want]
+        out = str(tmp_path / ("vqa%s.tsv" % threads))
+        inference.test_git_inference_single_tsv(str(tmp_path / "img.tsv"), "GIT_BASE", str(tmp_path / "q.tsv"), out)
+        got = [json.loads(s) for s, in tsv_io.tsv_reader(out)]
+        exp = [{"answer": "%d %d %d" % (want[i], 2000 + i, 3000 + j), "question_id": 10 * i + j}
+               for i in range(9) for j in range(1 + i % 2)]
+        assert got == exp
