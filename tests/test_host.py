@@ -442,3 +442,54 @@ def test_tsv_task_function_plumbing_without_a_gpu(tmp_path, monkeypatch):
         exp = [{"answer": "%d %d %d" % (want[i], 2000 + i, 3000 + j), "question_id": 10 * i + j}
                for i in range(9) for j in range(1 + i % 2)]
         assert got == exp
+
+
+def test_single_image_task_plumbing_without_a_gpu(tmp_path, monkeypatch, caplog):
+    """test_git_inference_single_image on the CPU with a stand-in model: image file(s) -> transform -> the batch the model
+    sees (list of [1,3,H,W] frames, prefix [1,P] starting with [CLS], the keep-the-last-38 rule), the parameter.yaml found
+    where the reference looks for it, 'output: ...' logged."""
+    import logging
+    from PIL import Image
+    rng = np.random.RandomState(12)
+    paths = []
+    for i in range(2):
+        p = tmp_path / ("f%d.png" % i)
+        Image.fromarray(rng.randint(0, 255, (50, 70, 3), dtype=np.uint8)).save(str(p))
+        paths.append(str(p))
+    seen = {}
+
+    class FakeModel:
+        def cuda(self): return self
+        def eval(self): return self
+
+        def __call__(self, batch):
+            seen["image"], seen["prefix"] = batch["image"], batch["prefix"]
+            return {"predictions": torch.tensor([[2001, 2002, 102]])}
+
+    def fake_build(name, tok, ckpt, **kw):
+        seen["build"] = (name, kw)
+        return FakeModel()
+
+    monkeypatch.setattr(inference, "get_tokenizer", lambda: inference.IdTokenizer())
+    monkeypatch.setattr(inference, "build_model", fake_build)
+    monkeypatch.setattr(inference, "get_image_transform",
+                        lambda param, gpu=False: (lambda im: inference.image_transform(im, param.get("test_crop_size", 224))))
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    monkeypatch.chdir(tmp_path)
+    with caplog.at_level(logging.INFO):
+        inference.test_git_inference_single_image(paths, "GIT_BASE_VATEX", " ".join(str(3000 + i) for i in range(50)))
+    assert inference.test_git_inference_single_image.last_output == "2001 2002"
+    assert any(r.message == "output: 2001 2002" for r in caplog.records)
+    assert isinstance(seen["image"], list) and [tuple(t.shape) for t in seen["image"]] == [(1, 3, 224, 224)] * 2
+    assert seen["prefix"].shape == (1, 39) and seen["prefix"][0, 0].item() == 101
+    assert seen["prefix"][0, 1:].tolist() == [3000 + i for i in range(12, 50)]          # the LAST 38 tokens are kept
+    assert seen["build"][0] == "GIT_BASE_VATEX" and "param" not in seen["build"][1]       # table entry, no yaml on disk
+    # a parameter.yaml where the reference reads it (aux_data/models/<name>/) takes over
+    d = tmp_path / "aux_data" / "models" / "MY_FINETUNE"
+    d.mkdir(parents=True)
+    (d / "parameter.yaml").write_text("test_crop_size: 160\nnum_image_with_embedding: 6\n")
+    inference.test_git_inference_single_image(paths[0], "MY_FINETUNE", "")
+    assert seen["build"][1]["param"] == {"test_crop_size": 160, "num_image_with_embedding": 6}
+    assert [tuple(t.shape) for t in seen["image"]] == [(1, 3, 160, 160)] and seen["prefix"].tolist() == [[101]]
+    with pytest.raises(KeyError):
+        inference.test_git_inference_single_image(paths[0], "NO_SUCH_MODEL", "")
