@@ -69,3 +69,121 @@ def test_rocprof_summary_on_synthetic_db(tmp_path):
     txt = open(out).read()
     assert "total GPU kernel time 0.004 ms over 3 dispatches" in txt.replace("0.0045", "0.004") or "3 dispatches" in txt
     assert "k_a" in txt and "k_b" in txt
+
+
+def _run_bench_with_fakes(monkeypatch, capsys, argv):
+    """bench.main() with torch.cuda and the engine replaced by stand-ins: checks the script's control flow (every
+    schedule flag) and the shape of its JSON line without a GPU.  Nothing here measures anything."""
+    import contextlib, json, time, types
+    import torch
+    import bench
+    from generativeimage2text_amd import engine as E, synthetic
+
+    class FakeEvent:
+        def __init__(self, enable_timing=False):
+            self.t = None
+
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    class FakeStream:
+        def wait_event(self, ev):
+            assert ev.t is not None, "waiting on an event that was never recorded"
+
+        def synchronize(self):
+            pass
+
+    log = []
+
+    class FakeEngine:
+        make_search = staticmethod(E.Engine.make_search)
+        generate_coalesced = E.Engine.generate_coalesced
+
+        def __init__(self, cfg, precision="bf16", max_batch=64, max_beams=1, max_frames=1, max_text_len=20, **kw):
+            self.c = types.SimpleNamespace(max_batch=max_batch, vocab=cfg.vocab)
+            self.half = None
+
+        def clone(self):
+            other = FakeEngine.__new__(FakeEngine)
+            other.c, other.half = self.c, None
+            return other
+
+        def load_state_dict(self, sd): pass
+        def set_graph(self, on): pass
+        def set_encode_after(self, other): pass
+        def profile_enable(self, on): pass
+
+        def profile_read(self):
+            return dict(vit_ms=4.0, prefill_ms=1.0, decode_ms=5.0, total_ms=10.0, gemm_ms=4.0, gemm_launches=66, gemm_flops=3e12,
+                        vit_gemm_ms=3.0, vit_gemm_launches=49, vit_gemm_flops=2.2e12, decode_step_ms=0.25, decode_steps=19,
+                        decode_step_bytes=3.77e8)
+
+        def _out(self, B, search):
+            toks = torch.full((B, search.max_steps), 7, dtype=torch.int64)
+            return toks, torch.zeros(B), torch.tensor([search.max_steps, 0, search.max_steps - 1, 0], dtype=torch.int32)
+
+        def generate(self, frames, search, prefix=None, sync=True):
+            log.append(("generate", int(frames[0].shape[0])))
+            return self._out(int(frames[0].shape[0]), search)
+
+        def generate_encode(self, frames, search, prefix=None):
+            assert self.half is None
+            self.half = int(frames[0].shape[0])
+            log.append(("encode", self.half))
+
+        def generate_decode(self, search, sync=True):
+            B, self.half = self.half, None
+            assert B is not None, "decode half without its encode half"
+            log.append(("decode", B))
+            return self._out(B, search)
+
+        def step_logits(self, tokens):
+            return torch.zeros(tokens.shape[0], self.c.vocab)
+
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda: None)
+    monkeypatch.setattr(E, "Engine", FakeEngine)
+    monkeypatch.setattr(synthetic, "random_state_dict", lambda cfg, seed=0: {})
+    monkeypatch.setattr(synthetic, "random_frames", lambda cfg, B, F, seed=0: [torch.zeros(B, 3, 8, 8) for _ in range(F)])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BENCH_GEMM_IMPL"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline"] + argv)
+    bench.main()
+    line = capsys.readouterr().out.strip().splitlines()[-1]
+    return json.loads(line), log
+
+
+def test_bench_control_flow_all_schedules(monkeypatch, capsys):
+    # the contract's fields, default (mixed) schedule
+    d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--warmup", "3"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_decode", "parity"):
+        assert k in d, k
+    assert d["steps"] == 8 and d["warmup"] == 3 and d["n_gpus"] == 1 and d["unit"] == "captions/s" and d["vs_baseline"] is None
+    assert d["config"]["schedule"] == "mixed" and d["config"]["contexts_in_flight"] == 4 and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"] and k in d["roofline_decode"], k
+    timed = [e for e in log if e[0] == "generate"]
+    assert len(timed) >= 4 + 3 + 8                      # priming pass over the contexts + warm-up + timed steps (+ roofline passes)
+    # phased: every decode half follows its own encode half, groups of G
+    d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "10", "--warmup", "4", "--phased", "4"])
+    assert d["config"]["schedule"].startswith("phased: groups of 4") and d["config"]["contexts_in_flight"] == 4
+    halves = [e[0] for e in log if e[0] in ("encode", "decode")]
+    assert halves.count("encode") == halves.count("decode") == 4 + 4 + 10
+    assert halves[:8] == ["encode"] * 4 + ["decode"] * 4
+    assert halves[-2:] == ["decode", "decode"] and halves[-4:-2] == ["encode", "encode"]      # the last, partial group of 2
+    # coalesced: two requests per engine pass
+    d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--warmup", "3", "--coalesce", "2"])
+    assert "2 requests of 64 images coalesced" in d["config"]["schedule"] and d["warmup"] == 4
+    passes = [e for e in log if e == ("generate", 128)]
+    assert len(passes) == 4 + 2 + 4                     # priming (one pass per context), warm-up 4 steps, 8 timed steps
+    import pytest
+    with pytest.raises(SystemExit):
+        _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "7", "--coalesce", "2"])
