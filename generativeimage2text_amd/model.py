@@ -5,8 +5,9 @@ Same names, argument meaning and return conventions as
   generativeimage2text/layers/decoder.py:774-1054 CaptioningModel (forward / infer)
   generativeimage2text/layers/decoder.py:208-222  AutoRegressiveBeamSearch  (constructor arguments)
   generativeimage2text/layers/decoder.py:1056-1081 GeneratorWithBeamSearch (constructor arguments)
-but all arithmetic happens in libgitmi.so (HIP, gfx950).  The two search classes are plain
-configuration holders here: the search itself runs on the device (csrc/kernels_search.hip).
+but all arithmetic happens in libgitmi.so (HIP, gfx950).  The two search classes hold the reference's constructor
+arguments; the search itself runs on the device (csrc/kernels_search.hip), inside gitmi_generate for model(batch) and
+behind `decoder.search(start_predictions, step)` for callers that bring their own `step` (decoder.py:224-231, 1083-1092).
 """
 from __future__ import annotations
 
@@ -17,6 +18,74 @@ import torch
 
 from .configs import GitModelConfig, config_from_param
 from .engine import Engine
+
+
+# ---- decoder.search(start_predictions, step): the reference's search seam as a method ----------------------------
+# The search itself runs on the device (csrc/kernels_search.hip) behind gitmi_search_begin / rows / advance / finish.
+# Those entry points live on an engine context, so a search with a caller-supplied `step` gets a SMALL context of its own
+# (a minimal model geometry with placeholder weights that are never used: only the search state and kernels are).
+_SEARCH_ENGINES: Dict[tuple, Engine] = {}
+
+
+def _search_engine(eos: int, sos: int, B: int, beams: int, T: int, factory=None) -> Engine:
+    """A context that only hosts searches: capacity (B sentences, `beams` beams, T positions).  `factory` (tests) builds
+    the context instead of Engine."""
+    key = (int(eos), int(B), int(beams), int(T))
+    eng = _SEARCH_ENGINES.get(key)
+    if eng is None:
+        if factory is not None:
+            eng = factory(eos, B, beams, T)
+        else:
+            from .synthetic import random_state_dict
+            cfg = GitModelConfig(name="search-only", image_size=64, patch=16, vit_width=128, vit_layers=2, vit_heads=2,
+                                 dec_hidden=128, dec_layers=2, dec_heads=2, dec_ffn=512, vocab=1000, max_pos=max(64, int(T)),
+                                 sos=int(sos), eos=int(eos))
+            eng = Engine(cfg, precision="f32", max_batch=int(B), max_beams=int(beams), max_frames=1, max_text_len=int(T))
+            eng.load_state_dict(random_state_dict(cfg, seed=0))
+        if len(_SEARCH_ENGINES) >= 4:                        # a few capacities at most stay alive
+            _SEARCH_ENGINES.pop(next(iter(_SEARCH_ENGINES))).close()
+        _SEARCH_ENGINES[key] = eng
+    return eng
+
+
+def _begin_and_run(decoder, start_predictions, step, search_struct, first_step_rows_per_sentence, stop_when_all_eos, fmt,
+                   engine_factory=None):
+    start = start_predictions.detach().to("cpu", torch.int64)
+    assert start.dim() == 2, "start_predictions is [batch, prefix_length]"
+    B, P = start.shape
+    T, k = int(decoder.max_steps), int(decoder.beam_size)
+    if P > T:
+        raise ValueError(f"prefix of {P} tokens exceeds max_steps={T}")
+    dev = start_predictions.device
+    eng = _search_engine(decoder._eos_index, int(start[0, 0]), B, k, T, engine_factory)
+    # the vocabulary size is only known from the first logits: the first `step` call is made on the start rows as the
+    # reference makes it (one row per sentence for AutoRegressiveBeamSearch, decoder.py:259; B*k rows for the generator,
+    # decoder.py:1101-1102), then the device search begins and receives those logits as its first advance
+    if P < T:
+        first_rows = start if (first_step_rows_per_sentence or k == 1) else start.repeat_interleave(k, dim=0)
+        logits = step(first_rows.to(dev))
+        if logits.shape[0] != B * k:
+            logits = logits.repeat_interleave(k, dim=0)
+        eng.search_begin(search_struct, start, int(logits.shape[-1]))
+        eng.search_advance(logits)
+    else:
+        eng.search_begin(search_struct, start, 2)
+    while True:
+        rows = eng.search_rows()                                        # int64 [B*k, t], rows of a sentence contiguous
+        t = int(rows.shape[1])
+        if t >= T:
+            break
+        if stop_when_all_eos and bool((rows[:, -1] == decoder._eos_index).all()):
+            break                                                       # decoder.py:319-320
+        eng.search_advance(step(rows.to(dev)))
+    tokens, logprobs, info = eng.search_finish()
+    seq_len, early = int(info[0]), int(info[1])
+    tokens, logprobs = tokens.to(dev), logprobs.to(dev)
+    if fmt == "autoregressive":
+        if early:                                                       # decoder.py:279-291
+            return tokens[:, P:P + 1], logprobs[:, None]
+        return tokens[:, :seq_len], logprobs
+    return tokens, logprobs[:, None]
 
 
 class AutoRegressiveBeamSearch:
@@ -31,6 +100,19 @@ class AutoRegressiveBeamSearch:
         self.per_node_beam_size = per_node_beam_size or beam_size
         self.kind = "autoregressive"
         self.length_penalty = 1.0
+
+    def search(self, start_predictions: torch.Tensor, step, only_return_best: bool = True, do_sample: bool = False,
+               top_k: int = 0, top_p=None, num_return_sequences: int = 1, temperature: float = 1, _engine_factory=None):
+        """decoder.py:224-440 with a caller-supplied `step(rows int64 [R, t]) -> logits fp32 [R, V]`:
+        -> (predictions int64 [B, length <= max_steps] incl. the start tokens, logprobs fp32 [B]); when every sentence
+        ends at its first step with beam_size == 1: ([B, 1], [B, 1]) (decoder.py:279-291).  The sampling branch and
+        only_return_best=False are used by SCST training only and are not implemented."""
+        if do_sample or not only_return_best or num_return_sequences != 1 or temperature != 1:
+            raise NotImplementedError("AutoRegressiveBeamSearch.search: only the inference form "
+                                      "(only_return_best=True, do_sample=False) is implemented")
+        s = Engine.make_search("autoregressive", self.max_steps, self.beam_size, self.per_node_beam_size)
+        return _begin_and_run(self, start_predictions, step, s, first_step_rows_per_sentence=True, stop_when_all_eos=True,
+                              fmt="autoregressive", engine_factory=_engine_factory)
 
 
 class GeneratorWithBeamSearch:
@@ -50,6 +132,18 @@ class GeneratorWithBeamSearch:
         assert temperature > 0, "`temperature` should be strictely positive."        # decoder.py:1081
         self.temperature = temperature
         self.kind = "generator"
+
+    def search(self, input_ids: torch.Tensor, step, num_keep_best: int = 1, do_sample: bool = False, top_k=None,
+               top_p=None, num_return_sequences: int = 1, seed: int = 0, _engine_factory=None):
+        """decoder.py:1083-1290 with a caller-supplied `step`: -> (decoded int64 [B, max_steps] = best hypothesis + EOS,
+        right-padded with EOS, logprobs fp32 [B, 1]).  `step` is called for every position up to max_steps (the reference
+        stops calling it once every sentence is done; the extra steps cannot change the result)."""
+        if num_keep_best != 1 or num_return_sequences != 1:
+            raise NotImplementedError("GeneratorWithBeamSearch.search: num_keep_best = num_return_sequences = 1 only")
+        s = Engine.make_search("generator", self.max_steps, self.beam_size, self.per_node_beam_size, self.length_penalty,
+                               do_sample=do_sample, top_k=top_k or 0, top_p=top_p, temperature=self.temperature, seed=seed)
+        return _begin_and_run(self, input_ids, step, s, first_step_rows_per_sentence=False, stop_when_all_eos=False,
+                              fmt="generator", engine_factory=_engine_factory)
 
 
 def load_state_dict_by_suffix(model_keys: Sequence[str], loaded: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

@@ -493,3 +493,109 @@ def test_single_image_task_plumbing_without_a_gpu(tmp_path, monkeypatch, caplog)
     assert [tuple(t.shape) for t in seen["image"]] == [(1, 3, 160, 160)] and seen["prefix"].tolist() == [[101]]
     with pytest.raises(KeyError):
         inference.test_git_inference_single_image(paths[0], "NO_SUCH_MODEL", "")
+
+
+class _FakeSearchContext:
+    """Stand-in for the engine's search seam (begin / rows / advance / finish): greedy over whatever logits it is given,
+    first beam only -- enough to check the host loop of decoder.search(): which rows `step` sees, when the loop stops,
+    how the results are shaped.  (The search itself is tested on the GPU against the scripted reference goldens.)"""
+
+    def __init__(self, eos, B, beams, T):
+        self.eos, self.B, self.k, self.T = eos, B, beams, T
+        self.calls = []
+
+    def search_begin(self, search, start, vocab):
+        self.vocab = vocab
+        self.seq = start.clone()                                   # [B, t]
+        self.lp = torch.zeros(self.B)
+        self.P = start.shape[1]
+        self.early = 0
+
+    def search_rows(self):
+        return self.seq.repeat_interleave(self.k, dim=0)
+
+    def search_advance(self, logits):
+        assert logits.shape == (self.B * self.k, self.vocab), logits.shape
+        lg = logits.float()[::self.k]
+        ended = self.seq[:, -1] == self.eos if self.seq.shape[1] > self.P else torch.zeros(self.B, dtype=torch.bool)
+        nxt = lg.log_softmax(-1).argmax(-1)
+        nxt[ended] = self.eos
+        self.lp += torch.where(ended, torch.zeros(self.B), lg.log_softmax(-1).max(-1).values)
+        self.seq = torch.cat([self.seq, nxt[:, None]], 1)
+        if self.seq.shape[1] == self.P + 1 and self.k == 1 and bool((nxt == self.eos).all()):
+            self.early = 1
+
+    def search_finish(self):
+        t = self.seq.shape[1]
+        tokens = torch.full((self.B, self.T), self.eos, dtype=torch.int64)
+        tokens[:, :t] = self.seq
+        return tokens, self.lp.clone(), torch.tensor([t, self.early, t - self.P, 0], dtype=torch.int32)
+
+    def close(self):
+        pass
+
+
+def test_search_methods_host_loop(monkeypatch):
+    """AutoRegressiveBeamSearch.search / GeneratorWithBeamSearch.search (decoder.py:224-231, 1083-1092): the rows the
+    caller's `step` receives, the early exits, the shapes handed back -- on a stand-in search context."""
+    made = []
+
+    def factory(eos, B, beams, T):
+        made.append(_FakeSearchContext(eos, B, beams, T))
+        return made[-1]
+
+    V, eos = 30, 2
+    seen = []
+
+    def step_never_eos(rows):
+        seen.append(tuple(rows.shape))
+        lg = torch.zeros(rows.shape[0], V)
+        lg[torch.arange(rows.shape[0]), (rows[:, -1] + 3) % (V - 3) + 3] = 5.0       # successor token, never EOS (= 2)
+        return lg
+
+    # AutoRegressiveBeamSearch, beam 3: first call sees ONE row per sentence, later calls B*k rows; runs to max_steps
+    model._SEARCH_ENGINES.clear()
+    dec = model.AutoRegressiveBeamSearch(eos_index=eos, max_steps=7, beam_size=3, per_node_beam_size=2, fix_missing_prefix=True)
+    start = torch.tensor([[5, 9], [5, 11]])
+    preds, lps = dec.search(start, step_never_eos, _engine_factory=factory)
+    assert seen == [(2, 2)] + [(6, t) for t in range(3, 7)]
+    assert preds.shape == (2, 7) and lps.shape == (2,) and preds[:, :2].tolist() == start.tolist()
+    assert (preds != eos).all()
+
+    # beam 1, every sentence ends at its first step: the early return ([B,1], [B,1]) and only ONE step call
+    model._SEARCH_ENGINES.clear()
+    seen.clear()
+
+    def step_eos(rows):
+        seen.append(tuple(rows.shape))
+        lg = torch.zeros(rows.shape[0], V)
+        lg[:, eos] = 9.0
+        return lg
+    dec1 = model.AutoRegressiveBeamSearch(eos_index=eos, max_steps=7, beam_size=1, per_node_beam_size=1, fix_missing_prefix=True)
+    preds, lps = dec1.search(torch.tensor([[5], [6], [7]]), step_eos, _engine_factory=factory)
+    assert seen == [(3, 1)] and preds.tolist() == [[eos]] * 3 and lps.shape == (3, 1)
+
+    # EOS in the middle: the loop stops calling `step` once every row's last token is EOS (decoder.py:319-320)
+    model._SEARCH_ENGINES.clear()
+    seen.clear()
+
+    def step_eos_at_4(rows):
+        seen.append(tuple(rows.shape))
+        return step_eos(rows) if rows.shape[1] >= 3 else step_never_eos(rows)
+    preds, lps = dec1.search(torch.tensor([[5], [6]]), step_eos_at_4, _engine_factory=factory)
+    seen_shapes = [s for s in seen if len(s) == 2]
+    assert preds.shape == (2, 4) and preds[:, -1].tolist() == [eos, eos]
+    assert max(t for _, t in seen_shapes) == 3                      # no call on the 4-token rows
+
+    # GeneratorWithBeamSearch: B*k rows from the first call on, one call per position up to max_steps, [B, T] + [B, 1]
+    model._SEARCH_ENGINES.clear()
+    seen.clear()
+    gen = model.GeneratorWithBeamSearch(eos_index=eos, max_steps=6, beam_size=4, per_node_beam_size=2, length_penalty=0.6)
+    decoded, lps = gen.search(torch.tensor([[5, 9, 4]]), step_never_eos, _engine_factory=factory)
+    assert seen == [(4, t) for t in range(3, 6)]
+    assert decoded.shape == (1, 6) and lps.shape == (1, 1)
+    with pytest.raises(NotImplementedError):
+        gen.search(torch.tensor([[5]]), step_never_eos, num_keep_best=2, _engine_factory=factory)
+    with pytest.raises(NotImplementedError):
+        dec.search(start, step_never_eos, do_sample=True, _engine_factory=factory)
+    model._SEARCH_ENGINES.clear()
