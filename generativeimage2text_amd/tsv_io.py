@@ -7,7 +7,7 @@
 
 Only what `test_git_inference_single_tsv` and the converters of its outputs need (random row access, streaming
 write, concat).  The format is pinned against the reference's own writer / reader / concat by
-oracle/make_tsv_golden.py -> tests/golden/tsv_wire.npz (tests/test_host.py).
+oracle/make_host_golden.py -> tests/golden/tsv_wire.npz (tests/test_host.py).
 """
 from __future__ import annotations
 

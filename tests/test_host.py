@@ -178,7 +178,7 @@ def _gold_tsv():
 
 
 def _rows_fixture():
-    # the rows oracle/make_tsv_golden.py fed to the REFERENCE's tsv_writer
+    # the rows oracle/make_host_golden.py fed to the REFERENCE's tsv_writer
     jpeg_like = base64.b64encode(bytes(range(256)) * 3).decode()
     return [["img_0", jpeg_like], ["img 1 with spaces", "café 中文"], ["k2", ""],
             ["k3", "  padded field  ", "third"], [4, 5.5, "mixed"], ["only_one_column"]]
@@ -186,7 +186,7 @@ def _rows_fixture():
 
 def test_tsv_writer_bytes_equal_reference(tmp_path):
     """.tsv, .lineidx and .lineidx.8b byte for byte what the reference's tsv_writer wrote for the same rows
-    (tests/golden/tsv_wire.npz, frozen by oracle/make_tsv_golden.py from /root/reference)."""
+    (tests/golden/tsv_wire.npz, frozen by oracle/make_host_golden.py from /root/reference)."""
     g = _gold_tsv()
     a = str(tmp_path / "a.tsv")
     tsv_io.tsv_writer(_rows_fixture(), a)
