@@ -182,7 +182,6 @@ def main():
                     help="only time the CPU port at several thread counts (median of 3, bs=8) and print JSON")
     args = ap.parse_args()
     if args.cpu_sweep:
-        import statistics
         res = []
         for th in (16, 32, 64, 128):
             runs = [cpu_baseline(8, args.max_steps, th) for _ in range(3)]
