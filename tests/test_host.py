@@ -599,3 +599,28 @@ def test_search_methods_host_loop(monkeypatch):
     with pytest.raises(NotImplementedError):
         dec.search(start, step_never_eos, do_sample=True, _engine_factory=factory)
     model._SEARCH_ENGINES.clear()
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """include/gitmi.h is a C header (C99, no C++ or HIP types in any signature): a C translation unit that includes it
+    and takes the address of every declared entry point compiles with gcc and links against libgitmi.so."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    names = _declared_functions()
+    src = tmp_path / "abi.c"
+    src.write_text('#include "gitmi.h"\n#include <stdio.h>\ntypedef void (*fn_t)(void);\nint main(void) {\n  fn_t f[] = {\n'
+                   + "".join("    (fn_t)%s,\n" % n for n in names)
+                   + '  };\n  printf("%d %d\\n", (int)(sizeof f / sizeof f[0]), gitmi_abi_version());\n  return 0;\n}\n')
+    inc = os.path.join(ROOT, "include")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lib = engine.LIB_PATH
+    if not os.path.exists(lib):
+        pytest.skip("libgitmi.so not built")
+    exe = tmp_path / "abi"
+    r = subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), lib, "-Wl,-rpath," + os.path.dirname(lib),
+                        "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr          # every symbol the header declares resolves in the library
