@@ -63,6 +63,51 @@ def vit_bf16(cfg, w, images, stream: str):
 mx = 0.0
 
 
+def prefill_kv_bf16(cfg, w, feats, stream: str):
+    """Image rows through the decoder (prefill) with the engine's bf16 arithmetic; the post-norm residual (the
+    LayerNorm output) and the pre-norm sums stored as `stream`; "operand" = no separate residual copy at all: the
+    residual is read back from the bf16 operand copy of the LayerNorm output.  -> per layer (K, V) as bf16-rounded
+    tensors (what the decode attention reads)."""
+    rs = {"fp32": (lambda t: t), "fp16": f16, "bf16": bf, "operand": bf}[stream]
+    ys = rs if stream != "operand" else f16            # the pre-norm sum keeps a stream of its own (fp16 there)
+    P = "textual.visual_projection."
+    y = ys(lin(feats, w[P + "0.weight"], w[P + "0.bias"]))
+    h = O._layer_norm(y, w[P + "1.weight"], w[P + "1.bias"], 1e-5)
+    H, hd = cfg.dec_heads, cfg.dec_hidden // cfg.dec_heads
+    out = []
+    for i in range(cfg.dec_layers):
+        p = f"textual.transformer.encoder.layer.{i}."
+        h_res = rs(h)                                  # residual copy of the hidden state
+        q = bf(lin(h, w[p + "attention.self.query.weight"], w[p + "attention.self.query.bias"]))
+        k = bf(lin(h, w[p + "attention.self.key.weight"], w[p + "attention.self.key.bias"]))
+        v = bf(lin(h, w[p + "attention.self.value.weight"], w[p + "attention.self.value.bias"]))
+        out.append((k, v))
+        if i + 1 == cfg.dec_layers:
+            break
+        qh, kh, vh = (O._split_heads(t, H) for t in (q, k, v))
+        pr = torch.softmax((qh @ kh.transpose(-1, -2)) * hd ** -0.5, dim=-1)
+        ctx = bf(O._merge_heads(bf(pr) @ vh))
+        y = ys(lin(ctx, w[p + "attention.output.dense.weight"], w[p + "attention.output.dense.bias"]) + h_res)
+        a = O._layer_norm(y, w[p + "attention.output.LayerNorm.weight"], w[p + "attention.output.LayerNorm.bias"], 1e-12)
+        a_res = rs(a)
+        u = bf(O._gelu_erf(lin(a, w[p + "intermediate.dense.weight"], w[p + "intermediate.dense.bias"])))
+        y = ys(lin(u, w[p + "output.dense.weight"], w[p + "output.dense.bias"]) + a_res)
+        h = O._layer_norm(y, w[p + "output.LayerNorm.weight"], w[p + "output.LayerNorm.bias"], 1e-12)
+    return out
+
+
+def prefill_kv_ref(cfg, w, feats):
+    x = O.project_visual(cfg, w, feats)
+    out = []
+    for i in range(cfg.dec_layers):
+        p = f"textual.transformer.encoder.layer.{i}."
+        out.append((O._affine(x, w[p + "attention.self.key.weight"], w[p + "attention.self.key.bias"]),
+                    O._affine(x, w[p + "attention.self.value.weight"], w[p + "attention.self.value.bias"])))
+        if i + 1 < cfg.dec_layers:
+            x = O.bert_layer(cfg, w, i, x, x, None)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="GIT_BASE")
@@ -83,6 +128,18 @@ def main():
                 err = (out - ref).abs()
                 print(f"{seed:4d} | {name:6s} | {err.max().item():.4f}      | {err.pow(2).mean().sqrt().item():.5f} | {ref.pow(2).mean().sqrt().item():.3f}"
                       + (f" | stream max |x| {mx:.1f}" if name == "fp32" else ""))
+                if name == "fp32":
+                    feats_eng = out                    # the features the engine's prefill starts from
+            # prefill: image K / V of every decoder layer vs the fp32 oracle's, by how the prefill's streams are stored
+            kv_ref = prefill_kv_ref(cfg, w, ref)
+            print("     prefill stream | max |dK| | max |dV| | rms dK  | rms dV   (over all decoder layers; K rms %.3f)" %
+                  kv_ref[0][0].pow(2).mean().sqrt().item())
+            for name in ("fp32", "fp16", "bf16", "operand"):
+                kv = prefill_kv_bf16(cfg, w, feats_eng, name)
+                dk = torch.cat([(a[0] - b[0]).flatten() for a, b in zip(kv, kv_ref)])
+                dv = torch.cat([(a[1] - b[1]).flatten() for a, b in zip(kv, kv_ref)])
+                print(f"     {name:14s} | {dk.abs().max().item():.4f}   | {dv.abs().max().item():.4f}   | "
+                      f"{dk.pow(2).mean().sqrt().item():.5f} | {dv.pow(2).mean().sqrt().item():.5f}")
 
 
 if __name__ == "__main__":
