@@ -152,6 +152,9 @@ struct gitmi_engine {
     hipGraphExec_t graph_exec_b = nullptr;
     bool graph_is_split = false;
     bool half_submitted = false;        // gitmi_generate_encode submitted, its gitmi_generate_decode not yet
+    // residual streams of the image encoder and the prefill (v_x, p_y, p_hf) stored in fp16 instead of fp32 (bf16 mode
+    // only; GITMI_STREAM_F16=1): half the bytes of their read-modify-writes at 2^-11 relative rounding
+    bool stream_f16 = false;
     hipEvent_t gev[3] = {nullptr, nullptr, nullptr};
     // serving schedule: this context's image encoder starts only after `enc_after`'s has finished (at most one encoder
     // in flight on the device; decode chains of the other contexts fill in beside it)
@@ -229,6 +232,28 @@ static int gemm(gitmi_engine* e, hipStream_t s, const void* A, int lda, const vo
     return 0;
 }
 
+// GEMM whose output (and residual, if any) are rows of a residual stream: fp32, or fp16 with stream_f16
+static int gemm_stream(gitmi_engine* e, hipStream_t s, const void* A, int lda, const void* W, const float* bias,
+                       const void* res, int ldr, void* C, int ldc, int M, int N, int K, int tag) {
+    GemmArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.res = (const float*)res; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldr; g.act = 0;
+    g.out_f16 = e->stream_f16 ? 1 : 0;
+    SpanGuard sp(e, s, tag, 2.0 * (double)M * (double)N * (double)K);
+    HIPCK(launch_gemm(g, e->f32, !e->stream_f16, s));
+    return 0;
+}
+// LayerNorm of stream rows x -> operand copy y_t (compute dtype) [+ stream copy y_s]
+static int ln_stream(gitmi_engine* e, hipStream_t s, const void* x, int ldx, const float* gamma, const float* beta, float eps,
+                     void* y_t, int ld_t, void* y_s, int ld_s, int rows, int D) {
+    if (e->stream_f16)
+        HIPCK(launch_layernorm_s16(x, ldx, gamma, beta, eps, nullptr, y_t, ld_t, false, y_s, ld_s, rows, D, 0, 0, 0, s));
+    else
+        HIPCK(launch_layernorm((const float*)x, ldx, gamma, beta, eps, nullptr, y_t, ld_t, e->f32, (float*)y_s, ld_s, rows, D,
+                               0, 0, 0, s));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 extern "C" int gitmi_abi_version(void) { return GITMI_ABI_VERSION; }
 extern "C" const char* gitmi_last_error(void) { return g_err; }
@@ -275,6 +300,7 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     if (const char* env = getenv("GITMI_ATTN_DBG")) e->attn_dbg = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_DBG")) e->dgemm_dbg = atoi(env);
     if (const char* env = getenv("GITMI_SKINNY")) e->skinny = atoi(env) != 0;
+    if (const char* env = getenv("GITMI_STREAM_F16")) e->stream_f16 = !e->f32 && atoi(env) != 0;
     if (const char* env = getenv("GITMI_GEMM_IMPL")) set_gemm_impl(atoi(env));
     if (attn_decode_configure() != hipSuccess) { delete e; return fail("hipFuncSetAttribute failed"); }
     *out = e;
@@ -689,7 +715,7 @@ extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
     if (!src->finalized) return fail("gitmi_clone: source weights not finalized");
     HIPCK(hipSetDevice(src->device));
     gitmi_engine* e = new gitmi_engine();
-    e->cfg = src->cfg; e->device = src->device; e->f32 = src->f32; e->esz = src->esz;
+    e->cfg = src->cfg; e->device = src->device; e->f32 = src->f32; e->esz = src->esz; e->stream_f16 = src->stream_f16;
     e->attn_impl = src->attn_impl; e->Kp = src->Kp; e->Kp_pad = src->Kp_pad;
     // a clone starts at the native resolution (its own gitmi_set_image_shape state and resized table)
     e->N_nat = e->N = src->N_nat; e->g_nat = e->gh = e->gw = src->g_nat; e->H = e->W = src->cfg.image_size;
@@ -753,10 +779,10 @@ static int encode_frames_impl(gitmi_engine* e, const float* const* frames, int F
                             e->H, e->W, c.patch, e->Kp, e->Kp_pad, s));
     RCK(gemm(e, s, e->patches, e->Kp_pad, e->conv_w, nullptr, nullptr, 0, e->patch_out, D, true, BI * g2, D, e->Kp_pad, 0,
              TAG_GEMM_VIT));
-    HIPCK(launch_vit_assemble_ln(e->patch_out, e->cls, e->pos_cur, e->lnpre_g, e->lnpre_b, 1e-5f, e->v_x, BI, N, D, s));
+    HIPCK(launch_vit_assemble_ln(e->patch_out, e->cls, e->pos_cur, e->lnpre_g, e->lnpre_b, 1e-5f, e->v_x, e->stream_f16, BI, N, D, s));
     for (int l = 0; l < c.vit_layers; ++l) {
         const VitLayerW& L = e->vit[l];
-        HIPCK(launch_layernorm(e->v_x, D, L.ln1g, L.ln1b, 1e-5f, nullptr, e->v_h, D, e->f32, nullptr, 0, M, D, 0, 0, 0, s));
+        RCK(ln_stream(e, s, e->v_x, D, L.ln1g, L.ln1b, 1e-5f, e->v_h, D, nullptr, 0, M, D));
         RCK(gemm(e, s, e->v_h, D, L.wqkv, L.bqkv, nullptr, 0, e->v_qkv, 3 * D, e->f32, M, 3 * D, D, 0, TAG_GEMM_VIT));
         AttnFullArgs a{};
         a.q = e->v_qkv;
@@ -767,16 +793,25 @@ static int encode_frames_impl(gitmi_engine* e, const float* const* frames, int F
         a.ldo = D;
         a.N = N; a.H = c.vit_heads; a.scale = 0.125f;
         HIPCK(launch_attn_full(a, BI, e->f32, e->attn_impl, s));
-        RCK(gemm(e, s, e->v_ctx, D, L.wo, L.bo, e->v_x, D, e->v_x, D, true, M, D, D, 0, TAG_GEMM_VIT));
-        HIPCK(launch_layernorm(e->v_x, D, L.ln2g, L.ln2b, 1e-5f, nullptr, e->v_h, D, e->f32, nullptr, 0, M, D, 0, 0, 0, s));
+        RCK(gemm_stream(e, s, e->v_ctx, D, L.wo, L.bo, e->v_x, D, e->v_x, D, M, D, D, TAG_GEMM_VIT));
+        RCK(ln_stream(e, s, e->v_x, D, L.ln2g, L.ln2b, 1e-5f, e->v_h, D, nullptr, 0, M, D));
         RCK(gemm(e, s, e->v_h, D, L.w1, L.b1, nullptr, 0, e->v_u, 4 * D, e->f32, M, 4 * D, D, 1, TAG_GEMM_VIT));
-        RCK(gemm(e, s, e->v_u, 4 * D, L.w2, L.b2, e->v_x, D, e->v_x, D, true, M, D, 4 * D, 0, TAG_GEMM_VIT));
+        RCK(gemm_stream(e, s, e->v_u, 4 * D, L.w2, L.b2, e->v_x, D, e->v_x, D, M, D, 4 * D, TAG_GEMM_VIT));
     }
     // ln_post (+ temporal embedding of the frame), scattered into the concatenated [B, F*N, D] feature tensor
     for (int fr = 0; fr < F_eff; ++fr) {
         const float* te = (c.num_frames > 0 && e->use_temb) ? e->temb[fr] : nullptr;
-        HIPCK(launch_layernorm(e->v_x + (size_t)fr * B * N * D, D, e->lnpost_g, e->lnpost_b, 1e-5f, te, e->feats, D, e->f32,
-                               feats_out, D, B * N, D, N, Nimg, fr * N, s));
+        if (e->stream_f16) {
+            const char* xs = (const char*)e->v_x + (size_t)fr * B * N * D * 2;      // fp16 rows
+            HIPCK(launch_layernorm_s16(xs, D, e->lnpost_g, e->lnpost_b, 1e-5f, te, e->feats, D, false, nullptr, 0, B * N, D, N,
+                                       Nimg, fr * N, s));
+            if (feats_out)      // parity hook: the fp32 copy of the features comes from a second pass over the same rows
+                HIPCK(launch_layernorm_s16(xs, D, e->lnpost_g, e->lnpost_b, 1e-5f, te, feats_out, D, true, nullptr, 0, B * N, D,
+                                           N, Nimg, fr * N, s));
+        } else {
+            HIPCK(launch_layernorm(e->v_x + (size_t)fr * B * N * D, D, e->lnpost_g, e->lnpost_b, 1e-5f, te, e->feats, D, e->f32,
+                                   feats_out, D, B * N, D, N, Nimg, fr * N, s));
+        }
     }
     e->cur_B = B; e->cur_F = F_eff; e->cur_Nimg = Nimg;
     e->have_feats = true;
@@ -797,8 +832,8 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
     const int d = c.dec_hidden, ffn = c.dec_ffn, D = c.vit_width;
     const int B = e->cur_B, Nimg = e->cur_Nimg, M = B * Nimg;
     SpanGuard phase(e, s, TAG_PREFILL, 0);
-    RCK(gemm(e, s, e->feats, D, e->vp_w, e->vp_b, nullptr, 0, e->p_y, d, true, M, d, D, 0, TAG_GEMM_OTHER));
-    HIPCK(launch_layernorm(e->p_y, d, e->vp_lng, e->vp_lnb, 1e-5f, nullptr, e->p_ht, d, e->f32, e->p_hf, d, M, d, 0, 0, 0, s));
+    RCK(gemm_stream(e, s, e->feats, D, e->vp_w, e->vp_b, nullptr, 0, e->p_y, d, M, d, D, TAG_GEMM_OTHER));
+    RCK(ln_stream(e, s, e->p_y, d, e->vp_lng, e->vp_lnb, 1e-5f, e->p_ht, d, e->p_hf, d, M, d));
     for (int l = 0; l < c.dec_layers; ++l) {
         const DecLayerW& L = e->dec[l];
         const bool last = l + 1 == c.dec_layers;
@@ -821,11 +856,11 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
         a.ldo = d;
         a.N = Nimg; a.H = c.dec_heads; a.scale = 0.125f;
         HIPCK(launch_attn_full(a, B, e->f32, e->attn_impl, s));
-        RCK(gemm(e, s, e->p_ctx, d, L.wo, L.bo, e->p_hf, d, e->p_y, d, true, M, d, d, 0, TAG_GEMM_OTHER));
-        HIPCK(launch_layernorm(e->p_y, d, L.lnag, L.lnab, 1e-12f, nullptr, e->p_ht, d, e->f32, e->p_hf, d, M, d, 0, 0, 0, s));
+        RCK(gemm_stream(e, s, e->p_ctx, d, L.wo, L.bo, e->p_hf, d, e->p_y, d, M, d, d, TAG_GEMM_OTHER));
+        RCK(ln_stream(e, s, e->p_y, d, L.lnag, L.lnab, 1e-12f, e->p_ht, d, e->p_hf, d, M, d));
         RCK(gemm(e, s, e->p_ht, d, L.w1, L.b1, nullptr, 0, e->p_u, ffn, e->f32, M, ffn, d, 2, TAG_GEMM_OTHER));
-        RCK(gemm(e, s, e->p_u, ffn, L.w2, L.b2, e->p_hf, d, e->p_y, d, true, M, d, ffn, 0, TAG_GEMM_OTHER));
-        HIPCK(launch_layernorm(e->p_y, d, L.lnog, L.lnob, 1e-12f, nullptr, e->p_ht, d, e->f32, e->p_hf, d, M, d, 0, 0, 0, s));
+        RCK(gemm_stream(e, s, e->p_u, ffn, L.w2, L.b2, e->p_hf, d, e->p_y, d, M, d, ffn, TAG_GEMM_OTHER));
+        RCK(ln_stream(e, s, e->p_y, d, L.lnog, L.lnob, 1e-12f, e->p_ht, d, e->p_hf, d, M, d));
     }
     e->have_prefill = true;
     return 0;

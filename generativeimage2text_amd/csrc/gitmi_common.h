@@ -23,6 +23,36 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// ---- fp16: storage type of the residual stream in bf16 engine mode (GITMI_STREAM_F16): half the bytes of fp32 at
+// 2^-11 relative rounding -- tools/residual_precision_study.py: +0.002 max feature error, a bf16 stream costs 3x
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
+    const f16x2_t v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ void unpack2h(uint32_t u, float& lo, float& hi) {
+    const f16x2_t v = __builtin_bit_cast(f16x2_t, u);
+    lo = (float)v[0];
+    hi = (float)v[1];
+}
+// 4 consecutive elements of a residual-stream row (16-byte aligned fp32 / 8-byte aligned fp16)
+__device__ __forceinline__ f32x4_t ld4s(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+__device__ __forceinline__ f32x4_t ld4s(const f16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    float a, b, c, d;
+    unpack2h(u.x, a, b);
+    unpack2h(u.y, c, d);
+    return f32x4_t{a, b, c, d};
+}
+__device__ __forceinline__ void st4s(float* p, f32x4_t v) { *reinterpret_cast<f32x4_t*>(p) = v; }
+__device__ __forceinline__ void st4s(f16_t* p, f32x4_t v) {
+    uint2 u;
+    u.x = pack2h(v[0], v[1]);
+    u.y = pack2h(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
 // ---- typed element access: T is float (exact path) or bf16_t (fast path) ----------
 template <typename T> __device__ __forceinline__ float ld(const T* p);
 template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
@@ -30,6 +60,8 @@ template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { retur
 template <typename T> __device__ __forceinline__ void st(T* p, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <> __device__ __forceinline__ float ld<f16_t>(const f16_t* p) { return (float)*p; }
+template <> __device__ __forceinline__ void st<f16_t>(f16_t* p, float v) { *p = (f16_t)v; }
 
 // load 8 consecutive elements as floats (16-byte aligned for bf16, 32 for float)
 __device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {

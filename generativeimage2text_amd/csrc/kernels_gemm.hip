@@ -21,6 +21,7 @@
 // sit on one XCD's L2.
 #include "gitmi_common.h"
 #include "launchers.h"
+#include <type_traits>
 
 namespace gitmi {
 
@@ -66,6 +67,19 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4], b
     }
 }
 
+template <>
+__device__ __forceinline__ void store4<f16_t>(f16_t* p, const float (&v)[4], bool vec) {
+    if (vec) {
+        uint2 t;
+        t.x = pack2h(v[0], v[1]);
+        t.y = pack2h(v[2], v[3]);
+        *reinterpret_cast<uint2*>(p) = t;
+    } else {
+        p[0] = (f16_t)v[0]; p[1] = (f16_t)v[1]; p[2] = (f16_t)v[2]; p[3] = (f16_t)v[3];
+    }
+}
+
+// TOut = f16_t: C and the residual are rows of the fp16 residual stream (GemmArgs::out_f16)
 template <typename TIn, typename TOut, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     using TR = GemmTraits<TIn>;
@@ -218,15 +232,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], g.act);
             }
             if (g.res) {
-                const float* rp = g.res + (size_t)m * g.ldr + n;
-                if (full && vec_r) {
-                    f32x4_t t = *reinterpret_cast<const f32x4_t*>(rp);
+                if constexpr (std::is_same<TOut, f16_t>::value) {
+                    const f16_t* rp = reinterpret_cast<const f16_t*>(g.res) + (size_t)m * g.ldr + n;
+                    if (full && vec_r) {                     // 8-byte aligned: ldr % 4 == 0 and a 16-byte aligned base
+                        const f32x4_t t = ld4s(rp);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += t[r];
+                        for (int r = 0; r < 4; ++r) v[r] += t[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < g.N) v[r] += (float)rp[r];
+                    }
                 } else {
+                    const float* rp = g.res + (size_t)m * g.ldr + n;
+                    if (full && vec_r) {
+                        f32x4_t t = *reinterpret_cast<const f32x4_t*>(rp);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < g.N) v[r] += rp[r];
+                        for (int r = 0; r < 4; ++r) v[r] += t[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < g.N) v[r] += rp[r];
+                    }
                 }
             }
             TOut* cp = C + (size_t)m * g.ldc + n;
@@ -273,6 +300,15 @@ hipError_t launch_gemm(const GemmArgs& g_in, bool in_f32, bool out_f32, hipStrea
     GemmArgs g = g_in;
     g.dbg = g_gemm_dbg;
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (g.out_f16) {
+        // fp16 residual-stream rows out (and in, as the residual): the p8 kernel for the large-M phases, the generic
+        // kernel otherwise (the ring / direct-to-LDS generations have no fp16 epilogue)
+        if (in_f32 || out_f32 || g.K % 64 != 0) return hipErrorInvalidValue;
+        if (g_gemm_impl != 0 && g.M > 512 && gemm_dlds_supported(g, false, false) && (!g.res || g.ldr % 8 == 0) &&
+            gemm_p8_supports(g))
+            return launch_gemm_p8(g, false, s);
+        return launch_gemm_tiles<bf16_t, f16_t>(g, s);
+    }
     // impl: -1 auto | 0 register-staged (also fp32, odd shapes) | 1 direct-to-LDS 128x128 | 2 256x128 3-stage ring |
     //       6 256x256x32 4-stage ring | 9 256x256x64 half-tile pipeline (kernels_gemm10.hip)
     if (g_gemm_impl != 0 && gemm_dlds_supported(g, in_f32, out_f32)) {

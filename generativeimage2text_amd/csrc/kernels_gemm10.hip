@@ -62,6 +62,25 @@ __device__ __forceinline__ float add_unfused(float a, float b) {
     return a + b;
 }
 
+// epilogue barrier: orders this workgroup's LDS traffic only.  __syncthreads() would also wait for every outstanding
+// global store of the wave (vmcnt(0)) -- the slab just written out -- before the next slab may even be staged.
+#define P8_LDS_BARRIER()                                   \
+    do {                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier();                      \
+        asm volatile("" ::: "memory");                     \
+    } while (0)
+
+// 16-bit output types: bf16_t (operands of the next GEMM) and f16_t (the residual stream in bf16 engine mode)
+template <typename T> __device__ __forceinline__ uint32_t pack2o(float lo, float hi) {
+    if constexpr (std::is_same<T, f16_t>::value) return pack2h(lo, hi);
+    else return pack2bf(lo, hi);
+}
+template <typename T> __device__ __forceinline__ void unpack2o(uint32_t u, float& lo, float& hi) {
+    if constexpr (std::is_same<T, f16_t>::value) unpack2h(u, lo, hi);
+    else { lo = __uint_as_float(u << 16); hi = __uint_as_float(u & 0xffff0000u); }
+}
+
 template <int N> __device__ __forceinline__ void wait_vm() {
     if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -327,14 +346,14 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                             *reinterpret_cast<f32x4_t*>(p) = f32x4_t{v[0], v[1], v[2], v[3]};
                         } else {
                             uint2 t2;
-                            t2.x = pack2bf(v[0], v[1]);
-                            t2.y = pack2bf(v[2], v[3]);
+                            t2.x = pack2o<TOut>(v[0], v[1]);
+                            t2.y = pack2o<TOut>(v[2], v[3]);
                             *reinterpret_cast<uint2*>(p) = t2;
                         }
                     }
                 }
             }
-            __syncthreads();
+            P8_LDS_BARRIER();
 #pragma unroll 4
             for (int q = 0; q < MH * CPR / 512; ++q) {
                 const int chunk = tid + q * 512;
@@ -352,25 +371,31 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                     } else {
                         u32x4_t v = *reinterpret_cast<const u32x4_t*>(ep + row * EPS + cc * EPC);
                         if (g.res) {
-                            const float* rp = g.res + (size_t)m * g.ldr + n;
-                            const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(rp);
-                            const f32x4_t r1 = *reinterpret_cast<const f32x4_t*>(rp + 4);
-                            float f[8];
+                            float f[8], rs[8];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                f[2 * e] = __uint_as_float(v[e] << 16);
-                                f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
+                            for (int e = 0; e < 4; ++e) unpack2o<TOut>(v[e], f[2 * e], f[2 * e + 1]);
+                            if constexpr (std::is_same<TOut, f16_t>::value) {
+                                // the residual IS the fp16 stream (g.res points at f16 rows; may alias C: same thread reads, then writes)
+                                const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const f16_t*>(g.res) + (size_t)m * g.ldr + n);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) unpack2h(rr[e], rs[2 * e], rs[2 * e + 1]);
+                            } else {
+                                const float* rp = g.res + (size_t)m * g.ldr + n;
+                                const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(rp);
+                                const f32x4_t r1 = *reinterpret_cast<const f32x4_t*>(rp + 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { rs[e] = r0[e]; rs[4 + e] = r1[e]; }
                             }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { f[e] += r0[e]; f[4 + e] += r1[e]; }
+                            for (int e = 0; e < 8; ++e) f[e] += rs[e];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = pack2bf(f[2 * e], f[2 * e + 1]);
+                            for (int e = 0; e < 4; ++e) v[e] = pack2o<TOut>(f[2 * e], f[2 * e + 1]);
                         }
                         *reinterpret_cast<u32x4_t*>(C + (size_t)m * g.ldc + n) = v;
                     }
                 }
             }
-            __syncthreads();
+            P8_LDS_BARRIER();
         }
 }
 
@@ -438,6 +463,7 @@ static int p8_plan(const GemmArgs& g, int mh, int* ng_out, int* max_cnt_out) {
 // rounds x relative tile time (4 units for the 256-row tile, 3 for the 192-row one)
 int gemm_p8_cost(const GemmArgs& g, int mh) { return p8_plan(g, mh, nullptr, nullptr) * (mh / 32); }
 
+// g.out_f16: C (and the residual, if any) are f16_t rows -- the residual stream of the bf16 engine mode
 hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s) {
     // the 192-row tile when it fills a partial round better (N = 768 at M = 12608: 198 workgroups instead of 150);
     // dbg 64 / 128 force the 192- / 256-row tile (tests, A/B)
@@ -450,6 +476,11 @@ hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s) {
     g.nwg = 8 * max_cnt;
     const bool staged = (g.dbg & 256) != 0;              // A/B: fp32 outputs through the LDS-staged epilogue
     g.dbg &= ~256;
+    if (g.out_f16) {
+        if (mh == 96) launch_p8_t<f16_t, 96>(g, s);
+        else launch_p8_t<f16_t, 128>(g, s);
+        return hipGetLastError();
+    }
     if (mh == 96) {
         if (!out_f32) launch_p8_t<bf16_t, 96>(g, s);
         else if (staged) launch_p8_t<float, 96, 0>(g, s);

@@ -23,26 +23,27 @@ constexpr int LN_MAXV = 16;   // supports D <= 1024 with one wave per row
 
 // y = (x - mean) * rsqrt(var + eps) * gamma + beta (+ add_after[D]);  statistics in fp32,
 // biased variance from centred values (matches at::native layer_norm numerics class).
-template <typename TOut>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
+// TS = element type of the residual stream: x and the optional y_f copy (float, or f16_t in bf16 engine mode)
+template <typename TOut, typename TS = float>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TS* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         const float* __restrict__ add_after,
                                                         TOut* __restrict__ y_t, int ld_t,
-                                                        float* __restrict__ y_f, int ld_f, int rows, int D,
+                                                        TS* __restrict__ y_f, int ld_f, int rows, int D,
                                                         RowMap map) {
     // one wave per row, 16-byte accesses: lane handles columns (lane + 64*i)*4 .. +4  (D % 4 == 0, D <= 1024)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + (size_t)row * ldx;
+    const TS* xr = x + (size_t)row * ldx;
     constexpr int NV = LN_MAXV / 4;
     f32x4_t v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
-        v[i] = c < D ? *reinterpret_cast<const f32x4_t*>(xr + c) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        v[i] = c < D ? ld4s(xr + c) : f32x4_t{0.f, 0.f, 0.f, 0.f};
         s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
     const float mean = wave_sum(s) / (float)D;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                     *reinterpret_cast<uint2*>(y_t + orow * ld_t + c) = t;
                 }
             }
-            if (y_f) *reinterpret_cast<f32x4_t*>(y_f + orow * ld_f + c) = f32x4_t{o[0], o[1], o[2], o[3]};
+            if (y_f) st4s(y_f + orow * ld_f + c, f32x4_t{o[0], o[1], o[2], o[3]});
         }
     }
 }
@@ -103,6 +104,24 @@ __global__ void im2col_kernel(const float* __restrict__ img, TOut* __restrict__ 
             val = img[(((size_t)b * C + c) * H + gy * p + ky) * W + gx * p + kx];
         }
         st<TOut>(out + i, val);
+    }
+}
+
+// The same for 16-pixel patches and bf16 output (ViT-B/16, the benchmark path), eight consecutive kx per thread: two
+// 16-byte reads of an image row, one 16-byte store.  Thread order = output order, so stores are row-contiguous.
+__global__ __launch_bounds__(256) void im2col_p16_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B, int C,
+                                                         int H, int W, int gh, int gw, int Kpad) {
+    const int K8 = (C * 256) >> 3;                                   // 8-element groups per patch row (K = C*16*16)
+    const size_t total = (size_t)B * gh * gw * K8;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k8 = (int)(i % K8);
+        const size_t prow = i / K8;
+        const int kx0 = (k8 & 1) * 8, ky = (k8 >> 1) & 15, c = k8 >> 5;
+        const int gx = (int)(prow % gw), gy = (int)((prow / gw) % gh), b = (int)(prow / ((size_t)gh * gw));
+        const float* src = img + (((size_t)b * C + c) * H + gy * 16 + ky) * W + gx * 16 + kx0;
+        float v[8];
+        ld8(src, v);
+        st8(out + prow * Kpad + (size_t)k8 * 8, v);
     }
 }
 
@@ -153,12 +172,13 @@ __global__ void pos_bicubic_kernel(const float* __restrict__ pos, float* __restr
 
 // token row (b, n): n == 0 ? class_embedding : patch_out[b*g2 + n - 1];  + positional[n];  ln_pre.
 // Output: fp32 residual stream X[B*N, D].
+template <typename TS>
 __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __restrict__ patch_out,
                                                               const float* __restrict__ cls,
                                                               const float* __restrict__ pos,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps,
-                                                              float* __restrict__ X, int B, int N, int D) {
+                                                              TS* __restrict__ X, int B, int N, int D) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * N) return;
@@ -185,7 +205,7 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane + 64 * i;
-        if (c < D) X[(size_t)row * D + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        if (c < D) st<TS>(X + (size_t)row * D + c, (v[i] - mean) * rstd * gamma[c] + beta[c]);
     }
 }
 
@@ -316,6 +336,9 @@ hipError_t launch_im2col(const float* img, void* out, bool out_f32, int B, int H
     if (out_f32)
         hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, img, (float*)out, B,
                            3, H, W, p, gh, gw, K, Kpad);
+    else if (p == 16 && K == 3 * 256 && Kpad == K && (W & 3) == 0 && ((uintptr_t)img & 15) == 0)
+        hipLaunchKernelGGL(im2col_p16_kernel, dim3(grid_for(total / 8, 256)), dim3(256), 0, s, img, (bf16_t*)out, B, 3, H, W,
+                           gh, gw, Kpad);
     else
         hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, img, (bf16_t*)out,
                            B, 3, H, W, p, gh, gw, K, Kpad);
@@ -329,10 +352,33 @@ hipError_t launch_pos_bicubic(const float* pos, float* out, int g, int gh, int g
 }
 
 hipError_t launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* gamma,
-                                  const float* beta, float eps, float* X, int B, int N, int D, hipStream_t s) {
+                                  const float* beta, float eps, void* X, bool x_f16, int B, int N, int D, hipStream_t s) {
     if (D > 64 * LN_MAXV) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(vit_assemble_ln_kernel, dim3((B * N + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, gamma,
-                       beta, eps, X, B, N, D);
+    if (x_f16)
+        hipLaunchKernelGGL(vit_assemble_ln_kernel<f16_t>, dim3((B * N + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, gamma,
+                           beta, eps, (f16_t*)X, B, N, D);
+    else
+        hipLaunchKernelGGL(vit_assemble_ln_kernel<float>, dim3((B * N + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, gamma,
+                           beta, eps, (float*)X, B, N, D);
+    return hipGetLastError();
+}
+
+// LayerNorm over a residual stream stored in fp16 (bf16 engine mode): x and the optional stream copy y_s are f16_t,
+// the operand copy y_t is bf16 (t_is_f32: fp32 -- the parity hook that hands the features back); add_after / row remap as in
+// launch_layernorm.
+hipError_t launch_layernorm_s16(const void* x, int ldx, const float* gamma, const float* beta, float eps,
+                                const float* add_after, void* y_t, int ld_t, bool t_is_f32, void* y_s, int ld_s,
+                                int rows, int D, int map_n_in, int map_n_out, int map_off, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (D > 64 * LN_MAXV || (D & 3) || (ldx & 3) || (ld_t & 3) || (y_s && (ld_s & 3))) return hipErrorInvalidValue;
+    RowMap m{map_n_in > 0 ? map_n_in : rows, map_n_in > 0 ? map_n_out : rows, map_off};
+    dim3 grid((rows + 3) / 4), block(256);
+    if (t_is_f32)
+        hipLaunchKernelGGL((layernorm_kernel<float, f16_t>), grid, block, 0, s, (const f16_t*)x, ldx, gamma, beta, eps,
+                           add_after, (float*)y_t, ld_t, (f16_t*)y_s, ld_s, rows, D, m);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<bf16_t, f16_t>), grid, block, 0, s, (const f16_t*)x, ldx, gamma, beta, eps,
+                           add_after, (bf16_t*)y_t, ld_t, (f16_t*)y_s, ld_s, rows, D, m);
     return hipGetLastError();
 }
 

@@ -13,6 +13,7 @@ struct GemmArgs {
     int tiles_n, nwg;
     int ng;     // XCD tile partition: N split into ng groups, M into 8/ng (kernels_gemm3.hip)
     int dbg;    // timing experiments only (gemm_ring_kernel): 1 no C stores, 2 no epilogue, 4 no MFMA, 8 no loads in loop
+    int out_f16; // C and `res` are f16_t rows (residual stream of the bf16 engine mode); bf16 inputs, p8 + generic kernel only
 };
 hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t s);
 // second-generation bf16 kernel (direct-to-LDS staging, swizzled LDS, LDS-staged epilogue)
@@ -64,7 +65,10 @@ hipError_t launch_im2col(const float* img, void* out, bool out_f32, int B, int H
                          hipStream_t s);
 hipError_t launch_pos_bicubic(const float* pos, float* out, int g, int gh, int gw, int D, hipStream_t s);
 hipError_t launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* gamma,
-                                  const float* beta, float eps, float* X, int B, int N, int D, hipStream_t s);
+                                  const float* beta, float eps, void* X, bool x_f16, int B, int N, int D, hipStream_t s);
+hipError_t launch_layernorm_s16(const void* x, int ldx, const float* gamma, const float* beta, float eps,
+                                const float* add_after, void* y_t, int ld_t, bool t_is_f32, void* y_s, int ld_s,
+                                int rows, int D, int map_n_in, int map_n_out, int map_off, hipStream_t s);
 hipError_t launch_embed_ln(const int* ids, int ld_ids, int pos, const float* words, const float* positions,
                            const float* gamma, const float* beta, float eps, float* h_f, void* h_t, bool t_is_f32,
                            int R, int D, int vocab, bool frag, hipStream_t s);
