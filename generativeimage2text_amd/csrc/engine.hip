@@ -159,6 +159,7 @@ struct gitmi_engine {
     // serving schedule: this context's image encoder starts only after `enc_after`'s has finished (at most one encoder
     // in flight on the device; decode chains of the other contexts fill in beside it)
     gitmi_engine* enc_after = nullptr;
+    std::vector<gitmi_engine*> enc_watchers;   // contexts whose enc_after is this one (they wait on enc_done)
     hipEvent_t enc_done = nullptr;
     double split_encode_ms = 0, split_decode_ms = 0;
     int split_calls = 0, split_steps = 0;
@@ -171,9 +172,9 @@ struct gitmi_engine {
     // hipGraph cache for gitmi_generate
     struct GraphKey {
         int B, Q, F, P, kind, k, pn, T, H, W, ragged, ident, temb; double lp;
-        int smp, top_k; double top_p, temp; unsigned long long seed;
+        int smp, top_k; double top_p, temp, rp; unsigned long long seed;
         bool operator==(const GraphKey& o) const {
-            return smp == o.smp && top_k == o.top_k && top_p == o.top_p && temp == o.temp && seed == o.seed && B == o.B && Q == o.Q && F == o.F && P == o.P && kind == o.kind && k == o.k && pn == o.pn && T == o.T &&
+            return rp == o.rp && smp == o.smp && top_k == o.top_k && top_p == o.top_p && temp == o.temp && seed == o.seed && B == o.B && Q == o.Q && F == o.F && P == o.P && kind == o.kind && k == o.k && pn == o.pn && T == o.T &&
                    H == o.H && W == o.W && ragged == o.ragged && ident == o.ident && temb == o.temb && lp == o.lp;
         }
     };
@@ -321,6 +322,12 @@ extern "C" void gitmi_destroy(gitmi_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
     hipDeviceSynchronize();
+    // serving-schedule links: nobody keeps a pointer to a destroyed context
+    if (e->enc_after) {
+        auto& w = e->enc_after->enc_watchers;
+        w.erase(std::remove(w.begin(), w.end(), e), w.end());
+    }
+    for (gitmi_engine* w : e->enc_watchers) w->enc_after = nullptr;
     destroy_graph(e);
     if (e->own_stream) hipStreamDestroy(e->own_stream);
     if (e->fence_in) hipEventDestroy(e->fence_in);
@@ -426,7 +433,9 @@ static int alloc_workspaces(gitmi_engine* e) {
     const int D = c.vit_width, d = c.dec_hidden;
     const size_t Mv = (size_t)c.max_batch * c.max_frames * e->Nmax;  // ViT rows: all frames of a call in one pass
     const size_t Mp = (size_t)c.max_batch * c.max_frames * e->Nmax;  // prefill rows
-    const size_t R = (size_t)round_up(c.max_batch * c.max_beams, 16);   // fragment-major operand buffers hold whole 16-row tiles
+    // fragment-major operand buffers hold whole 16-row tiles, and the wide chain GEMMs / the vocabulary head load their
+    // activations four tiles (64 rows) at a time whatever M is: every row-sized buffer is padded to 64 rows
+    const size_t R = (size_t)round_up(c.max_batch * c.max_beams, 64);
     const int T = c.max_text_len;
     RCK(dev_alloc(e, &e->patches, (size_t)c.max_batch * c.max_frames * (e->Nmax - 1) * e->Kp_pad * esz));
     RCK(dev_alloc_t(e, &e->patch_out, (size_t)c.max_batch * c.max_frames * (e->Nmax - 1) * D));
@@ -472,8 +481,9 @@ static int alloc_workspaces(gitmi_engine* e) {
     RCK(dev_alloc_t(e, &e->logits, R * e->ldl));
     // candidate lists of a step: the fused vocabulary head writes one list per (row, 128-column workgroup)
     e->vocab_cols = 128;                  // columns per workgroup of the fused head (239 workgroups for the 30522-token vocabulary)
-    if (vocab_parts(c.vocab, e->vocab_cols) > 256) return fail("vocabularies above 32768 tokens are not supported by the fused head");
-    e->vocab_nparts = vocab_parts(c.vocab, e->vocab_cols);
+    // only the bf16 decode chain uses the fused head (finalize_weights turns the chain off for vocabularies above 32768
+    // tokens); f32 engines and search-only contexts get ONE list per row from row_topm / sample_rows
+    e->vocab_nparts = (e->skinny && !e->f32) ? vocab_parts(c.vocab, e->vocab_cols) : 1;
     RCK(dev_alloc_t(e, &e->part_val, R * (size_t)e->vocab_nparts * 16));
     RCK(dev_alloc_t(e, &e->part_idx, R * (size_t)e->vocab_nparts * 16));
     RCK(dev_alloc_t(e, &e->part_lse, R * (size_t)e->vocab_nparts));
@@ -945,6 +955,11 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
 }
 
 static int sample_candidates(gitmi_engine* e, const float* logits, int ldl, int R, int step, hipStream_t s, StepCands* cands);
+// repetition penalty of the current search (GENERATOR only; 0 and 1 both mean "off")
+static float rep_penalty_of(const gitmi_engine* e) {
+    const double rp = e->sample.repetition_penalty;
+    return (e->ss.kind == GITMI_SEARCH_GENERATOR && rp > 0 && rp != 1.0) ? (float)rp : 0.f;
+}
 
 // vocabulary head of the step: candidate lists for the search (and optionally the logits themselves)
 static int decode_head_impl(gitmi_engine* e, const int* ids, int ld_ids, int cur_len, int R, int beams, int suppress_kind,
@@ -963,6 +978,7 @@ static int decode_head_impl(gitmi_engine* e, const int* ids, int ld_ids, int cur
         v.stats_in = e->stats_o; v.strips_in = d / 16; v.inv_d = 1.0f / (float)d; v.eps_in = 1e-12f;
         v.M = R; v.N = c.vocab; v.K = d; v.cols_per_wg = e->vocab_cols;
         v.ids = ids; v.ld_ids = ld_ids; v.cur_len = cur_len; v.plen = e->plen_dev; v.beams = beams; v.suppress_kind = suppress_kind;
+        v.rep_penalty = ids ? rep_penalty_of(e) : 0.f;
         v.part_val = e->part_val; v.part_idx = e->part_idx; v.part_lse = e->part_lse;
         v.logits_out = logits_out; v.ld_logits = ldl;
         {
@@ -976,7 +992,8 @@ static int decode_head_impl(gitmi_engine* e, const int* ids, int ld_ids, int cur
         cands->nparts = 1; cands->slots = row_topm_slots(M);
         if (sampling) RCK(sample_candidates(e, e->logits, e->ldl, R, cur_len, s, cands));
         else if (ids)
-            HIPCK(launch_row_topm(e->logits, e->ldl, c.vocab, ids, ld_ids, cur_len, e->plen_dev, beams, suppress_kind, M, R,
+            HIPCK(launch_row_topm(e->logits, e->ldl, c.vocab, ids, ld_ids, cur_len, e->plen_dev, beams, suppress_kind,
+                                  rep_penalty_of(e), M, R,
                                   e->part_val, e->part_idx, e->part_lse, s));
         if (logits_out && logits_out != e->logits) HIPCK(launch_copy_f32(e->logits, e->ldl, logits_out, ldl, R, c.vocab, s));
     }
@@ -1047,6 +1064,11 @@ static int search_begin_impl(gitmi_engine* e, const gitmi_search* sp, int B, int
     if (sp->max_steps > c.max_text_len) return fail("search: max_steps %d exceeds max_text_len %d", sp->max_steps, c.max_text_len);
     if (minP < 1 || maxP > sp->max_steps) return fail("search: prefix lengths [%d,%d] outside [1,max_steps]", minP, maxP);
     if (sp->kind == GITMI_SEARCH_GENERATOR && !(sp->length_penalty > 0)) return fail("search: length_penalty must be > 0");
+    if (sp->repetition_penalty != 0 && sp->repetition_penalty != 1.0) {
+        if (sp->kind != GITMI_SEARCH_GENERATOR) return fail("search: repetition_penalty belongs to GeneratorWithBeamSearch (decoder.py:1064)");
+        if (!(sp->repetition_penalty >= 1.0)) return fail("search: `repetition_penalty` should be >= 1 (decoder.py:1080)");
+        if (sp->max_steps > 1024) return fail("search: repetition_penalty supports histories up to 1024 tokens");
+    }
     if (sp->do_sample) {
         if (sp->kind != GITMI_SEARCH_GENERATOR) return fail("search: do_sample is implemented for GeneratorWithBeamSearch (decoder.py:1146-1166) only");
         if (sp->temperature < 0) return fail("search: temperature must be > 0");
@@ -1074,7 +1096,8 @@ static int sample_candidates(gitmi_engine* e, const float* logits, int ldl, int 
     const gitmi_search& sp = e->sample;
     const float temp = sp.temperature > 0 ? (float)sp.temperature : 1.0f;
     HIPCK(launch_sample_rows(logits, ldl, e->ss.V, R, temp, sp.top_k, (float)sp.top_p, e->ss.pn, sp.seed, step,
-                             e->part_val, e->part_idx, e->part_lse, nullptr, s));
+                             e->part_val, e->part_idx, e->part_lse, nullptr, e->ss.ids[e->ss_cur], e->ss.T, step,
+                             rep_penalty_of(e), s));
     cands->part_val = e->part_val; cands->part_idx = e->part_idx; cands->part_lse = e->part_lse;
     cands->nparts = 1; cands->slots = e->ss.pn;
     return 0;
@@ -1142,8 +1165,19 @@ extern "C" int gitmi_search_advance(gitmi_engine* e, const float* logits, void* 
     if (st.sampled) RCK(sample_candidates(e, logits, st.V, R, e->ss_len, s, &cands));
     else
         HIPCK(launch_row_topm(logits, st.V, st.V, st.ids[e->ss_cur], st.T, e->ss_len, e->plen_dev, st.k,
-                              st.kind == GITMI_SEARCH_AUTOREGRESSIVE ? 1 : 0, M, R, e->part_val, e->part_idx, e->part_lse, s));
+                              st.kind == GITMI_SEARCH_AUTOREGRESSIVE ? 1 : 0, rep_penalty_of(e), M, R, e->part_val,
+                              e->part_idx, e->part_lse, s));
     return search_step_impl(e, cands, false, s);
+}
+
+extern "C" int gitmi_search_done_count(gitmi_engine* e, int* done_out, void* stream) {
+    RCK(check_ready(e));
+    if (!done_out) return fail("search_done_count: null argument");
+    int h = 0;
+    HIPCK(hipMemcpyAsync(&h, e->ss.info, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCK(hipStreamSynchronize((hipStream_t)stream));
+    *done_out = h;
+    return 0;
 }
 
 extern "C" int gitmi_search_finish(gitmi_engine* e, int64_t* tokens_out, float* logprob_out, int32_t* info_out,
@@ -1254,7 +1288,10 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     key.T = sp->max_steps; key.H = e->H; key.W = e->W; key.lp = sp->length_penalty;
     key.ragged = ragged ? 1 : 0; key.ident = e->img_identity ? 1 : 0; key.temb = e->use_temb ? 1 : 0;
     key.smp = sp->do_sample; key.top_k = sp->top_k; key.top_p = sp->top_p; key.temp = sp->temperature; key.seed = sp->seed;
-    const bool split = e->profile_mode == 2 || e->enc_after != nullptr || e->enc_done != nullptr || phase != 0;
+    key.rp = sp->repetition_penalty;
+    // two graphs (encode + prefill | decode) whenever something has to happen between them: profiling events, the
+    // enc_done record other contexts wait for, or the caller submits the halves itself
+    const bool split = e->profile_mode == 2 || e->enc_after != nullptr || !e->enc_watchers.empty() || phase != 0;
     if (phase == 2 && !(e->graph_valid && key == e->graph_key && e->graph_is_split && e->half_submitted))
         return fail("generate_decode: no matching gitmi_generate_encode was submitted on this context");
     if (!e->graph_valid || !(key == e->graph_key) || split != e->graph_is_split) {
@@ -1299,7 +1336,7 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
         if (phase != 2) {
             if (e->enc_after && e->enc_after->enc_done) HIPCK(hipStreamWaitEvent(x, e->enc_after->enc_done, 0));
             HIPCK(hipGraphLaunch(e->graph_exec, x));
-            if (e->enc_done) HIPCK(hipEventRecord(e->enc_done, x));
+            if (e->enc_done && !e->enc_watchers.empty()) HIPCK(hipEventRecord(e->enc_done, x));
         }
         if (phase != 1) HIPCK(hipGraphLaunch(e->graph_exec_b, x));
         e->half_submitted = phase == 1;
@@ -1432,12 +1469,22 @@ extern "C" int gitmi_profile_enable(gitmi_engine* e, int on) {
 // starts only after the encoder of `after`'s most recently submitted call has finished; the decode steps are not
 // ordered.  Chain the contexts in a ring in submission order: at most one MFMA-bound encoder runs at a time and the
 // latency-bound decode chains of the other contexts fill in beside it.  after == NULL removes the dependency.
+static void unlink_encode_after(gitmi_engine* e) {
+    if (!e->enc_after) return;
+    auto& w = e->enc_after->enc_watchers;
+    w.erase(std::remove(w.begin(), w.end(), e), w.end());
+    e->enc_after = nullptr;
+}
 extern "C" int gitmi_set_encode_after(gitmi_engine* e, gitmi_engine* after) {
     if (!e) return fail("null engine");
+    if (after == e) return fail("set_encode_after: a context cannot wait for its own encoder");
     HIPCK(hipSetDevice(e->device));
-    e->enc_after = after;
-    if (!e->enc_done) HIPCK(hipEventCreateWithFlags(&e->enc_done, hipEventDisableTiming));
-    if (after && !after->enc_done) HIPCK(hipEventCreateWithFlags(&after->enc_done, hipEventDisableTiming));
+    unlink_encode_after(e);
+    if (after) {
+        if (!after->enc_done) HIPCK(hipEventCreateWithFlags(&after->enc_done, hipEventDisableTiming));
+        after->enc_watchers.push_back(e);
+        e->enc_after = after;
+    }
     return 0;
 }
 
@@ -1590,7 +1637,7 @@ extern "C" int gitmi_op_sample_rows(const float* logits, int R, int V, float tem
     float2* lse = nullptr;
     HIPCK(hipMalloc((void**)&lse, (size_t)R * sizeof(float2)));
     hipError_t err = launch_sample_rows(logits, V, V, R, temperature, top_k, top_p, ndraw, seed, step, draw_logprob, draw_token,
-                                        lse, filtered_out, (hipStream_t)stream);
+                                        lse, filtered_out, nullptr, 0, 0, 0.f, (hipStream_t)stream);
     if (err == hipSuccess) err = hipStreamSynchronize((hipStream_t)stream);
     hipFree(lse);
     HIPCK(err);

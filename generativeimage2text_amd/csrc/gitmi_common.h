@@ -116,6 +116,30 @@ __device__ __forceinline__ size_t frag_tile(int rt, int ks, int ksteps, int lane
     return (((size_t)rt * ksteps + ks) * 64 + lane) * 8;
 }
 
+// ---- repetition penalty of GeneratorWithBeamSearch.search (decoder.py:1135-1144): the raw score of every token that is
+// already in a row's history is multiplied (score < 0) or divided (score >= 0) by the penalty before the log-softmax.
+__device__ __forceinline__ float rep_penalize(float x, float rp) { return x < 0.f ? x * rp : x / rp; }
+// the history of a row as an open-addressing set in LDS (<= HIST_SLOTS / 2 tokens; empty slot = -1)
+constexpr int HIST_SLOTS = 2048;
+__device__ __forceinline__ unsigned int hist_hash(int tok) { return ((unsigned int)tok * 2654435761u) >> 21; }   // 11 bits
+__device__ __forceinline__ void hist_insert(int* tbl, int tok) {
+    unsigned int h = hist_hash(tok);
+    for (;;) {
+        const int old = atomicCAS(&tbl[h], -1, tok);
+        if (old == -1 || old == tok) return;
+        h = (h + 1) & (HIST_SLOTS - 1);
+    }
+}
+__device__ __forceinline__ bool hist_contains(const int* tbl, int tok) {
+    unsigned int h = hist_hash(tok);
+    for (;;) {
+        const int v = tbl[h];
+        if (v == tok) return true;
+        if (v == -1) return false;
+        h = (h + 1) & (HIST_SLOTS - 1);
+    }
+}
+
 // activation codes shared with the host
 #define GITMI_ACT_NONE 0
 #define GITMI_ACT_QUICKGELU 1   // x * sigmoid(1.702 x)            CLIP/model.py:171-173

@@ -276,6 +276,15 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
             if (suppress) last_tok = g.ids[(size_t)fm * g.ld_ids + g.cur_len - 1];
         }
     }
+    // repetition penalty: which of this lane's columns (bit st*4 + r <-> column c0 + st*16 + lg*4 + r) are in the row's history
+    unsigned int pen_mask = 0u;
+    const bool pen = g.ids != nullptr && g.rep_penalty != 0.f && g.rep_penalty != 1.f;
+    if (finisher && pen) {
+        for (int s = 0; s < g.cur_len; ++s) {
+            const int rel = g.ids[(size_t)fm * g.ld_ids + s] - c0;
+            if (rel >= 0 && rel < 16 * NS && ((rel >> 2) & 3) == lg) pen_mask |= 1u << ((rel >> 4) * 4 + (rel & 3));
+        }
+    }
 
     // ---- every operand fragment of this wave's K range, requested up front -------------------------------
     const int ksteps = g.K >> 5;
@@ -363,6 +372,7 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
                 float x = v[r];
                 const int idx = n + r;
                 if (idx >= g.N) continue;
+                if ((pen_mask >> (st * 4 + r)) & 1u) x = rep_penalize(x, g.rep_penalty);
                 if (idx == last_tok) x = -10000.f;
                 if (x > mx) { sm = sm * fast_exp(mx - x) + 1.f; mx = x; }
                 else sm += fast_exp(x - mx);

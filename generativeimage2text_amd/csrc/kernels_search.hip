@@ -32,9 +32,10 @@ template <int MMAX, int NT>
 __global__ __launch_bounds__(NT) void row_topm_kernel(const float* __restrict__ logits, int ldl, int V,
                                                        const int* __restrict__ ids, int ld_ids, int cur_len,
                                                        const int* __restrict__ plen, int beams, int suppress_kind,
-                                                       float* __restrict__ part_val, int* __restrict__ part_idx,
-                                                       float2* __restrict__ part_lse) {
+                                                       float rep_penalty, float* __restrict__ part_val,
+                                                       int* __restrict__ part_idx, float2* __restrict__ part_lse) {
     constexpr int NW = NT / 64;
+    __shared__ int s_hist[HIST_SLOTS];
     __shared__ float s_val[NT * MMAX];
     __shared__ int s_idx[NT * MMAX];
     __shared__ float s_red[2 * NW];
@@ -47,6 +48,14 @@ __global__ __launch_bounds__(NT) void row_topm_kernel(const float* __restrict__ 
     const int last = suppress ? ids[(size_t)r * ld_ids + cur_len - 1] : -1;
     float* cv = part_val + (size_t)r * MMAX;
     int* ci = part_idx + (size_t)r * MMAX;
+    // repetition penalty (GENERATOR, decoder.py:1135-1144): the tokens of this row's history, as a set in LDS
+    const bool pen = ids != nullptr && rep_penalty != 0.f && rep_penalty != 1.f;
+    if (pen) {
+        for (int i = tid; i < HIST_SLOTS; i += NT) s_hist[i] = -1;
+        __syncthreads();
+        for (int s = tid; s < cur_len; s += NT) hist_insert(s_hist, ids[(size_t)r * ld_ids + s]);
+        __syncthreads();
+    }
 
     float tv[MMAX];
     int ti[MMAX];
@@ -54,6 +63,7 @@ __global__ __launch_bounds__(NT) void row_topm_kernel(const float* __restrict__ 
     for (int j = 0; j < MMAX; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
     float mx = -INFINITY, sm = 0.f;
     auto feed = [&](float v, int i) {
+        if (pen && hist_contains(s_hist, i)) v = rep_penalize(v, rep_penalty);
         if (i == last) v = -10000.f;
         // online log-sum-exp
         if (v > mx) { sm = sm * __expf(mx - v) + 1.f; mx = v; }
@@ -182,20 +192,33 @@ __global__ __launch_bounds__(SMP_NT) void sample_rows_kernel(const float* __rest
                                                              float inv_temp, int top_k, float top_p, int ndraw,
                                                              unsigned int seed_lo, unsigned int seed_hi, int step,
                                                              float* __restrict__ part_val, int* __restrict__ part_idx,
-                                                             float2* __restrict__ part_lse, float* __restrict__ filtered_out) {
+                                                             float2* __restrict__ part_lse, float* __restrict__ filtered_out,
+                                                             const int* __restrict__ ids, int ld_ids, int cur_len,
+                                                             float rep_penalty) {
+    __shared__ int s_hist[HIST_SLOTS];
     __shared__ float sh_f[SMP_NT / 64];
     __shared__ int sh_i[SMP_NT / 64];
     __shared__ float s_bv[SMP_NT / 64];
     __shared__ int s_bi[SMP_NT / 64];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* x = logits + (size_t)r * ldl;
+    // repetition penalty on the raw scores, before the temperature (decoder.py:1135-1149)
+    const bool pen = ids != nullptr && rep_penalty != 0.f && rep_penalty != 1.f;
+    if (pen) {
+        for (int i = tid; i < HIST_SLOTS; i += SMP_NT) s_hist[i] = -1;
+        __syncthreads();
+        for (int s = tid; s < cur_len; s += SMP_NT) hist_insert(s_hist, ids[(size_t)r * ld_ids + s]);
+        __syncthreads();
+    }
     float xv[SMP_PER];
     unsigned int key[SMP_PER];
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < SMP_PER; ++i) {
         const int j = tid + i * SMP_NT;
-        xv[i] = j < V ? x[j] * inv_temp : -INFINITY;
+        float raw = j < V ? x[j] : 0.f;
+        if (pen && j < V && hist_contains(s_hist, j)) raw = rep_penalize(raw, rep_penalty);
+        xv[i] = j < V ? raw * inv_temp : -INFINITY;
         key[i] = j < V ? f2key(xv[i]) : 0u;
         mx = fmaxf(mx, xv[i]);
     }
@@ -479,9 +502,12 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
             float n_max = -INFINITY;
             for (int c = 0; c < ncand; ++c) {
                 if (st.sampled) {
-                    // sampling branch (decoder.py:1155-1166): the per_node draws of beam 0, then of beam 1, ... in draw order
+                    // sampling branch (decoder.py:1155-1166): the per_node draws of beam 0, then of beam 1, ... in draw order.
+                    // Word and score of candidate c come from beam row c / pn, but the reference attaches it to beam
+                    // c % k: its beam offsets are arange(k) * V tiled per_node times over the flattened [k, pn] draws
+                    // (beam_indices.repeat(batch, per_node_beam_size), decoder.py:1161-1164).  Reproduced as is.
                     const int j = c / pn, d = c % pn;
-                    n_score[c] = c_val[j][d] + st.score[src][b * k + j]; n_beam[c] = j; n_word[c] = c_idx[j][d];
+                    n_score[c] = c_val[j][d] + st.score[src][b * k + j]; n_beam[c] = c % k; n_word[c] = c_idx[j][d];
                 } else {
                     float best = 0.f; int bj = -1; long long bflat = 0;
                     for (int j = 0; j < k; ++j) {
@@ -713,13 +739,14 @@ hipError_t launch_load_ids(const long long* tokens, int R, int t, int* ids, int*
 int row_topm_slots(int M) { return M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : M <= 8 ? 8 : 16; }
 
 hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, int ld_ids, int cur_len,
-                           const int* plen, int beams, int suppress_kind, int M, int R, float* part_val,
-                           int* part_idx, float2* part_lse, hipStream_t s) {
+                           const int* plen, int beams, int suppress_kind, float rep_penalty, int M, int R,
+                           float* part_val, int* part_idx, float2* part_lse, hipStream_t s) {
     if (M < 1 || M > 16) return hipErrorInvalidValue;
+    if (rep_penalty != 0.f && rep_penalty != 1.f && ids && cur_len > HIST_SLOTS / 2) return hipErrorInvalidValue;
     // one workgroup per row; more threads per row when the per-thread candidate list is short (LDS: NT*MMAX*8 B)
 #define GITMI_TOPM(MM, NTT)                                                                                         \
     hipLaunchKernelGGL((row_topm_kernel<MM, NTT>), dim3(R), dim3(NTT), 0, s, logits, ldl, V, ids, ld_ids, cur_len, plen, \
-                       beams, suppress_kind, part_val, part_idx, part_lse)
+                       beams, suppress_kind, rep_penalty, part_val, part_idx, part_lse)
     if (M <= 1) GITMI_TOPM(1, 1024);
     else if (M <= 2) GITMI_TOPM(2, 1024);
     else if (M <= 4) GITMI_TOPM(4, 1024);
@@ -731,12 +758,14 @@ hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, 
 
 hipError_t launch_sample_rows(const float* logits, int ldl, int V, int R, float temperature, int top_k, float top_p,
                               int ndraw, unsigned long long seed, int step, float* part_val, int* part_idx,
-                              float2* part_lse, float* filtered_out, hipStream_t s) {
+                              float2* part_lse, float* filtered_out, const int* ids, int ld_ids, int cur_len,
+                              float rep_penalty, hipStream_t s) {
     if (R <= 0) return hipSuccess;
+    if (rep_penalty != 0.f && rep_penalty != 1.f && ids && cur_len > HIST_SLOTS / 2) return hipErrorInvalidValue;
     if (V > SMP_NT * SMP_PER || V < 2 || ndraw < 1 || ndraw > SS_CMAX || !(temperature > 0.f)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sample_rows_kernel, dim3(R), dim3(SMP_NT), 0, s, logits, ldl, V, 1.0f / temperature, top_k, top_p, ndraw,
                        (unsigned int)(seed & 0xffffffffu), (unsigned int)(seed >> 32), step, part_val, part_idx, part_lse,
-                       filtered_out);
+                       filtered_out, ids, ld_ids, cur_len, rep_penalty);
     return hipGetLastError();
 }
 

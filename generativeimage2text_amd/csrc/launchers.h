@@ -51,6 +51,7 @@ struct VocabArgs {
     int M, N, K, cols_per_wg;
     // no-immediate-repeat rule (decoder.py:330): rows of AUTOREGRESSIVE sentences past their first search step
     const int* ids; int ld_ids, cur_len; const int* plen; int beams, suppress_kind;
+    float rep_penalty;          // GENERATOR repetition penalty over ids[row][0..cur_len) (decoder.py:1135-1144); 0 or 1: off
     float* part_val; int* part_idx; float2* part_lse;     // [M][gridDim.x][slots], [M][gridDim.x] (max, sum exp)
     float* logits_out; int ld_logits;                      // optional full logits (teacher-forced parity hook)
 };
@@ -144,10 +145,11 @@ int row_topm_slots(int M);
 // filtered_out (optional): the filtered logits [R, V] (-inf = removed) for parity checks.
 hipError_t launch_sample_rows(const float* logits, int ldl, int V, int R, float temperature, int top_k, float top_p,
                               int ndraw, unsigned long long seed, int step, float* part_val, int* part_idx,
-                              float2* part_lse, float* filtered_out, hipStream_t s);
+                              float2* part_lse, float* filtered_out, const int* ids, int ld_ids, int cur_len,
+                              float rep_penalty, hipStream_t s);
 hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, int ld_ids, int cur_len,
-                           const int* plen, int beams, int suppress_kind, int M, int R, float* part_val,
-                           int* part_idx, float2* part_lse, hipStream_t s);
+                           const int* plen, int beams, int suppress_kind, float rep_penalty, int M, int R,
+                           float* part_val, int* part_idx, float2* part_lse, hipStream_t s);
 hipError_t launch_search_step(const SearchState& st, int src, int cur_len, const StepCands& in, const EmbedArgs& em,
                               bool t_is_f32, hipStream_t s);
 hipError_t launch_search_init(const SearchState& st, hipStream_t s);

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_dgemm", "gitmi_op_dgemm_res",
     "gitmi_op_vocab_topm", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
     "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after", "gitmi_op_sample_rows",
-    "gitmi_generate_encode", "gitmi_generate_decode",
+    "gitmi_generate_encode", "gitmi_generate_decode", "gitmi_search_done_count",
 ]
 
 
@@ -43,7 +43,7 @@ class GitmiSearch(C.Structure):
     _fields_ = [("kind", C.c_int32), ("beam_size", C.c_int32), ("per_node_beam_size", C.c_int32),
                 ("max_steps", C.c_int32), ("length_penalty", C.c_double),
                 ("do_sample", C.c_int32), ("top_k", C.c_int32), ("top_p", C.c_double), ("temperature", C.c_double),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("repetition_penalty", C.c_double)]
 
 
 class GitmiProfile(C.Structure):
@@ -92,6 +92,7 @@ def load_library() -> C.CDLL:
     lib.gitmi_search_rows.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
     lib.gitmi_search_advance.argtypes = [vp, vp, vp]
     lib.gitmi_search_finish.argtypes = [vp, vp, vp, vp, vp]
+    lib.gitmi_search_done_count.argtypes = [vp, C.POINTER(C.c_int), vp]
     lib.gitmi_profile_enable.argtypes = [vp, i32]
     lib.gitmi_profile_read.argtypes = [vp, C.POINTER(GitmiProfile)]
     lib.gitmi_set_graph.argtypes = [vp, i32]
@@ -116,7 +117,7 @@ def load_library() -> C.CDLL:
     for name in EXPORTED_SYMBOLS:
         if name not in ("gitmi_last_error", "gitmi_destroy"):
             getattr(lib, name).restype = C.c_int
-    if lib.gitmi_abi_version() != 4:
+    if lib.gitmi_abi_version() != 5:
         raise GitmiError("libgitmi.so ABI version mismatch")
     _lib = lib
     return lib
@@ -256,13 +257,14 @@ class Engine:
     @staticmethod
     def make_search(kind: str, max_steps: int, beam_size: int, per_node_beam_size: int,
                     length_penalty: float = 1.0, do_sample: bool = False, top_k: int = 0, top_p: float = 1.0,
-                    temperature: float = 1.0, seed: int = 0) -> GitmiSearch:
+                    temperature: float = 1.0, seed: int = 0, repetition_penalty: float = 1.0) -> GitmiSearch:
         s = GitmiSearch()
         s.kind = SEARCH_AUTOREGRESSIVE if kind in ("greedy", "autoregressive") else SEARCH_GENERATOR
         s.beam_size, s.per_node_beam_size, s.max_steps = int(beam_size), int(per_node_beam_size), int(max_steps)
         s.length_penalty = float(length_penalty)
         s.do_sample, s.top_k, s.top_p = int(bool(do_sample)), int(top_k or 0), float(1.0 if top_p is None else top_p)
         s.temperature, s.seed = float(temperature), int(seed)
+        s.repetition_penalty = float(repetition_penalty)
         return s
 
     def generate(self, frames: Sequence[torch.Tensor], search: GitmiSearch,
@@ -378,6 +380,12 @@ class Engine:
         self._keep_logits = logits
         _ck(self.lib.gitmi_search_advance(self._h, logits.data_ptr(), _stream()))
 
+    def search_done_count(self) -> int:
+        """Sentences of the running search that need no further step (synchronises the stream)."""
+        n = C.c_int()
+        _ck(self.lib.gitmi_search_done_count(self._h, C.byref(n), _stream()))
+        return int(n.value)
+
     def search_finish(self):
         dev = f"cuda:{self.device}"
         tokens = torch.empty(self._search_B, self._search_T, device=dev, dtype=torch.int64)
@@ -454,7 +462,9 @@ def strip_stats(x: torch.Tensor) -> torch.Tensor:
 
 def to_frag(x: torch.Tensor, row_multiple: int = 16) -> torch.Tensor:
     """Row-major bf16 [R, K] -> the fragment-major operand layout of the decode chain (include/gitmi.h): 16-row x
-    32-k tiles in MFMA operand order, rows zero-padded to `row_multiple`."""
+    32-k tiles in MFMA operand order, rows zero-padded to `row_multiple`.  ACTIVATION operands of the decode-chain kernels
+    must be padded to 64 rows: the wide GEMMs and the vocabulary head load four 16-row tiles at a time whatever M is
+    (rows past M are loaded, never stored)."""
     R, K = x.shape
     Rp = (R + row_multiple - 1) // row_multiple * row_multiple
     xp = torch.zeros(Rp, K, dtype=x.dtype, device=x.device)
@@ -490,7 +500,7 @@ def op_dgemm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, colsum: Optio
     else:
         M, K = A.shape
         N = W.shape[0]
-        Af, Wf = to_frag(A), to_frag(W)
+        Af, Wf = to_frag(A, 64), to_frag(W)
     out = torch.empty((M + 15) // 16 * 16 if frag_out else M, N, device=A.device, dtype=torch.bfloat16)
     strips = 0 if stats is None else int(stats.shape[0])
     _ck(lib.gitmi_op_dgemm(Af.data_ptr(), Wf.data_ptr(), bias.data_ptr(), _ptr(colsum), _ptr(stats), strips, eps,
@@ -506,7 +516,7 @@ def op_dgemm_res(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, res_x: to
     lib = load_library()
     M, N = res_x.shape
     K = A.shape[1]
-    Af, Wf = (A, W) if packed else (to_frag(A), to_frag(W))
+    Af, Wf = (A, W) if packed else (to_frag(A, 64), to_frag(W))
     x = torch.empty(M, N, device=A.device, dtype=torch.float32)
     xb = torch.empty((M + 15) // 16 * 16, N, device=A.device, dtype=torch.bfloat16)
     st = torch.empty(N // 16, M, 2, device=A.device, dtype=torch.float32)
@@ -532,7 +542,7 @@ def op_vocab_topm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, mtop: in
     else:
         M = A.shape[0]
         Vp = (V + cols_per_wg - 1) // cols_per_wg * cols_per_wg
-        Af, Wf, bp, cp = to_frag(A), to_frag(W, cols_per_wg), _pad_vec(bias, Vp), _pad_vec(colsum, Vp)
+        Af, Wf, bp, cp = to_frag(A, 64), to_frag(W, cols_per_wg), _pad_vec(bias, Vp), _pad_vec(colsum, Vp)
     nparts = (V + cols_per_wg - 1) // cols_per_wg
     slots = 1 if mtop <= 1 else 2 if mtop <= 2 else 4 if mtop <= 4 else 8 if mtop <= 8 else 16
     pv = torch.empty(M, nparts, slots, device=A.device, dtype=torch.float32)

@@ -78,6 +78,8 @@ def _begin_and_run(decoder, start_predictions, step, search_struct, first_step_r
         if stop_when_all_eos and bool((rows[:, -1] == decoder._eos_index).all()):
             break                                                       # decoder.py:319-320
         eng.search_advance(step(rows.to(dev)))
+        if not stop_when_all_eos and eng.search_done_count() >= B:
+            break                                                       # decoder.py:1251: every sentence is done
     tokens, logprobs, info = eng.search_finish()
     seq_len, early = int(info[0]), int(info[1])
     tokens, logprobs = tokens.to(dev), logprobs.to(dev)
@@ -127,8 +129,8 @@ class GeneratorWithBeamSearch:
         self.length_penalty = length_penalty
         assert self.per_node_beam_size > 1
         assert self.length_penalty > 0, "`length_penalty` should be strictely positive."
-        if repetition_penalty != 1:
-            raise NotImplementedError("repetition_penalty (decoder.py:1135-1144) is not implemented")
+        assert repetition_penalty >= 1.0, "`repetition_penalty` should be >= 1."        # decoder.py:1080
+        self.repetition_penalty = repetition_penalty
         assert temperature > 0, "`temperature` should be strictely positive."        # decoder.py:1081
         self.temperature = temperature
         self.kind = "generator"
@@ -136,12 +138,13 @@ class GeneratorWithBeamSearch:
     def search(self, input_ids: torch.Tensor, step, num_keep_best: int = 1, do_sample: bool = False, top_k=None,
                top_p=None, num_return_sequences: int = 1, seed: int = 0, _engine_factory=None):
         """decoder.py:1083-1290 with a caller-supplied `step`: -> (decoded int64 [B, max_steps] = best hypothesis + EOS,
-        right-padded with EOS, logprobs fp32 [B, 1]).  `step` is called for every position up to max_steps (the reference
-        stops calling it once every sentence is done; the extra steps cannot change the result)."""
+        right-padded with EOS, logprobs fp32 [B, 1]).  Like the reference, the loop stops calling `step` once every
+        sentence is done (decoder.py:1251)."""
         if num_keep_best != 1 or num_return_sequences != 1:
             raise NotImplementedError("GeneratorWithBeamSearch.search: num_keep_best = num_return_sequences = 1 only")
         s = Engine.make_search("generator", self.max_steps, self.beam_size, self.per_node_beam_size, self.length_penalty,
-                               do_sample=do_sample, top_k=top_k or 0, top_p=top_p, temperature=self.temperature, seed=seed)
+                               do_sample=do_sample, top_k=top_k or 0, top_p=top_p, temperature=self.temperature, seed=seed,
+                               repetition_penalty=self.repetition_penalty)
         return _begin_and_run(self, input_ids, step, s, first_step_rows_per_sentence=False, stop_when_all_eos=False,
                               fmt="generator", engine_factory=_engine_factory)
 
@@ -248,7 +251,8 @@ class CaptioningModel:
         return Engine.make_search(d.kind, d.max_steps, d.beam_size, d.per_node_beam_size, d.length_penalty,
                                   do_sample=bool(sp.get("do_sample", False)), top_k=sp.get("top_k") or 0,
                                   top_p=sp.get("top_p"), temperature=getattr(d, "temperature", 1.0),
-                                  seed=int(sp.get("seed", 0)))
+                                  seed=int(sp.get("seed", 0)),
+                                  repetition_penalty=getattr(d, "repetition_penalty", 1.0))
 
     def forward(self, batch: Mapping[str, Union[torch.Tensor, Sequence[torch.Tensor]]],
                 search_param: Optional[dict] = None) -> Dict[str, torch.Tensor]:

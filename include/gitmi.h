@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GITMI_ABI_VERSION 4
+#define GITMI_ABI_VERSION 5
 
 /* compute precision of GEMM/attention operands (accumulation, LayerNorm statistics,
  * softmax, residual stream and logits are fp32 in both modes) */
@@ -92,6 +92,10 @@ typedef struct gitmi_search {
     double  top_p;                /* >= 1 or <= 0: off                                                 */
     double  temperature;          /* > 0; 1 = unchanged (0 is read as 1)                               */
     uint64_t seed;
+    /* GENERATOR only: repetition penalty (decoder.py:1064, 1135-1144) -- before the log-softmax (and before the sampling
+     * filter) the raw score of every token already in a row's history (start tokens included) is multiplied by it when
+     * negative and divided by it otherwise.  >= 1; 0 and 1 both mean off. */
+    double  repetition_penalty;
 } gitmi_search;
 
 /* per-phase device timings (ms) of the last profiled gitmi_generate(), see gitmi_profile_enable */
@@ -135,7 +139,8 @@ int  gitmi_clone(gitmi_engine* src, gitmi_engine** out);
  * calls starts only after the encoder of `after`'s most recently submitted call has finished (decode steps are not
  * ordered).  Chain context i (in submission order) after context i - c: at most c MFMA-bound encoders run at a time while
  * the latency-bound decode chains of the other contexts fill in beside them (measured best on MI355X: 4 contexts, c = 2;
- * bench.py --encoder-chains).  after = NULL: no dependency. */
+ * bench.py --encoder-chains).  after = NULL: no dependency (the context goes back to one hipGraph per call once no other
+ * context waits for it either).  Destroying either context of a link removes the link. */
 int  gitmi_set_encode_after(gitmi_engine* e, gitmi_engine* after);
 
 /* ---- input resolution of the following encode/generate calls (default: image_size x image_size).
@@ -220,6 +225,10 @@ int  gitmi_search_begin(gitmi_engine* e, const gitmi_search* search, int B,
 /* current rows the `step` callable would receive: int64 [R, cur_len]; returns cur_len via *t */
 int  gitmi_search_rows(gitmi_engine* e, int64_t* tokens_out, int* R, int* t, void* stream);
 int  gitmi_search_advance(gitmi_engine* e, const float* logits, void* stream);
+/* sentences that need no further step (synchronises `stream`): GENERATOR -- sentences whose BeamHypotheses are done
+ * (the reference leaves its loop at all(done), decoder.py:1251); AUTOREGRESSIVE -- sentences whose beams all ended with
+ * EOS (decoder.py:319).  Steps past *done_out == B are idempotent; a host loop uses this to stop calling `step`. */
+int  gitmi_search_done_count(gitmi_engine* e, int* done_out, void* stream);
 int  gitmi_search_finish(gitmi_engine* e, int64_t* tokens_out, float* logprob_out,
                          int32_t* info_out, void* stream);
 

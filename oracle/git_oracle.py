@@ -519,9 +519,12 @@ class _Hypotheses:
 
 def search_generator(start: Tensor, step: Callable[[Tensor], Tensor], eos: int, max_steps: int,
                      beam_size: int = 4, per_node_beam_size: int = 2,
-                     length_penalty: float = 0.6, trace: Optional[List[Tensor]] = None) -> Tuple[Tensor, Tensor]:
+                     length_penalty: float = 0.6, trace: Optional[List[Tensor]] = None,
+                     repetition_penalty: float = 1.0) -> Tuple[Tensor, Tensor]:
     """GeneratorWithBeamSearch.search, greedy-beam branch, num_keep_best=1
     (decoder.py:1083-1290).  Shipped default: beam 4, per_node 2, length_penalty 0.6.
+    repetition_penalty != 1 (decoder.py:1135-1144): the raw score of every token already in a row's history is
+    multiplied (score < 0) or divided (score >= 0) by it before the log-softmax.
 
     Returns (decoded int64 [B, max_steps] EOS-padded incl. start tokens, logprobs fp32 [B,1])."""
     B, cur = start.shape
@@ -533,7 +536,16 @@ def search_generator(start: Tensor, step: Callable[[Tensor], Tensor], eos: int, 
     beam_scores = beam_scores.reshape(-1)
     done = [False] * B
     while cur < max_steps:                                                      # :1128
-        lp = torch.log_softmax(step(ids), dim=-1)                               # :1169
+        scores = step(ids)
+        if repetition_penalty != 1.0:                                           # :1136-1144
+            scores = scores.clone()
+            for i in range(B * k):
+                for tok in set(ids[i].tolist()):
+                    if scores[i, tok] < 0:
+                        scores[i, tok] *= repetition_penalty
+                    else:
+                        scores[i, tok] /= repetition_penalty
+        lp = torch.log_softmax(scores, dim=-1)                                  # :1169
         V = lp.shape[-1]
         tot = (lp + beam_scores[:, None]).reshape(B, k * V)
         nxt_s, nxt_i = torch.topk(tot, per_node_beam_size * k, dim=1, largest=True, sorted=True)   # :1175

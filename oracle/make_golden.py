@@ -348,7 +348,11 @@ SCRIPTED = {
     "s2_prefix": ("beam", 1, 3, 60, 2, 10, 4, 2, 0.6, 10, (6,), 4.0),
     "s2_k1": ("beam", 2, 1, 60, 2, 9, 1, 2, 1.0, 11, (3,), 5.0),
     "s2_k3_pn3": ("beam", 2, 1, 60, 2, 9, 3, 3, 0.8, 12, (4,), 3.0),
+    "s2_rep_penalty": ("beam", 3, 1, 60, 2, 12, 4, 2, 0.6, 13, (6, 7), 4.0),      # repetition_penalty 1.3 (SCRIPTED_RP)
+    "s2_rep_penalty_prefix": ("beam", 1, 4, 60, 2, 12, 3, 2, 0.8, 33, (8,), 4.0),  # repetition_penalty 2.0, prefix tokens count
 }
+# repetition_penalty of GeneratorWithBeamSearch (decoder.py:1135-1144) per scripted case (default 1 = off)
+SCRIPTED_RP = {"s2_rep_penalty": 1.3, "s2_rep_penalty_prefix": 2.0}
 
 
 def run_scripted():
@@ -358,24 +362,35 @@ def run_scripted():
         g = torch.Generator().manual_seed(100 + seed)
         start = torch.randint(3, V, (1 if P > 1 else B, P), generator=g)
         step = scripted_step_factory(seed, V, eos, at, boost)
+        ref_calls = []                          # row lengths the REFERENCE calls `step` on (decoder.search host-loop parity)
+
+        def counted(rows, _step=step, _calls=ref_calls):
+            _calls.append(int(rows.shape[1]))
+            return _step(rows)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             if kind == "greedy":
                 ref_dec = D.AutoRegressiveBeamSearch(eos_index=eos, max_steps=T, beam_size=k,
                                                      per_node_beam_size=pn, fix_missing_prefix=True)
-                rp, rl = ref_dec.search(start, step)
+                rp, rl = ref_dec.search(start, counted)
                 op, ol = O.search_autoregressive(start, step, eos, T, k, pn)
             else:
+                rpen = SCRIPTED_RP.get(name, 1.0)
                 ref_dec = D.GeneratorWithBeamSearch(eos_index=eos, max_steps=T, beam_size=k,
-                                                    per_node_beam_size=pn, length_penalty=lpn)
-                rp, rl = ref_dec.search(start, step)
-                op, ol = O.search_generator(start, step, eos, T, k, pn, lpn)
+                                                    per_node_beam_size=pn, length_penalty=lpn, repetition_penalty=rpen)
+                rp, rl = ref_dec.search(start, counted)
+                op, ol = O.search_generator(start, step, eos, T, k, pn, lpn, repetition_penalty=rpen)
+                if rpen != 1.0:      # the case must actually exercise the penalty
+                    np_, _ = D.GeneratorWithBeamSearch(eos_index=eos, max_steps=T, beam_size=k, per_node_beam_size=pn,
+                                                       length_penalty=lpn).search(start, step)
+                    assert not torch.equal(np_, rp), (name, "repetition_penalty changes nothing in this case")
         assert rp.shape == op.shape and torch.equal(rp, op), (name, rp, op)
         assert rl.shape == ol.shape and (rl - ol).abs().max().item() < 1e-5, (name, rl, ol)
         print(f"[scripted {name}] OK shape {tuple(rp.shape)} row0 {rp[0].tolist()} lp {rl.flatten()[:2].tolist()}")
         out[name + ".start"] = start.numpy()
         out[name + ".pred"] = rp.numpy()
         out[name + ".logprob"] = rl.numpy()
+        out[name + ".step_calls"] = np.array(ref_calls, dtype=np.int64)
     np.savez_compressed(os.path.join(GOLD, "scripted_search.npz"), **out)
 
 

@@ -195,7 +195,8 @@ def test_device_search_scripted(name):
     cfg = dataclasses.replace(O.CONFIGS["TINY"], eos=eos, vocab=1000)
     eng = Engine(cfg, precision="f32", max_batch=B, max_beams=k, max_frames=1, max_text_len=T)
     eng.load_state_dict(O.make_weights(cfg, seed=1))
-    s = Engine.make_search("greedy" if kind == "greedy" else "beam", T, k, pn, lpn if lpn > 0 else 1.0)
+    s = Engine.make_search("greedy" if kind == "greedy" else "beam", T, k, pn, lpn if lpn > 0 else 1.0,
+                           repetition_penalty=MG.SCRIPTED_RP.get(name, 1.0))       # decoder.py:1135-1144
     eng.search_begin(s, start, V)
     for _ in range(T - P):
         rows = eng.search_rows().cpu()
@@ -213,6 +214,8 @@ def test_device_search_scripted(name):
     assert got_p.shape == exp_p.shape, (got_p.shape, exp_p.shape)
     assert np.array_equal(got_p.cpu().numpy(), exp_p), (got_p, exp_p)
     assert np.allclose(got_l.cpu().numpy(), exp_l, atol=1e-4), (got_l, exp_l)
+    # ... and `step` was called on exactly the row lengths the reference called it on (golden: counted on the reference)
+    assert calls == gold[name + ".step_calls"].tolist(), (calls, gold[name + ".step_calls"].tolist())
     eng.close()
 
 
@@ -661,8 +664,6 @@ def test_generate_as_two_submissions_equals_one_call(precision):
     eng.close()
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("GITMI_PENDING_TESTS"),
-                    reason="written after the round's GPU budget was spent: set GITMI_PENDING_TESTS=1 to run; enable once verified")
 @pytest.mark.parametrize("name", sorted(MG.SCRIPTED))
 def test_search_method_scripted(name):
     """decoder.search(start_predictions, step) of the two mirror classes (the reference's search seam as a method, over
@@ -675,9 +676,33 @@ def test_search_method_scripted(name):
     if kind == "greedy":
         dec = AutoRegressiveBeamSearch(eos_index=eos, max_steps=T, beam_size=k, per_node_beam_size=pn, fix_missing_prefix=True)
     else:
-        dec = GeneratorWithBeamSearch(eos_index=eos, max_steps=T, beam_size=k, per_node_beam_size=pn, length_penalty=lpn)
-    got_p, got_l = dec.search(start.cuda(), lambda rows: step(rows.cpu()).cuda())
+        dec = GeneratorWithBeamSearch(eos_index=eos, max_steps=T, beam_size=k, per_node_beam_size=pn, length_penalty=lpn,
+                                      repetition_penalty=MG.SCRIPTED_RP.get(name, 1.0))
+    calls = []
+
+    def counted_step(rows):
+        calls.append(int(rows.shape[1]))
+        return step(rows.cpu()).cuda()
+    got_p, got_l = dec.search(start.cuda(), counted_step)
     exp_p, exp_l = gold[name + ".pred"], gold[name + ".logprob"]
     assert got_p.shape == exp_p.shape, (got_p.shape, exp_p.shape)
     assert np.array_equal(got_p.cpu().numpy(), exp_p), (got_p, exp_p)
     assert np.allclose(got_l.cpu().numpy(), exp_l, atol=1e-4), (got_l, exp_l)
+    # the reference calls `step` exactly as often (counted on the reference class itself)
+    D = MG.import_reference()[1] if hasattr(MG, "import_reference") and __import__("os").path.isdir("/root/reference") else None
+    if D is not None:
+        ref_calls = []
+
+        def ref_step(rows):
+            ref_calls.append(int(rows.shape[1]))
+            return step(rows)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if kind == "greedy":
+                D.AutoRegressiveBeamSearch(eos_index=eos, max_steps=T, beam_size=k, per_node_beam_size=pn,
+                                           fix_missing_prefix=True).search(start, ref_step)
+            else:
+                D.GeneratorWithBeamSearch(eos_index=eos, max_steps=T, beam_size=k, per_node_beam_size=pn, length_penalty=lpn,
+                                          repetition_penalty=MG.SCRIPTED_RP.get(name, 1.0)).search(start, ref_step)
+        assert calls == ref_calls, (calls, ref_calls)

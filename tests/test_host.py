@@ -26,12 +26,12 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(engine.EXPORTED_SYMBOLS) == declared
-    assert lib.gitmi_abi_version() == 4
+    assert lib.gitmi_abi_version() == 5
 
 
 def test_struct_layouts_match_header():
     assert engine.C.sizeof(engine.GitmiConfig) == 21 * 4
-    assert engine.C.sizeof(engine.GitmiSearch) == 56          # 4 x int32, double, 2 x int32, 2 x double, uint64
+    assert engine.C.sizeof(engine.GitmiSearch) == 64          # 4 x int32, double, 2 x int32, 2 x double, uint64, double
     assert engine.GitmiSearch.length_penalty.offset == 16 and engine.GitmiSearch.top_p.offset == 32
     assert engine.GitmiSearch.seed.offset == 48
     import re, os
@@ -525,6 +525,12 @@ class _FakeSearchContext:
         if self.seq.shape[1] == self.P + 1 and self.k == 1 and bool((nxt == self.eos).all()):
             self.early = 1
 
+    def search_done_count(self):
+        # stand-in rule: a sentence is done once its row ends with EOS
+        if self.seq.shape[1] <= self.P:
+            return 0
+        return int((self.seq[:, -1] == self.eos).sum())
+
     def search_finish(self):
         t = self.seq.shape[1]
         tokens = torch.full((self.B, self.T), self.eos, dtype=torch.int64)
@@ -594,6 +600,12 @@ def test_search_methods_host_loop(monkeypatch):
     decoded, lps = gen.search(torch.tensor([[5, 9, 4]]), step_never_eos, _engine_factory=factory)
     assert seen == [(4, t) for t in range(3, 6)]
     assert decoded.shape == (1, 6) and lps.shape == (1, 1)
+    # ... and no further `step` calls once the search reports every sentence done (decoder.py:1251)
+    model._SEARCH_ENGINES.clear()
+    seen.clear()
+    gen9 = model.GeneratorWithBeamSearch(eos_index=eos, max_steps=9, beam_size=4, per_node_beam_size=2, length_penalty=0.6)
+    decoded, lps = gen9.search(torch.tensor([[5], [6]]), step_eos_at_4, _engine_factory=factory)
+    assert max(t for _, t in seen) == 3 and decoded.shape == (2, 9)
     with pytest.raises(NotImplementedError):
         gen.search(torch.tensor([[5]]), step_never_eos, num_keep_best=2, _engine_factory=factory)
     with pytest.raises(NotImplementedError):

@@ -47,7 +47,7 @@ def graph_timeit(fn, n=100):
 gen = torch.Generator().manual_seed(0)
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 for name, (N, K, res) in {"qkv": (2304, 768, False), "ffn1": (3072, 768, False), "out": (768, 768, True), "ffn2": (768, 3072, True)}.items():
-    A = E.to_frag(torch.randn(R, K, generator=gen).bfloat16().cuda())
+    A = E.to_frag(torch.randn(R, K, generator=gen).bfloat16().cuda(), 64)
     W = E.to_frag((torch.randn(N, K, generator=gen) * K ** -0.5).bfloat16().cuda())
     bias = torch.randn(N, generator=gen).cuda()
     x = torch.randn(R, K if not res else N, generator=gen).cuda()
@@ -72,7 +72,7 @@ xx = torch.randn(64, 768).cuda(); g1 = torch.ones(768).cuda(); b1 = torch.zeros(
 print("layernorm64 %.2f" % graph_timeit(lambda: E.op_layernorm(xx, g1, b1, 1e-5)))
 # vocabulary head
 V, K = 30522, 768
-A = E.to_frag(torch.randn(R, K, generator=gen).bfloat16().cuda())
+A = E.to_frag(torch.randn(R, K, generator=gen).bfloat16().cuda(), 64)
 W = E.to_frag((torch.randn(V, K, generator=gen) * K ** -0.5).bfloat16().cuda(), 128)
 Vp = W.shape[0]
 bias = torch.zeros(Vp).cuda(); bias[:V] = torch.randn(V, generator=gen).cuda()

@@ -29,7 +29,7 @@ def chain_time(build, n):
 
 for name, (N, K) in {"qkv": (2304, 768), "ffn1": (3072, 768)}.items():
     S = 96
-    A = E.to_frag(torch.randn(R, K, generator=gen).bfloat16().cuda())
+    A = E.to_frag(torch.randn(R, K, generator=gen).bfloat16().cuda(), 64)
     Ws = [E.to_frag((torch.randn(N, K, generator=gen) * K ** -0.5).bfloat16().cuda()) for _ in range(S)]
     Us = [torch.randn_like(Ws[0].float()).bfloat16() for _ in range(S)]
     bias = torch.randn(N, generator=gen).cuda()
