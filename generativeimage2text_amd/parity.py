@@ -10,18 +10,55 @@ top-2 log-prob after the no-repeat rule, decoder.py:330-366; beam: the top 2k+1 
 """
 from __future__ import annotations
 
-from typing import Dict
+from typing import Dict, Optional
 
 import numpy as np
 
+# ---- fixed acceptance constants of the bf16 engine mode ------------------------------------------------------------
+# None of these is derived from the engine under test (round-2 review: a threshold of "4 x the measured error" widens its
+# own acceptance band when a kernel regresses).  They were set ONCE from measurements on MI355X (profiles/r03_*parity*)
+# with about 2x head-room, per model geometry:
+#   thr        a row may leave the reference's ids only at a search decision whose fp32 margin is below thr
+#   lerr_frac  bound on the teacher-forced logit error, as a fraction of the logit span
+#   ferr       bound on the visual-feature error (unit-variance LayerNorm outputs)
+# GIT_BASE: measured logit error 0.011 on a span of 11.9 (0.94e-3 x span), every divergence at a margin <= 0.007.
+BF16_BOUNDS = {
+    "TINY":            {"thr": 0.06, "lerr_frac": 4.0e-3, "ferr": 0.05},
+    "TINY_VIDEO":      {"thr": 0.06, "lerr_frac": 4.0e-3, "ferr": 0.05},
+    "TINY_L":          {"thr": 0.06, "lerr_frac": 4.0e-3, "ferr": 0.05},
+    "GIT_BASE":        {"thr": 0.05, "lerr_frac": 2.5e-3, "ferr": 0.05},
+    "GIT_BASE_VATEX":  {"thr": 0.05, "lerr_frac": 2.5e-3, "ferr": 0.05},
+    "GIT_BASE_VQAv2":  {"thr": 0.05, "lerr_frac": 2.5e-3, "ferr": 0.05},
+    "GIT_LARGE":       {"thr": 0.05, "lerr_frac": 2.5e-3, "ferr": 0.05},
+}
+# floors on rows whose ids equal the reference's token for token, per full-batch golden (measured in round 2:
+# 50-55 / 64, 55 / 64 beam, 27 / 32, 14 / 16); a kernel regression that loses rows fails here even when every lost row
+# has a near-tie somewhere in its 19 steps
+IDENTICAL_FLOORS = {
+    "full_bench_b64_greedy": 48, "full_base_b64_greedy": 48, "full_base_b64_beam4": 52,
+    "full_large_b32_greedy": 25, "full_vatex_b16_greedy": 13,
+}
+
+
+def bf16_bounds(config_name: str) -> Dict[str, float]:
+    """Constants for a model geometry; names that extend a known one (GIT_LARGE_COCO, vqa_small ...) fall back to
+    their family."""
+    if config_name in BF16_BOUNDS:
+        return BF16_BOUNDS[config_name]
+    for key in ("GIT_LARGE", "GIT_BASE_VATEX", "GIT_BASE_VQAv2", "GIT_BASE", "TINY_VIDEO", "TINY_L", "TINY"):
+        if config_name.startswith(key):
+            return BF16_BOUNDS[key]
+    return BF16_BOUNDS["GIT_BASE"]
+
 
 def ids_parity(got: np.ndarray, ref: np.ndarray, step_margin: np.ndarray, thr: float, chained: bool,
-               first_decision_pos: int = 1) -> Dict[str, float]:
+               first_decision_pos: int = 1, min_identical: Optional[int] = None) -> Dict[str, float]:
     """got / ref: int [B, L*] id matrices in the reference's return convention.
     chained=False (greedy, one beam): decision s wrote position first_decision_pos + s; a row must equal the
         reference up to the first decision whose margin is below thr.
     chained=True (beam search): the decisions of an image are coupled through beam re-ordering, so a row may differ
         only if SOME decision margin of its image is below thr.
+    min_identical: floor on the rows that must equal the reference token for token (IDENTICAL_FLOORS).
     Raises AssertionError on a violation; returns the counts."""
     B = ref.shape[0]
     identical, safe, worst = 0, 0, 0.0
@@ -46,5 +83,7 @@ def ids_parity(got: np.ndarray, ref: np.ndarray, step_margin: np.ndarray, thr: f
                                     f"{m[s_idx]:.4f} >= {thr:.4f}")
             worst = max(worst, float(m[s_idx]))
     assert identical >= safe
+    if min_identical is not None:
+        assert identical >= min_identical, f"only {identical} of {B} rows equal the reference ids (floor {min_identical})"
     return {"rows": int(B), "identical": int(identical), "safe_rows": int(safe),
             "first_divergence_margin_max": round(worst, 5), "threshold": round(float(thr), 5)}

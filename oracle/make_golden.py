@@ -200,6 +200,7 @@ FULL_CASES = {
     "full_base_b64_beam4": ("GIT_BASE", dict(seed=1241, tie_output=False, successor=4.0, eos_bias=10.5), 64, 1, O.BEAM4),   # cfg3
     "full_large_b32_greedy": ("GIT_LARGE", ("bench", 1242, -5.0), 32, 1, O.GREEDY),                          # cfg4 per GPU
     "full_vatex_b16_greedy": ("GIT_BASE_VATEX", ("bench", 1243, -5.0), 16, 6, O.GREEDY),                     # cfg5
+    "full_bench_b64_beam4": ("GIT_BASE", ("bench", 1234, -5.0), 64, 1, O.BEAM4),                             # cfg3 exactly as `bench.py --search beam` runs it
 }
 
 

@@ -111,6 +111,74 @@ def test_two_rank_bench_gather(tmp_path):
     assert (tmp_path / "ok").exists()
 
 
+class _StandInEngine:
+    """What bench.main needs from an engine context: generate() returning (tokens [B, T], logprobs [B], info [4])."""
+
+    def __init__(self, rank, batch, T):
+        self.rank, self.batch, self.T = rank, batch, T
+        self.calls = 0
+
+    def clone(self):
+        return _StandInEngine(self.rank, self.batch, self.T)
+
+    def set_encode_after(self, other):
+        pass
+
+    def set_graph(self, on):
+        pass
+
+    def generate(self, frames, search, sync=True):
+        self.calls += 1
+        toks = torch.full((self.batch, self.T), 1000 + self.rank, dtype=torch.int64)
+        return toks, torch.full((self.batch,), -float(self.rank)), torch.tensor([self.T, 0, self.T - 1, 0], dtype=torch.int32)
+
+
+def _bench_main_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import bench
+    gathered = []
+    real_gather = bench.gather_results
+
+    def spy(tokens, logprobs):
+        out = real_gather(tokens, logprobs)
+        gathered.append(out)
+        return out
+    bench.gather_results = spy
+    res = bench.main(["--gpus", str(world), "--steps", "4", "--warmup", "1", "--batch", "3", "--contexts", "2",
+                      "--no-cpu-baseline"],
+                     engine_factory=lambda args, r: (_StandInEngine(r, args.batch, args.max_steps), [torch.zeros(1)]))
+    if rank == 0:
+        assert res["n_gpus"] == world and res["config"]["global_batch"] == world * 3 and res["config"]["parallelism"] == "dp2"
+        assert res["value"] > 0 and res["steps"] == 4
+        t, l = gathered[-1]                                   # rank 0 received the rows of BOTH ranks, in rank order
+        assert t.shape == (world * 3, 20) and t[:3].eq(1000).all() and t[3:].eq(1001).all() and l.tolist() == [0.0] * 3 + [-1.0] * 3
+        open(os.path.join(tmpdir, "ok"), "w").write(json.dumps(res))
+    else:
+        assert res is None and gathered[-1] == (None, None)
+
+
+def test_two_rank_bench_main_with_standin_engine(tmp_path):
+    """bench.main under a 2-rank launcher environment (gloo, stand-in engine): every rank runs, rank 0 prints ONE line
+    with n_gpus == --gpus == WORLD_SIZE, the gather delivers every rank's rows to rank 0."""
+    mp.spawn(_bench_main_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert json.loads((tmp_path / "ok").read_text())["n_gpus"] == 2
+
+
+def test_bench_refuses_gpu_count_mismatch(tmp_path):
+    """`python bench.py --gpus 2` must not print a 1-GPU line: with a launcher environment that disagrees it exits, and
+    without one it starts the ranks itself -- which fails loudly here because fewer than 2 GPUs are visible."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout) and '"metric"' not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout) and '"metric"' not in r.stdout
+
+
 def test_json_dump_is_the_reference_format():
     from generativeimage2text_amd import inference
     assert inference.json_dump({"question_id": 7, "answer": "a b"}) == '{"answer":"a b","question_id":7}'

@@ -4,12 +4,15 @@ were generated from the real reference (oracle/make_golden.py).
 Tolerances (stated per north_star):
   f32 engine mode  : tokens bit-identical to the reference; features / logits / log-probs |err| <= 1e-4
                      (measured ~3e-6: fp32 summation order only)
-  bf16 engine mode : features <= 0.05 abs on unit-variance LayerNorm outputs (measured ~0.02), teacher-forced logits
-                     within 8e-3 of the logit range (measured ~3e-3; bf16 carries 2^-9 per operand through 18 layers,
-                     DESIGN.md "parity budget"), teacher-forced argmax identical wherever the reference's top-1/top-2
-                     margin exceeds 4x the measured error, and END-TO-END ids compared on EVERY row: a row may leave
-                     the reference's ids only at a step whose fp32 decision margin (golden `step_margin`) is below
-                     4x the measured bf16 logit error -- a genuine near-tie; rows without such a step must be identical.
+  bf16 engine mode : FIXED constants per model geometry (generativeimage2text_amd.parity.BF16_BOUNDS, set once from
+                     measurements with ~2x head-room, never from the run under test): visual features <= ferr abs on
+                     unit-variance LayerNorm outputs, teacher-forced logits within lerr_frac of the logit span,
+                     teacher-forced argmax identical wherever the reference's top-1/top-2 margin exceeds thr, and
+                     END-TO-END ids compared on EVERY row: a row may leave the reference's ids only at a step whose fp32
+                     decision margin (golden `step_margin`) is below thr -- a genuine near-tie; rows without such a step
+                     must be identical; the full-batch goldens additionally carry a FLOOR on identical rows
+                     (parity.IDENTICAL_FLOORS).  Every case appends its measured figures to
+                     gpurun_out/parity_measured.jsonl (copied to profiles/ per round).
 """
 import numpy as np
 import pytest
@@ -27,6 +30,19 @@ BIG_CASES = ["base_greedy", "base_greedy_eos", "base_beam4", "base_prefix_beam4"
              "vqa_base_480x640"]
 FULL_CASES = ["full_bench_b64_greedy", "full_base_b64_greedy", "full_base_b64_beam4", "full_large_b32_greedy",
               "full_vatex_b16_greedy"]
+
+
+def record_measurement(**kw):
+    """One JSON line per bf16 comparison (what the fixed bounds of parity.BF16_BOUNDS are set from)."""
+    import json, os
+    from conftest import ROOT
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_measured.jsonl"), "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
 
 
 def make_engine(cfg, w, precision, B, search, frames=1, T=None, max_image_hw=None):
@@ -86,35 +102,41 @@ def check_f32(name):
 
 
 def check_bf16(name):
+    from generativeimage2text_amd.parity import bf16_bounds, ids_parity
     g, cfg, feats, logits, preds, lps = run_case(name, "bf16")
+    bnd = bf16_bounds(cfg.name)
     big = cfg.vocab > 5000
     fs = feats[:, ::7, ::5] if big else feats
-    ferr = np.abs(fs.numpy() - g["feat_sample"]).max()
-    assert ferr < 0.05, ferr
+    ferr = float(np.abs(fs.numpy() - g["feat_sample"]).max())
     ls = logits[:, ::3] if big else logits
     ref = g["tf_logits"]
-    lerr = np.abs(ls.numpy() - ref).max()
-    span = ref.max() - ref.min()
-    assert lerr < 8e-3 * span, (lerr, span)
-    # token identity wherever the reference's own margin is resolvable at bf16 precision
-    am = logits.argmax(-1).numpy()
-    for r in range(am.shape[0]):
-        if g["tf_top2_margin"][r] > 4 * lerr:
-            assert am[r] == g["tf_argmax"][r]
-    # end-to-end ids, every row
-    ref_p = g["predictions"]
-    kind = eval(str(g["search"]), {"__builtins__": {}}, {})[0]
-    if ref_p.shape[1] <= 1 and kind == "greedy":                        # first-step early return (decoder.py:279-291)
-        if preds.shape == ref_p.shape:
-            assert np.array_equal(preds.numpy(), ref_p)
-        return
-    from generativeimage2text_amd.parity import ids_parity
-    kind, _, k, _, _ = eval(str(g["search"]), {"__builtins__": {}}, {})
-    chained = not (kind == "greedy" and k == 1)
-    # golden predictions of prefixed cases have the prefix stripped (decoder.py:1004-1006): decision s wrote position s
-    stats = ids_parity(preds.numpy(), ref_p, g["step_margin"], 4 * lerr * (2 if chained else 1), chained,
-                       first_decision_pos=0 if g["prefix"].size else 1)
-    print(name, stats)
+    lerr = float(np.abs(ls.numpy() - ref).max())
+    span = float(ref.max() - ref.min())
+    rec = {"case": name, "config": cfg.name, "ferr": round(ferr, 5), "lerr": round(lerr, 5), "span": round(span, 3),
+           "lerr_frac": round(lerr / span, 6)}
+    try:
+        assert ferr < bnd["ferr"], ferr
+        assert lerr < bnd["lerr_frac"] * span, (lerr, span)
+        # token identity wherever the reference's own margin is resolvable at bf16 precision
+        am = logits.argmax(-1).numpy()
+        for r in range(am.shape[0]):
+            if g["tf_top2_margin"][r] > bnd["thr"]:
+                assert am[r] == g["tf_argmax"][r]
+        # end-to-end ids, every row
+        ref_p = g["predictions"]
+        kind, _, k, _, _ = eval(str(g["search"]), {"__builtins__": {}}, {})
+        if ref_p.shape[1] <= 1 and kind == "greedy":                        # first-step early return (decoder.py:279-291)
+            if preds.shape == ref_p.shape:
+                assert np.array_equal(preds.numpy(), ref_p)
+            return
+        chained = not (kind == "greedy" and k == 1)
+        # golden predictions of prefixed cases have the prefix stripped (decoder.py:1004-1006): decision s wrote position s
+        stats = ids_parity(preds.numpy(), ref_p, g["step_margin"], bnd["thr"] * (2 if chained else 1), chained,
+                           first_decision_pos=0 if g["prefix"].size else 1)
+        rec.update(stats)
+        print(name, stats)
+    finally:
+        record_measurement(**rec)
 
 
 @pytest.mark.parametrize("name", TINY_CASES)
@@ -175,11 +197,19 @@ def test_full_batch_ids_against_reference(name):
             assert preds.shape == ref_p.shape and np.array_equal(preds.numpy(), ref_p)
             assert np.allclose(lps.numpy(), ref_l, atol=1e-4)
         else:
+            from generativeimage2text_amd.parity import IDENTICAL_FLOORS, bf16_bounds
+            bnd = bf16_bounds(cfg.name)
             span = float(g["tf_logits"].max() - g["tf_logits"].min())
-            assert lerr < 8e-3 * span, (lerr, span)
-            stats = ids_parity(preds.numpy(), ref_p, g["step_margin"], 4 * lerr * (2 if chained else 1), chained)
-            print(name, prec, "logit err %.4f of span %.2f" % (lerr, span), stats)
-            assert stats["identical"] >= stats["safe_rows"]
+            rec = {"case": name, "config": cfg.name, "lerr": round(lerr, 5), "span": round(span, 3),
+                   "lerr_frac": round(lerr / span, 6)}
+            try:
+                assert lerr < bnd["lerr_frac"] * span, (lerr, span)
+                stats = ids_parity(preds.numpy(), ref_p, g["step_margin"], bnd["thr"] * (2 if chained else 1), chained,
+                                   min_identical=IDENTICAL_FLOORS[name])
+                rec.update(stats)
+                print(name, prec, "logit err %.4f of span %.2f" % (lerr, span), stats)
+            finally:
+                record_measurement(**rec)
 
 
 # ---- the search seam with scripted logits (no model): device search == reference search ----------
@@ -445,17 +475,28 @@ def test_long_step_budget_polling_path(kind):
     w = O.make_weights(cfg, seed=77, tie_output=False, eos_bias=2.2)
     frames = O.make_images(cfg, 5, 1, seed=8)
     search = O.SearchConfig("greedy", 60, 1, 1) if kind == "greedy" else O.SearchConfig("beam", 60, 4, 2, 0.6)
+    trace = []
     with torch.no_grad():
-        ref = O.caption(cfg, w, frames, search, cached=True)
+        ref = O.caption(cfg, w, frames, search, cached=True, trace=trace)
+    margins = torch.stack(trace, dim=1).numpy()                       # [B, decisions] fp32 decision margins of the oracle
     for prec in ("f32", "bf16"):
         eng = make_engine(cfg, w, prec, 5, search)
         tokens, logprobs, info = eng.generate([f.cuda() for f in frames], search_struct(search))
         preds, lps = format_like_reference(search, tokens, logprobs, info, None)
+        assert info.tolist()[2] < 59              # stopped early: fewer decode steps than the budget
         if prec == "f32":
             assert preds.shape == ref["predictions"].shape, (preds.shape, ref["predictions"].shape)
             assert torch.equal(preds, ref["predictions"])
             assert torch.allclose(lps, ref["logprobs"], atol=2e-3)
-            assert info.tolist()[2] < 59          # stopped early: fewer decode steps than the budget
+        else:
+            # bf16 (fused head, folded LayerNorms, eager polling path): a row may differ from the reference only if one of
+            # its decisions is a near-tie (fixed threshold, parity.BF16_BOUNDS); compared on EOS-padded rows
+            from generativeimage2text_amd.parity import bf16_bounds, ids_parity
+            L = max(preds.shape[1], ref["predictions"].shape[1])
+            pad = lambda x: torch.cat([x, torch.full((x.shape[0], L - x.shape[1]), cfg.eos, dtype=x.dtype)], 1).numpy()
+            stats = ids_parity(pad(preds), pad(ref["predictions"]), margins, 2 * bf16_bounds(cfg.name)["thr"], chained=True)
+            record_measurement(case="long_budget_" + kind, config=cfg.name, **stats)
+            assert torch.isfinite(lps).all()
         eng.close()
 
 
@@ -473,11 +514,13 @@ def test_ragged_prefixes_equal_per_question_reference_calls(kind):
               "ar_beam": O.SearchConfig("greedy", 18, 3, 2)}[kind]
     prefixes = [[101, 7, 44], [101], [101, 300, 2, 9, 512, 77], [101, 5], [101, 7, 44, 13, 8], [101, 640, 3, 3, 21, 90, 14, 2]]
     image_of = [0, 0, 1, 2, 2, 1]
-    want = []
+    want, min_margin = [], []
     with torch.no_grad():
         for p, im in zip(prefixes, image_of):
-            ref = O.caption(cfg, w, [frames[0][im:im + 1]], search, prefix=torch.tensor([p]), cached=True)
+            tr = []
+            ref = O.caption(cfg, w, [frames[0][im:im + 1]], search, prefix=torch.tensor([p]), cached=True, trace=tr)
             want.append((ref["predictions"][0].tolist(), float(ref["logprobs"].flatten()[0])))
+            min_margin.append(float(torch.stack(tr, 1).min()) if tr else float("inf"))
     eng = make_engine(cfg, w, "f32", 8, search)
     dev = [f.cuda() for f in frames]
     for graph in (True, False):
@@ -492,11 +535,26 @@ def test_ragged_prefixes_equal_per_question_reference_calls(kind):
                 got = tokens[q, P:].tolist()
             assert got == want[q][0], (kind, q, got, want[q][0])
             assert abs(float(logprobs[q]) - want[q][1]) < 1e-4, (kind, q)
-    # bf16 mode runs the same call (fused vocabulary head, folded LayerNorms): shapes / termination sane
+    # bf16 mode runs the same call (fused vocabulary head, folded LayerNorms): a sentence may differ from its own
+    # reference call only if one of that call's decisions is a near-tie (fixed threshold, parity.BF16_BOUNDS)
+    from generativeimage2text_amd.parity import bf16_bounds
+    thr = bf16_bounds(cfg.name)["thr"] * (1 if (search.kind == "greedy" and search.beam_size == 1) else 2)
     eb = make_engine(cfg, w, "bf16", 8, search)
     tb, lb, sb, _ = eb.generate_prefixed(dev, search_struct(search), prefixes, image_of)
+    tb, sb = tb.cpu(), sb.cpu()
+    same = 0
     for q, p in enumerate(prefixes):
         assert tb[q, :len(p)].tolist() == p
+        P, (L, early) = len(p), sb[q].tolist()
+        if search.kind == "greedy":
+            got = (tb[q, P:P + 1] if early else tb[q, :L])[P:].tolist()
+        else:
+            got = tb[q, P:].tolist()
+        same += got == want[q][0]
+        if min_margin[q] >= thr:
+            assert got == want[q][0], (kind, q, got, want[q][0], min_margin[q])
+    record_measurement(case="ragged_prefixes_" + kind, config=cfg.name, identical=same, rows=len(prefixes),
+                       min_margins=[round(m, 4) for m in min_margin])
     assert torch.isfinite(lb).all()
     eng.close()
     eb.close()
