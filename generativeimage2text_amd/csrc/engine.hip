@@ -1644,6 +1644,48 @@ extern "C" int gitmi_op_sample_rows(const float* logits, int R, int V, float tem
     return 0;
 }
 
+// ---- error attribution hooks (tools/error_attribution.py): hand the products of a stage from one context to another
+// of the SAME model in the other precision, so that a stage can be switched between bf16 and fp32 on its own.
+//   stage 1: visual features (image encoder output)        -> dst runs prefill + decode itself
+//   stage 2: + the image K/V of every decoder layer (prefill) -> dst runs only the decode steps itself
+extern "C" int gitmi_debug_import_stage(gitmi_engine* dst, gitmi_engine* src, int stage, void* stream) {
+    RCK(check_ready(dst));
+    if (!src || !src->finalized) return fail("debug_import_stage: bad source");
+    if (stage != 1 && stage != 2) return fail("debug_import_stage: stage must be 1 or 2");
+    const gitmi_config &a = dst->cfg, &b = src->cfg;
+    if (a.vit_width != b.vit_width || a.dec_hidden != b.dec_hidden || a.dec_layers != b.dec_layers || a.dec_heads != b.dec_heads)
+        return fail("debug_import_stage: the two contexts are different models");
+    if (!src->have_feats || (stage == 2 && !src->have_prefill)) return fail("debug_import_stage: the source has not run that stage");
+    if (src->cur_B > a.max_batch || src->cur_F > a.max_frames || src->N != dst->N) return fail("debug_import_stage: capacity / resolution mismatch");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t M = (size_t)src->cur_B * src->cur_Nimg;
+    HIPCK(launch_convert(src->feats, src->f32, dst->feats, dst->f32, M * a.vit_width, s));
+    dst->cur_B = src->cur_B; dst->cur_F = src->cur_F; dst->cur_Nimg = src->cur_Nimg;
+    dst->have_feats = true; dst->have_prefill = false;
+    if (stage == 2) {
+        for (int l = 0; l < a.dec_layers; ++l) {
+            HIPCK(launch_convert(src->img_kv[l], src->f32, dst->img_kv[l], dst->f32, M * 3 * a.dec_hidden, s));
+            RCK(kv_repack(dst, l, dst->cur_B, dst->cur_Nimg, s));
+        }
+        dst->have_prefill = true;
+    }
+    return 0;
+}
+// the vocabulary head of `dst` (bf16: the fused, LayerNorm-folded head) applied to the last hidden state that `src`
+// (an fp32 context) computed in its most recent gitmi_step_logits over R rows: logits_out fp32 [R, vocab] (device)
+extern "C" int gitmi_debug_head_from(gitmi_engine* dst, gitmi_engine* src, int R, float* logits_out, void* stream) {
+    RCK(check_ready(dst));
+    if (!src || !src->f32 || !logits_out) return fail("debug_head_from: the source must be an fp32 context");
+    if (dst->f32 || !dst->skinny) return fail("debug_head_from: the destination must run the bf16 decode chain");
+    const gitmi_config& c = dst->cfg;
+    if (c.dec_hidden != src->cfg.dec_hidden || c.vocab != src->cfg.vocab) return fail("debug_head_from: different models");
+    if (R < 1 || R > c.max_batch * c.max_beams) return fail("debug_head_from: R outside the capacity");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCK(launch_chain_input(src->d_y, dst->xo_b, dst->stats_o, R, c.dec_hidden, s));   // d_y: pre-LayerNorm sum of the last layer
+    StepCands cands{};
+    return decode_head_impl(dst, nullptr, c.max_text_len, 1, R, 1, 0, 1, logits_out, c.vocab, s, &cands);
+}
+
 extern "C" int gitmi_debug_set_gemm_impl(int impl) {
     set_gemm_impl(impl);
     return 0;

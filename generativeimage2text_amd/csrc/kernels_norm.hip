@@ -278,6 +278,29 @@ __global__ void convert_pad_kernel(const float* __restrict__ src, TOut* __restri
     }
 }
 
+// element-wise dtype conversion (debug / attribution hooks: tensors handed from an fp32 context to a bf16 one and back)
+template <typename TIn, typename TOut>
+__global__ void convert_any_kernel(const TIn* __restrict__ src, TOut* __restrict__ dst, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        st<TOut>(dst + i, ld<TIn>(src + i));
+}
+
+// fp32 rows x [R, d] -> what a decode-chain N = d GEMM leaves for its consumer (kernels_dgemm.hip): the bf16 copy in the
+// fragment-major operand layout and the (sum, sum of squares) partials of every 16-column strip, [d/16][R]
+__global__ void chain_input_kernel(const float* __restrict__ x, bf16_t* __restrict__ xb, float2* __restrict__ stats, int R, int d) {
+    const int strips = d >> 4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R * strips; i += gridDim.x * blockDim.x) {
+        const int r = i / strips, sp = i % strips;
+        float sum = 0.f, sq = 0.f;
+        for (int c = 0; c < 16; ++c) {
+            const float v = x[(size_t)r * d + sp * 16 + c];
+            sum += v; sq += v * v;
+            xb[frag_offset(r, sp * 16 + c, d >> 5)] = f2bf(v);
+        }
+        stats[(size_t)sp * R + r] = float2{sum, sq};
+    }
+}
+
 __global__ void copy_f32_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
                                 int rows, int cols) {
     const size_t total = (size_t)rows * cols;
@@ -414,6 +437,23 @@ hipError_t launch_convert_pad(const float* src, void* dst, bool dst_f32, size_t 
     else
         hipLaunchKernelGGL(convert_pad_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, src,
                            (bf16_t*)dst, rows, K, Kpad);
+    return hipGetLastError();
+}
+
+hipError_t launch_convert(const void* src, bool src_f32, void* dst, bool dst_f32, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const dim3 g(grid_for(n, 256)), b(256);
+    if (src_f32 && dst_f32) hipLaunchKernelGGL((convert_any_kernel<float, float>), g, b, 0, s, (const float*)src, (float*)dst, n);
+    else if (src_f32) hipLaunchKernelGGL((convert_any_kernel<float, bf16_t>), g, b, 0, s, (const float*)src, (bf16_t*)dst, n);
+    else if (dst_f32) hipLaunchKernelGGL((convert_any_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)src, (float*)dst, n);
+    else hipLaunchKernelGGL((convert_any_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain_input(const float* x, void* xb, float2* stats, int R, int d, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    if (d % 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(chain_input_kernel, dim3(grid_for((size_t)R * (d >> 4), 256)), dim3(256), 0, s, x, (bf16_t*)xb, stats, R, d);
     return hipGetLastError();
 }
 

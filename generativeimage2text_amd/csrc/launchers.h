@@ -76,6 +76,8 @@ hipError_t launch_embed_ln(const int* ids, int ld_ids, int pos, const float* wor
 hipError_t launch_frag_pack(const void* src_bf16, void* dst_bf16, int rows, int rows_out, int K, hipStream_t s);
 hipError_t launch_convert_pad(const float* src, void* dst, bool dst_f32, size_t rows, int K, int Kpad,
                               hipStream_t s);
+hipError_t launch_convert(const void* src, bool src_f32, void* dst, bool dst_f32, size_t n, hipStream_t s);
+hipError_t launch_chain_input(const float* x, void* xb_frag, float2* stats, int R, int d, hipStream_t s);
 hipError_t launch_copy_f32(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s);
 hipError_t launch_fill_i32(int* dst, int value, int n, hipStream_t s);
 

@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_op_vocab_topm", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
     "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after", "gitmi_op_sample_rows",
     "gitmi_generate_encode", "gitmi_generate_decode", "gitmi_search_done_count",
+    "gitmi_debug_import_stage", "gitmi_debug_head_from",
 ]
 
 
@@ -93,6 +94,8 @@ def load_library() -> C.CDLL:
     lib.gitmi_search_advance.argtypes = [vp, vp, vp]
     lib.gitmi_search_finish.argtypes = [vp, vp, vp, vp, vp]
     lib.gitmi_search_done_count.argtypes = [vp, C.POINTER(C.c_int), vp]
+    lib.gitmi_debug_import_stage.argtypes = [vp, vp, i32, vp]
+    lib.gitmi_debug_head_from.argtypes = [vp, vp, i32, vp, vp]
     lib.gitmi_profile_enable.argtypes = [vp, i32]
     lib.gitmi_profile_read.argtypes = [vp, C.POINTER(GitmiProfile)]
     lib.gitmi_set_graph.argtypes = [vp, i32]
@@ -379,6 +382,20 @@ class Engine:
         logits = logits.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
         self._keep_logits = logits
         _ck(self.lib.gitmi_search_advance(self._h, logits.data_ptr(), _stream()))
+
+    # -- error attribution hooks (tools/error_attribution.py) ---------------------------------------
+    def debug_import_stage(self, src: "Engine", stage: int) -> None:
+        """Take the image features (stage 1) or features + image K/V of every decoder layer (stage 2) from `src`, a
+        context of the same model in the other precision; step_logits() then continues from there."""
+        _ck(self.lib.gitmi_debug_import_stage(self._h, src._h, int(stage), _stream()))
+        self._cur_B = src._cur_B
+
+    def debug_head_from(self, src: "Engine", R: int) -> torch.Tensor:
+        """This (bf16) context's fused vocabulary head on the last hidden state of src's (fp32) latest step_logits."""
+        out = torch.empty(R, self.c.vocab, device=f"cuda:{self.device}", dtype=torch.float32)
+        _ck(self.lib.gitmi_debug_head_from(self._h, src._h, int(R), out.data_ptr(), _stream()))
+        torch.cuda.current_stream().synchronize()
+        return out
 
     def search_done_count(self) -> int:
         """Sentences of the running search that need no further step (synchronises the stream)."""

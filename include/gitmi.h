@@ -318,6 +318,14 @@ int  gitmi_op_sample_rows(const float* logits, int R, int V, float temperature, 
                           uint64_t seed, int step, float* draw_logprob, int* draw_token, float* filtered_out,
                           void* stream);
 
+/* ---- error attribution hooks (tools/error_attribution.py; not part of the serving path).  Two contexts of the SAME
+ * model in different precisions: import_stage hands the products of the image encoder (stage 1) or of encoder + prefill
+ * (stage 2: the image K/V of every decoder layer) from `src` to `dst`, converted, so that gitmi_step_logits on `dst`
+ * continues from there; head_from applies dst's (bf16, fused) vocabulary head to the last hidden state of src's (fp32)
+ * most recent gitmi_step_logits over R rows -> logits_out fp32 [R, vocab] on the device. */
+int  gitmi_debug_import_stage(gitmi_engine* dst, gitmi_engine* src, int stage, void* stream);
+int  gitmi_debug_head_from(gitmi_engine* dst, gitmi_engine* src, int R, float* logits_out, void* stream);
+
 /* kernel selection for A/B measurements: -1 auto (default), 0 first-generation GEMM only,
  * 1 force the direct-to-LDS GEMM wherever its constraints hold */
 int  gitmi_debug_set_gemm_impl(int impl);
