@@ -78,11 +78,12 @@ def _cpu_run(sample_batch: int, max_steps: int, threads: int):
             "steps": int(out["predictions"].shape[1] - 1)}
 
 
-def cpu_baseline(sample_batch: int, max_steps: int, threads: int = 0, repeats: int = 3, big_batch: int = 64):
+def cpu_baseline(sample_batch: int, max_steps: int, threads: int = 0, repeats: int = 3, big_batch: int = 0):
     """Reference algorithm on the host cores (SURVEY.md 8d protocol): the oracle (a PORT of the reference: fp32, full
     recompute per step exactly like CaptioningModel.infer as shipped), greedy, GIT_BASE; one warm-up pass, then the
-    MEDIAN of `repeats` passes at bs = sample_batch (default 8) and ONE pass at bs = big_batch (64), thread count pinned
-    and reported.  torch's CPU kernels oversubscribe badly on a 256-thread host (measured 85x slower than 16 threads), so
+    MEDIAN of `repeats` passes at bs = sample_batch (default 8: ~15 s of CPU work in all), thread count pinned and
+    reported; `--cpu-big-batch 64` adds ONE pass at bs = 64 (75 s on the GPU box's host: 0.85 captions/s,
+    profiles/r03_a_bench.json).  torch's CPU kernels oversubscribe badly on a 256-thread host (measured 85x slower than 16 threads), so
     the thread count is capped; `python bench.py --cpu-sweep` measures other counts (profiles/r02_d_cpu_sweep.json).
     /root/reference does not exist on the GPU box, so the reference modules themselves cannot be timed there:
     kind = "port"."""
@@ -275,6 +276,7 @@ def main(argv=None, engine_factory=None):
     ap.add_argument("--cpu-sample", type=int, default=8,
                     help="batch size of the CPU baseline's median-of-3 passes (one bs=64 pass is timed besides)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-big-batch", type=int, default=0, help="also time ONE CPU pass at this batch size (64: ~75 s)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--contexts", type=int, default=4,
                     help="engine contexts (shared weights) kept in flight on separate HIP streams")
@@ -572,7 +574,8 @@ def main(argv=None, engine_factory=None):
         # the ids of the timed schedule's last batch are the ids of the solo pass (same images, same weights)
         result["timed_ids_equal_solo"] = bool(torch.equal(tokens.cpu(), tokens_solo.cpu()))
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.max_steps, args.cpu_threads)
+            result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.max_steps, args.cpu_threads,
+                                                  big_batch=args.cpu_big_batch)
 
     if rank == 0:
         assert result["n_gpus"] == args.gpus

@@ -16,28 +16,47 @@ import numpy as np
 
 # ---- fixed acceptance constants of the bf16 engine mode ------------------------------------------------------------
 # None of these is derived from the engine under test (round-2 review: a threshold of "4 x the measured error" widens its
-# own acceptance band when a kernel regresses).  They were set ONCE from measurements on MI355X (profiles/r03_*parity*)
-# with about 2x head-room, per model geometry:
-#   thr        a row may leave the reference's ids only at a search decision whose fp32 margin is below thr
-#   lerr_frac  bound on the teacher-forced logit error, as a fraction of the logit span
-#   ferr       bound on the visual-feature error (unit-variance LayerNorm outputs)
-# GIT_BASE: measured logit error 0.011 on a span of 11.9 (0.94e-3 x span), every divergence at a margin <= 0.007.
+# own acceptance band when a kernel regresses).  They were set ONCE from the measurements of profiles/r03_a_parity_measured.jsonl
+# (MI355X, both residual-stream storage types):
+#   thr        a row may leave the reference's ids only at a search decision whose fp32 margin is below thr (x 2 for
+#              beam search: summed log-probs).  Largest margin at which a row actually diverged: 0.0078 (greedy), 0.027 (beam)
+#   ferr       bound on the visual-feature error (unit-variance LayerNorm outputs; measured 0.015 - 0.023)
+#   lerr_frac  bound on the teacher-forced logit error as a fraction of the logit span: 1.5 x the measured value of every
+#              golden case (LERR_FRAC; the benchmark's identity-LayerNorm weights measure 0.9e-3, the oracle's weights with
+#              perturbed LayerNorm gains / successor structure 2e-3 ... 4.9e-3); the per-geometry value is the fallback for
+#              cases without an entry
 BF16_BOUNDS = {
-    "TINY":            {"thr": 0.06, "lerr_frac": 4.0e-3, "ferr": 0.05},
-    "TINY_VIDEO":      {"thr": 0.06, "lerr_frac": 4.0e-3, "ferr": 0.05},
-    "TINY_L":          {"thr": 0.06, "lerr_frac": 4.0e-3, "ferr": 0.05},
-    "GIT_BASE":        {"thr": 0.05, "lerr_frac": 2.5e-3, "ferr": 0.05},
-    "GIT_BASE_VATEX":  {"thr": 0.05, "lerr_frac": 2.5e-3, "ferr": 0.05},
-    "GIT_BASE_VQAv2":  {"thr": 0.05, "lerr_frac": 2.5e-3, "ferr": 0.05},
-    "GIT_LARGE":       {"thr": 0.05, "lerr_frac": 2.5e-3, "ferr": 0.05},
+    "TINY":            {"thr": 0.06, "lerr_frac": 4.0e-3, "ferr": 0.04},
+    "TINY_VIDEO":      {"thr": 0.06, "lerr_frac": 4.0e-3, "ferr": 0.04},
+    "TINY_L":          {"thr": 0.06, "lerr_frac": 4.0e-3, "ferr": 0.04},
+    "GIT_BASE":        {"thr": 0.05, "lerr_frac": 7.0e-3, "ferr": 0.04},
+    "GIT_BASE_VATEX":  {"thr": 0.05, "lerr_frac": 7.0e-3, "ferr": 0.04},
+    "GIT_BASE_VQAv2":  {"thr": 0.05, "lerr_frac": 7.0e-3, "ferr": 0.04},
+    "GIT_LARGE":       {"thr": 0.05, "lerr_frac": 7.0e-3, "ferr": 0.04},
 }
-# floors on rows whose ids equal the reference's token for token, per full-batch golden (measured in round 2:
-# 50-55 / 64, 55 / 64 beam, 27 / 32, 14 / 16); a kernel regression that loses rows fails here even when every lost row
-# has a near-tie somewhere in its 19 steps
+LERR_FRAC = {
+    "tiny_greedy_early_return": 0.0039, "tiny_greedy_untied": 0.004, "tiny_greedy_long": 0.0034, "tiny_beam4": 0.0038,
+    "tiny_beam4_noeos": 0.0037, "tiny_beam4_early_done": 0.0027, "tiny_beam3_pn3": 0.0035, "tiny_ar_beam3": 0.0031,
+    "tiny_prefix_greedy": 0.0041, "tiny_prefix_beam4": 0.0063, "tiny_video_greedy": 0.0031, "tiny_video_beam4": 0.0025,
+    "tiny_image_two_frames": 0.0036, "tinyl_greedy": 0.0038, "tiny_varres_up": 0.004, "tiny_varres_down_beam4": 0.0035,
+    "tiny_varres_prefix": 0.003, "tinyl_varres": 0.0041, "base_greedy": 0.0052, "base_greedy_eos": 0.0057,
+    "base_beam4": 0.0053, "base_prefix_beam4": 0.0074, "large_greedy": 0.0071, "vatex_greedy": 0.007,
+    "vqa_base_480x640": 0.0063, "full_bench_b64_greedy": 0.0015, "full_bench_b64_beam4": 0.0015,
+    "full_base_b64_greedy": 0.0072, "full_base_b64_beam4": 0.0053, "full_large_b32_greedy": 0.0016,
+    "full_vatex_b16_greedy": 0.0017,
+}
+# floors on rows whose ids equal the reference's token for token, per full-batch golden (measured: 50 / 64, 27 / 32,
+# 14 / 16; round 2: 55 / 64 beam); a kernel regression that loses rows fails here even when every lost row has a near-tie
+# somewhere in its 19 steps
 IDENTICAL_FLOORS = {
-    "full_bench_b64_greedy": 48, "full_base_b64_greedy": 48, "full_base_b64_beam4": 52,
+    "full_bench_b64_greedy": 48, "full_base_b64_greedy": 48, "full_base_b64_beam4": 52, "full_bench_b64_beam4": 48,
     "full_large_b32_greedy": 25, "full_vatex_b16_greedy": 13,
 }
+
+
+def lerr_frac_bound(case: str, config_name: str) -> float:
+    """Logit-error bound (fraction of the logit span) of a golden case."""
+    return LERR_FRAC.get(case, bf16_bounds(config_name)["lerr_frac"])
 
 
 def bf16_bounds(config_name: str) -> Dict[str, float]:

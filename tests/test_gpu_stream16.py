@@ -1,7 +1,8 @@
-"""GPU: the fp16 residual-stream option of the bf16 engine mode (GITMI_STREAM_F16=1: the ViT / prefill residual streams
-stored in fp16 instead of fp32 -- half the bytes of their read-modify-writes).  Same bounds as the fp32-stream bf16 mode
-(tests/test_gpu_parity.py::check_bf16): tools/residual_precision_study.py predicts +0.002 on the 0.023 max feature error.
-The unit checks compare the fp16-stream GEMM / LayerNorm paths with the fp32-stream ones directly."""
+"""GPU: the two storage types of the residual streams in bf16 engine mode.  fp16 is the default (the ViT / prefill
+residual streams stored in fp16 instead of fp32 -- half the bytes of their read-modify-writes; +3.6 % captions/s, same
+ids, profiles/r03_a_bench_f16_*.json); GITMI_STREAM_F16=0 keeps them in fp32.  Both must meet the same fixed bounds
+(tests/test_gpu_parity.py::check_bf16): this file runs the parity cases with the NON-default fp32 stream and compares the
+two directly."""
 import os
 
 import numpy as np
@@ -12,8 +13,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture()
-def stream16(monkeypatch):
-    monkeypatch.setenv("GITMI_STREAM_F16", "1")
+def stream32(monkeypatch):
+    monkeypatch.setenv("GITMI_STREAM_F16", "0")
     yield
     monkeypatch.delenv("GITMI_STREAM_F16", raising=False)
 
@@ -23,12 +24,12 @@ CASES = ["tiny_greedy_long", "tiny_beam4", "tiny_video_beam4", "tinyl_greedy", "
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_bf16_with_fp16_stream_within_tolerance(name, stream16):
+def test_bf16_with_fp32_stream_within_tolerance(name, stream32):
     from test_gpu_parity import check_bf16
     check_bf16(name)
 
 
-def test_fp16_stream_features_close_to_fp32_stream(stream16, monkeypatch):
+def test_fp16_stream_features_close_to_fp32_stream(monkeypatch):
     """Same weights and images through both stream precisions: the features differ by far less than the bf16 budget
     (prediction: ~0.003 max on unit-variance outputs), and the f32 engine mode ignores the switch."""
     from oracle import git_oracle as O
@@ -43,9 +44,11 @@ def test_fp16_stream_features_close_to_fp32_stream(stream16, monkeypatch):
         out = eng.encode(frames).cpu()
         eng.close()
         return out
+    monkeypatch.setenv("GITMI_STREAM_F16", "1")
     f16s, f32mode_on = feats("bf16"), feats("f32")
-    monkeypatch.delenv("GITMI_STREAM_F16")
+    monkeypatch.setenv("GITMI_STREAM_F16", "0")
     f32s, f32mode_off = feats("bf16"), feats("f32")
+    monkeypatch.delenv("GITMI_STREAM_F16")
     assert torch.equal(f32mode_on, f32mode_off)
     d = (f16s - f32s).abs().max().item()
     assert 0 < d < 0.02, d
