@@ -65,10 +65,11 @@ template <typename TOut> __device__ __forceinline__ uint32_t pack2_16(float lo, 
     else return pack2bf(lo, hi);
 }
 
-// 16 bytes from global memory by inline asm: invisible to hipcc's vmcnt bookkeeping (see the header)
-__device__ __forceinline__ f32x4_t asm_load_f32x4(const float* p) {
+// 16 bytes from global memory by inline asm (invisible to hipcc's vmcnt bookkeeping, see the header): SGPR base + 32-bit
+// per-lane byte offset + immediate, so that no 64-bit per-lane pointer has to live across the K loop
+template <int IMM> __device__ __forceinline__ f32x4_t asm_load_f32x4(const float* base, uint32_t voff) {
     f32x4_t v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(base), "n"(IMM) : "memory");
     return v;
 }
 
@@ -220,13 +221,19 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     f32x4_t bias4[2][2];                               // [qn][j] bias of the COMPUTE cursor's tile
     int em0 = 0, en0 = 0;                              // tile whose quadrants are being written
     auto load_bias = [&](int n0) {
+        if (g.bias) {
+            const float* base = g.bias + n0;                                 // wave-uniform
+            const uint32_t voff = (uint32_t)(wc * 32 + lg * 4) * 4u;
+            bias4[0][0] = asm_load_f32x4<0>(base, voff);
+            bias4[0][1] = asm_load_f32x4<64>(base, voff);
+            bias4[1][0] = asm_load_f32x4<512>(base, voff);
+            bias4[1][1] = asm_load_f32x4<576>(base, voff);
+        } else {
 #pragma unroll
-        for (int qn = 0; qn < 2; ++qn)
+            for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (g.bias) bias4[qn][j] = asm_load_f32x4(g.bias + n0 + qn * 128 + wc * 32 + j * 16 + lg * 4);
-                else bias4[qn][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            }
+                for (int j = 0; j < 2; ++j) bias4[qn][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
     };
     auto flush_quadrant = [&](auto qm_c, auto qn_c) {
         constexpr int qm = decltype(qm_c)::value, qn = decltype(qn_c)::value;
@@ -361,7 +368,10 @@ static void launch_p9_t(const GemmArgs& g, int nwg, hipStream_t s) {
 // dbg bits (A/B, tests): 64 / 128 force the 192- / 256-row tile; 512 the 8-slot ring (128 KiB, four half tiles in flight);
 // bits 12.. : workgroups per XCD (default 32 = one per CU)
 hipError_t launch_gemm_p9(GemmArgs g, hipStream_t s) {
-    int mh = gemm_p8_cost(g, 96) < gemm_p8_cost(g, 128) ? 96 : 128;
+    // the 192-row tile also on a tie when an activation is fused: the 256-row tile + activation temporaries does not fit
+    // the register file without scratch, and hipcc waits vmcnt(0) for its scratch reloads -- a drained DMA queue per tile
+    const int c96 = gemm_p8_cost(g, 96), c128 = gemm_p8_cost(g, 128);
+    int mh = (c96 < c128 || (c96 == c128 && g.act != GITMI_ACT_NONE)) ? 96 : 128;
     if (g.dbg & 64) mh = 96;
     if (g.dbg & 128) mh = 128;
     const bool ring8 = (g.dbg & 512) != 0;

@@ -94,11 +94,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TS* __restrict__ x
 // so that the N = hidden GEMMs of the encoder / prefill write plain 16-bit rows (no read-modify-write of the stream in
 // their epilogue) and the stream is touched once per LayerNorm, by a kernel that streams at HBM rate.
 template <typename TS>
-__global__ __launch_bounds__(256) void add_layernorm_kernel(const TS* __restrict__ x, int ldx, const f16_t* __restrict__ yadd,
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const TS* x, int ldx, const f16_t* __restrict__ yadd,
                                                             int ldy, TS* x_out, int ldxo, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
                                                             const float* __restrict__ add_after, bf16_t* __restrict__ y_t,
-                                                            int ld_t, TS* y_f, int ld_f, int rows, int D, RowMap map) {
+                                                            int ld_t, TS* y_f, int ld_f, float* __restrict__ y32, int ld32,
+                                                            int rows, int D, RowMap map) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const TS* __restrict
                 *reinterpret_cast<uint2*>(y_t + orow * ld_t + c) = t;
             }
             if (y_f) st4s(y_f + orow * ld_f + c, f32x4_t{o[0], o[1], o[2], o[3]});
+            if (y32) *reinterpret_cast<f32x4_t*>(y32 + orow * ld32 + c) = f32x4_t{o[0], o[1], o[2], o[3]};
         }
     }
 }
@@ -477,21 +479,21 @@ hipError_t launch_layernorm_s16(const void* x, int ldx, const float* gamma, cons
 
 hipError_t launch_add_layernorm(const void* x, bool s_f16, int ldx, const void* yadd_f16, int ldy, void* x_out, int ldxo,
                                 const float* gamma, const float* beta, float eps, const float* add_after, void* y_t_bf16,
-                                int ld_t, void* y_f, int ld_f, int rows, int D, int map_n_in, int map_n_out, int map_off,
-                                hipStream_t s) {
+                                int ld_t, void* y_f, int ld_f, float* y32, int ld32, int rows, int D, int map_n_in,
+                                int map_n_out, int map_off, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     if (!x && !yadd_f16) return hipErrorInvalidValue;
     if (D > 64 * LN_MAXV || (D & 3) || (x && (ldx & 3)) || (yadd_f16 && (ldy & 3)) || (x_out && (ldxo & 3)) || (ld_t & 3) ||
-        (y_f && (ld_f & 3)))
+        (y_f && (ld_f & 3)) || (y32 && (ld32 & 3)))
         return hipErrorInvalidValue;
     RowMap m{map_n_in > 0 ? map_n_in : rows, map_n_in > 0 ? map_n_out : rows, map_off};
     dim3 grid((rows + 3) / 4), block(256);
     if (s_f16)
         hipLaunchKernelGGL(add_layernorm_kernel<f16_t>, grid, block, 0, s, (const f16_t*)x, ldx, (const f16_t*)yadd_f16, ldy,
-                           (f16_t*)x_out, ldxo, gamma, beta, eps, add_after, (bf16_t*)y_t_bf16, ld_t, (f16_t*)y_f, ld_f, rows, D, m);
+                           (f16_t*)x_out, ldxo, gamma, beta, eps, add_after, (bf16_t*)y_t_bf16, ld_t, (f16_t*)y_f, ld_f, y32, ld32, rows, D, m);
     else
         hipLaunchKernelGGL(add_layernorm_kernel<float>, grid, block, 0, s, (const float*)x, ldx, (const f16_t*)yadd_f16, ldy,
-                           (float*)x_out, ldxo, gamma, beta, eps, add_after, (bf16_t*)y_t_bf16, ld_t, (float*)y_f, ld_f, rows, D, m);
+                           (float*)x_out, ldxo, gamma, beta, eps, add_after, (bf16_t*)y_t_bf16, ld_t, (float*)y_f, ld_f, y32, ld32, rows, D, m);
     return hipGetLastError();
 }
 

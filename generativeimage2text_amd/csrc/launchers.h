@@ -74,11 +74,11 @@ hipError_t launch_layernorm_s16(const void* x, int ldx, const float* gamma, cons
                                 const float* add_after, void* y_t, int ld_t, bool t_is_f32, void* y_s, int ld_s,
                                 int rows, int D, int map_n_in, int map_n_out, int map_off, hipStream_t s);
 // residual add + LayerNorm in one pass (bf16 engine mode with fp16 branch outputs): x_new = x + yadd [-> x_out],
-// LayerNorm(x_new) -> y_t (bf16) [, y_f (stream type)]; x == nullptr: x_new = yadd
+// LayerNorm(x_new) -> y_t (bf16) [, y_f (stream type), y32 (fp32 copy, parity hook)]; x == nullptr: x_new = yadd
 hipError_t launch_add_layernorm(const void* x, bool s_f16, int ldx, const void* yadd_f16, int ldy, void* x_out, int ldxo,
                                 const float* gamma, const float* beta, float eps, const float* add_after, void* y_t_bf16,
-                                int ld_t, void* y_f, int ld_f, int rows, int D, int map_n_in, int map_n_out, int map_off,
-                                hipStream_t s);
+                                int ld_t, void* y_f, int ld_f, float* y32, int ld32, int rows, int D, int map_n_in,
+                                int map_n_out, int map_off, hipStream_t s);
 hipError_t launch_embed_ln(const int* ids, int ld_ids, int pos, const float* words, const float* positions,
                            const float* gamma, const float* beta, float eps, float* h_f, void* h_t, bool t_is_f32,
                            int R, int D, int vocab, bool frag, hipStream_t s);
