@@ -133,6 +133,10 @@ struct gitmi_engine {
     long long* start_dev = nullptr;     // [max_batch][max_text_len] start tokens of every sentence
     int *plen_dev = nullptr, *img_of_dev = nullptr;
     bool img_identity = true;           // sentence b attends to image b
+    // token trie of trie-constrained greedy decoding (gitmi_set_trie; trie_decoder.py) + one cursor per sentence
+    int *trie_off = nullptr, *trie_tok = nullptr, *trie_child = nullptr, *trie_cursor = nullptr;
+    int trie_nodes = 0;
+    bool trie_search = false;           // the current search is GITMI_SEARCH_TRIE
     gitmi_search sample{};              // sampling parameters of the current search (do_sample, top_k, top_p, temperature, seed)
     int attn_dbg = 0, dgemm_dbg = 0;    // timing experiments (GITMI_ATTN_DBG, GITMI_DGEMM_DBG)
     bool use_temb = true;               // add img_temperal_embedding[i] to frame i (the reference does so only for a LIST of frames)
@@ -368,6 +372,9 @@ extern "C" void gitmi_destroy(gitmi_engine* e) {
     if (e->enc_done) hipEventDestroy(e->enc_done);
     for (auto ev : e->event_pool) hipEventDestroy(ev);
     for (void* p : e->allocs) hipFree(p);
+    if (e->trie_off) hipFree(e->trie_off);
+    if (e->trie_tok) hipFree(e->trie_tok);
+    if (e->trie_child) hipFree(e->trie_child);
     delete e;
 }
 
@@ -537,6 +544,7 @@ static int alloc_workspaces(gitmi_engine* e) {
     RCK(dev_alloc_t(e, &e->start_dev, (size_t)c.max_batch * T));
     RCK(dev_alloc_t(e, &e->plen_dev, (size_t)c.max_batch));
     RCK(dev_alloc_t(e, &e->img_of_dev, (size_t)c.max_batch));
+    RCK(dev_alloc_t(e, &e->trie_cursor, (size_t)c.max_batch));
     RCK(dev_alloc_t(e, &e->out_tokens, (size_t)c.max_batch * T));
     RCK(dev_alloc_t(e, &e->out_lp, (size_t)c.max_batch));
     RCK(dev_alloc_t(e, &e->out_info, 4));
@@ -1057,6 +1065,7 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
 }
 
 static int sample_candidates(gitmi_engine* e, const float* logits, int ldl, int R, int step, hipStream_t s, StepCands* cands);
+static int trie_candidates(gitmi_engine* e, const float* logits, int ldl, int cur_len, hipStream_t s, StepCands* cands);
 // repetition penalty of the current search (GENERATOR only; 0 and 1 both mean "off")
 static float rep_penalty_of(const gitmi_engine* e) {
     const double rp = e->sample.repetition_penalty;
@@ -1071,7 +1080,8 @@ static int decode_head_impl(gitmi_engine* e, const int* ids, int ld_ids, int cur
     const bool chain = e->skinny && !e->f32;
     cands->part_val = e->part_val; cands->part_idx = e->part_idx; cands->part_lse = e->part_lse;
     const bool sampling = ids != nullptr && e->ss.sampled;
-    if (sampling && !logits_out) { logits_out = e->logits; ldl = e->ldl; }     // the filter needs the whole row
+    const bool trie = ids != nullptr && e->trie_search;
+    if ((sampling || trie) && !logits_out) { logits_out = e->logits; ldl = e->ldl; }     // the filter / the trie need the whole row
     if (chain) {
         const DecLayerW& L = e->dec[c.dec_layers - 1];
         (void)L;
@@ -1089,10 +1099,12 @@ static int decode_head_impl(gitmi_engine* e, const int* ids, int ld_ids, int cur
         }
         cands->nparts = e->vocab_nparts; cands->slots = vocab_mtop_slots(M);
         if (sampling) RCK(sample_candidates(e, logits_out, ldl, R, cur_len, s, cands));
+        if (trie) RCK(trie_candidates(e, logits_out, ldl, cur_len, s, cands));
     } else {
         RCK(gemm(e, s, e->d_ht, d, e->out_w, e->out_b, nullptr, 0, e->logits, e->ldl, true, R, c.vocab, d, 0, TAG_GEMM_OTHER));
         cands->nparts = 1; cands->slots = row_topm_slots(M);
         if (sampling) RCK(sample_candidates(e, e->logits, e->ldl, R, cur_len, s, cands));
+        else if (trie) RCK(trie_candidates(e, e->logits, e->ldl, cur_len, s, cands));
         else if (ids)
             HIPCK(launch_row_topm(e->logits, e->ldl, c.vocab, ids, ld_ids, cur_len, e->plen_dev, beams, suppress_kind,
                                   rep_penalty_of(e), M, R,
@@ -1156,10 +1168,16 @@ static int search_begin_impl(gitmi_engine* e, const gitmi_search* sp, int B, int
                              hipStream_t s) {
     const gitmi_config& c = e->cfg;
     if (!sp) return fail("search: null config");
-    if (sp->kind != GITMI_SEARCH_AUTOREGRESSIVE && sp->kind != GITMI_SEARCH_GENERATOR) return fail("search: bad kind");
+    if (sp->kind != GITMI_SEARCH_AUTOREGRESSIVE && sp->kind != GITMI_SEARCH_GENERATOR && sp->kind != GITMI_SEARCH_TRIE)
+        return fail("search: bad kind");
+    if (sp->kind == GITMI_SEARCH_TRIE) {
+        if (sp->beam_size != 1) return fail("search: TrieAutoRegressiveBeamSearch asserts beam_size == 1 (trie_decoder.py:37)");
+        if (!e->trie_off) return fail("search: no trie loaded (gitmi_set_trie)");
+        if (sp->do_sample) return fail("search: the trie search has no sampling branch");
+    }
     if (B < 1 || B > c.max_batch) return fail("search: B=%d outside [1,%d]", B, c.max_batch);
     if (sp->beam_size < 1 || sp->beam_size > c.max_beams) return fail("search: beam_size %d outside [1,%d]", sp->beam_size, c.max_beams);
-    if (sp->per_node_beam_size < 1) return fail("search: per_node_beam_size must be >= 1");
+    if (sp->per_node_beam_size < 1 && sp->kind != GITMI_SEARCH_TRIE) return fail("search: per_node_beam_size must be >= 1");
     if (sp->kind == GITMI_SEARCH_GENERATOR && sp->per_node_beam_size < 2)
         return fail("search: GeneratorWithBeamSearch requires per_node_beam_size > 1 (decoder.py:1078)");
     if (sp->beam_size * sp->per_node_beam_size > 16) return fail("search: beam_size*per_node_beam_size > 16 unsupported");
@@ -1177,15 +1195,18 @@ static int search_begin_impl(gitmi_engine* e, const gitmi_search* sp, int B, int
         if (V > 32768) return fail("search: sampling supports vocabularies up to 32768 tokens");
     }
     SearchState& st = e->ss;
-    st.B = B; st.k = sp->beam_size; st.pn = sp->per_node_beam_size;
+    e->trie_search = sp->kind == GITMI_SEARCH_TRIE;
+    st.B = B; st.k = sp->beam_size; st.pn = e->trie_search ? 1 : sp->per_node_beam_size;
     st.T = sp->max_steps;           // max_length of the search AND the row stride of ids/kv_src/hyp_tok
-    st.V = V; st.eos = c.eos; st.kind = sp->kind; st.length_penalty = sp->length_penalty;
+    // the trie search shares AutoRegressiveBeamSearch's bookkeeping (beam 1): only the candidate selection differs
+    st.V = V; st.eos = c.eos; st.kind = e->trie_search ? GITMI_SEARCH_AUTOREGRESSIVE : sp->kind; st.length_penalty = sp->length_penalty;
     st.ragged = ragged ? 1 : 0;
     st.sampled = sp->do_sample ? 1 : 0;
     e->sample = *sp;
     st.start = e->start_dev; st.ld_start = c.max_text_len; st.plen = e->plen_dev;
     e->ss_cur = 0; e->ss_len = minP; e->ss_minP = minP;
     HIPCK(launch_search_init(st, s));
+    if (e->trie_search) HIPCK(launch_fill_i32(e->trie_cursor, 0, B, s));      // TokenTrie.reset(): every cursor at the root
     return 0;
 }
 
@@ -1202,6 +1223,17 @@ static int sample_candidates(gitmi_engine* e, const float* logits, int ldl, int 
                              rep_penalty_of(e), s));
     cands->part_val = e->part_val; cands->part_idx = e->part_idx; cands->part_lse = e->part_lse;
     cands->nparts = 1; cands->slots = e->ss.pn;
+    return 0;
+}
+
+// trie-constrained selection on the materialised logits of the step (trie_decoder.py:57-71, 115-158)
+static int trie_candidates(gitmi_engine* e, const float* logits, int ldl, int cur_len, hipStream_t s, StepCands* cands) {
+    const SearchState& st = e->ss;
+    TrieArgs tr{e->trie_off, e->trie_tok, e->trie_child, e->trie_cursor};
+    HIPCK(launch_trie_select(logits, ldl, st.V, st.ids[e->ss_cur], st.T, cur_len, e->plen_dev, st.eos, tr, st.B, e->part_val,
+                             e->part_idx, e->part_lse, s));
+    cands->part_val = e->part_val; cands->part_idx = e->part_idx; cands->part_lse = e->part_lse;
+    cands->nparts = 1; cands->slots = 1;
     return 0;
 }
 
@@ -1229,6 +1261,37 @@ static int fill_uniform_sentences(gitmi_engine* e, int B, const long long* prefi
     HIPCK(launch_fill_start(e->start_dev, e->cfg.max_text_len, prefix_dev, 0, 1, e->cfg.sos, B, P, s));
     HIPCK(launch_fill_i32(e->plen_dev, P, B, s));
     e->img_identity = true;
+    return 0;
+}
+
+// Token trie for GITMI_SEARCH_TRIE (trie_decoder.py:224-257 TokenTrie as CSR): node 0 is the root, the children of node n
+// are the edges child_off[n] .. child_off[n + 1] - 1 (token child_tok[e] leads to node child_node[e]).  Host arrays, copied.
+// n_nodes == 0 removes the trie.
+extern "C" int gitmi_set_trie(gitmi_engine* e, int n_nodes, const int32_t* child_off, const int32_t* child_tok,
+                              const int32_t* child_node) {
+    RCK(check_ready(e));
+    HIPCK(hipDeviceSynchronize());
+    destroy_graph(e);                                       // captured launches hold the old pointers
+    if (e->trie_off) { hipFree(e->trie_off); hipFree(e->trie_tok); hipFree(e->trie_child); }
+    e->trie_off = e->trie_tok = e->trie_child = nullptr;
+    e->trie_nodes = 0;
+    if (n_nodes <= 0) return 0;
+    if (!child_off || child_off[0] != 0) return fail("set_trie: child_off must start at 0");
+    const int n_edges = child_off[n_nodes];
+    for (int n = 0; n < n_nodes; ++n)
+        if (child_off[n + 1] < child_off[n]) return fail("set_trie: child_off must be non-decreasing");
+    if (n_edges > 0 && (!child_tok || !child_node)) return fail("set_trie: null edge arrays");
+    for (int i = 0; i < n_edges; ++i)
+        if (child_node[i] < 0 || child_node[i] >= n_nodes) return fail("set_trie: edge %d leads to node %d of %d", i, child_node[i], n_nodes);
+    HIPCK(hipMalloc((void**)&e->trie_off, (size_t)(n_nodes + 1) * sizeof(int)));
+    HIPCK(hipMalloc((void**)&e->trie_tok, (size_t)std::max(n_edges, 1) * sizeof(int)));
+    HIPCK(hipMalloc((void**)&e->trie_child, (size_t)std::max(n_edges, 1) * sizeof(int)));
+    HIPCK(hipMemcpy(e->trie_off, child_off, (size_t)(n_nodes + 1) * sizeof(int), hipMemcpyHostToDevice));
+    if (n_edges > 0) {
+        HIPCK(hipMemcpy(e->trie_tok, child_tok, (size_t)n_edges * sizeof(int), hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(e->trie_child, child_node, (size_t)n_edges * sizeof(int), hipMemcpyHostToDevice));
+    }
+    e->trie_nodes = n_nodes;
     return 0;
 }
 
@@ -1265,6 +1328,7 @@ extern "C" int gitmi_search_advance(gitmi_engine* e, const float* logits, void* 
     const int M = search_mtop(st), R = st.B * st.k;
     StepCands cands{e->part_val, e->part_idx, e->part_lse, 1, row_topm_slots(M)};
     if (st.sampled) RCK(sample_candidates(e, logits, st.V, R, e->ss_len, s, &cands));
+    else if (e->trie_search) RCK(trie_candidates(e, logits, st.V, e->ss_len, s, &cands));
     else
         HIPCK(launch_row_topm(logits, st.V, st.V, st.ids[e->ss_cur], st.T, e->ss_len, e->plen_dev, st.k,
                               st.kind == GITMI_SEARCH_AUTOREGRESSIVE ? 1 : 0, rep_penalty_of(e), M, R, e->part_val,
@@ -1310,7 +1374,7 @@ static int generate_decode(gitmi_engine* e, int Q, int minP, int maxP, bool ragg
     const SearchState& st = e->ss;
     const int k = sp->beam_size, R = Q * k;
     const int M = search_mtop(st);
-    const int suppress = sp->kind == GITMI_SEARCH_AUTOREGRESSIVE ? 1 : 0;
+    const int suppress = sp->kind != GITMI_SEARCH_GENERATOR ? 1 : 0;
     {
         SpanGuard phase(e, s, TAG_DECODE, 0);
         // position 0 is embedded here; every later position by the search step that appends its token

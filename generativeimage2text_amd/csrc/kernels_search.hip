@@ -350,6 +350,110 @@ __global__ __launch_bounds__(SMP_NT) void sample_rows_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------
+// Trie-constrained greedy step (TrieAutoRegressiveBeamSearch.search, trie_decoder.py:57-71, 115-158), one workgroup per
+// sentence (beam_size == 1).  On the step's logits x (the last token's logit set to -10000 after the first step, :121):
+//     lp    = log_softmax(x)                                  computed as (x - max) - log(sum exp(x - max)), like torch
+//     bonus = (max x - min x) + 1                             (:64, :151; -10000 is part of the min after the first step)
+//     lp[t] += bonus  for every child token t of the sentence's trie cursor
+//     (value, token) = top-1 of lp;  the cursor moves to the chosen child
+// and the pair is handed to the search step as a one-entry candidate list whose value already is a log-probability
+// (part_lse = (0, 1)); the step adds it to the running sum exactly like AutoRegressiveBeamSearch (:170-176).  Every
+// sentence has its OWN cursor: it behaves like its own batch-1 reference call (the reference moves one cursor with
+// row 0's choice and asserts as soon as row 0 has ended while another row has not).  A choice outside the trie -- the
+// reference would assert in TokenTrie.move -- leaves the sentence unconstrained from then on (cursor -1).
+constexpr int TRIE_NT = 1024;
+
+__global__ __launch_bounds__(TRIE_NT) void trie_select_kernel(const float* __restrict__ logits, int ldl, int V,
+                                                             const int* __restrict__ ids, int ld_ids, int cur_len,
+                                                             const int* __restrict__ plen, int eos, TrieArgs tr,
+                                                             float* __restrict__ part_val, int* __restrict__ part_idx,
+                                                             float2* __restrict__ part_lse) {
+    __shared__ float s_f[TRIE_NT / 64];
+    __shared__ float s_g[TRIE_NT / 64];
+    __shared__ int s_i[TRIE_NT / 64];
+    __shared__ int s_j[TRIE_NT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = TRIE_NT / 64;
+    const int P = plen[b];
+    if (cur_len < P) return;                                      // still inside the sentence's prefix: nothing to select
+    const bool first = cur_len == P;
+    const int last = ids[(size_t)b * ld_ids + cur_len - 1];
+    if (!first && last == eos) {                                  // ended: the search step forces EOS at log-prob 0 (:138-142)
+        if (tid == 0) { part_val[b] = 0.f; part_idx[b] = eos; part_lse[b] = float2{0.f, 1.f}; }
+        return;
+    }
+    const float* x = logits + (size_t)b * ldl;
+    const int sup = first ? -1 : last;
+    // ---- max (lowest index on ties), min
+    float mx = -INFINITY, mn = INFINITY;
+    int am = 0x7fffffff;
+    for (int i = tid; i < V; i += TRIE_NT) {
+        const float v = i == sup ? -10000.f : x[i];
+        if (v > mx) { mx = v; am = i; }
+        mn = fminf(mn, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(am, o, 64);
+        if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+        mn = fminf(mn, __shfl_xor(mn, o, 64));
+    }
+    if (lane == 0) { s_f[wave] = mx; s_i[wave] = am; s_g[wave] = mn; }
+    __syncthreads();
+    mx = s_f[0]; am = s_i[0]; mn = s_g[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        if (s_f[w] > mx || (s_f[w] == mx && s_i[w] < am)) { mx = s_f[w]; am = s_i[w]; }
+        mn = fminf(mn, s_g[w]);
+    }
+    __syncthreads();
+    // ---- log-sum-exp
+    float sm = 0.f;
+    for (int i = tid; i < V; i += TRIE_NT) sm += __expf((i == sup ? -10000.f : x[i]) - mx);
+    sm = wave_sum(sm);
+    if (lane == 0) s_f[wave] = sm;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += s_f[w];
+    __syncthreads();
+    const float logsum = logf(tot);
+    const float bonus = (mx - mn) + 1.0f;
+    // ---- best child of the cursor
+    const int node = tr.cursor[b];
+    const int e0 = node >= 0 ? tr.child_off[node] : 0, e1 = node >= 0 ? tr.child_off[node + 1] : 0;
+    float bv = -INFINITY;
+    int bt = 0x7fffffff, be = -1;
+    for (int e = e0 + tid; e < e1; e += TRIE_NT) {
+        const int t = tr.child_tok[e];
+        if (t < 0 || t >= V) continue;
+        const float xv = t == sup ? -10000.f : x[t];
+        const float v = ((xv - mx) - logsum) + bonus;
+        if (v > bv || (v == bv && t < bt)) { bv = v; bt = t; be = e; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int ot = __shfl_xor(bt, o, 64), oe = __shfl_xor(be, o, 64);
+        if (ov > bv || (ov == bv && ot < bt)) { bv = ov; bt = ot; be = oe; }
+    }
+    if (lane == 0) { s_f[wave] = bv; s_i[wave] = bt; s_j[wave] = be; }
+    __syncthreads();
+    if (tid == 0) {
+        bv = s_f[0]; bt = s_i[0]; be = s_j[0];
+        for (int w = 1; w < NW; ++w)
+            if (s_f[w] > bv || (s_f[w] == bv && s_i[w] < bt)) { bv = s_f[w]; bt = s_i[w]; be = s_j[w]; }
+        const float plain = (mx - mx) - logsum;                   // log-prob of the unconstrained arg-max
+        const bool take_valid = be >= 0 && (bv > plain || (bv == plain && bt <= am));
+        part_val[b] = take_valid ? bv : plain;
+        part_idx[b] = take_valid ? bt : am;
+        part_lse[b] = float2{0.f, 1.f};
+        tr.cursor[b] = take_valid ? tr.child_node[be] : -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Host arithmetic of the reference is Python double -> double here (decoder.py:1310-1341).
 __device__ __forceinline__ double length_norm(int len, double alpha) {
     return pow(5.0 + (double)len, alpha) / pow(6.0, alpha);
@@ -766,6 +870,16 @@ hipError_t launch_sample_rows(const float* logits, int ldl, int V, int R, float 
     hipLaunchKernelGGL(sample_rows_kernel, dim3(R), dim3(SMP_NT), 0, s, logits, ldl, V, 1.0f / temperature, top_k, top_p, ndraw,
                        (unsigned int)(seed & 0xffffffffu), (unsigned int)(seed >> 32), step, part_val, part_idx, part_lse,
                        filtered_out, ids, ld_ids, cur_len, rep_penalty);
+    return hipGetLastError();
+}
+
+hipError_t launch_trie_select(const float* logits, int ldl, int V, const int* ids, int ld_ids, int cur_len, const int* plen,
+                              int eos, const TrieArgs& tr, int B, float* part_val, int* part_idx, float2* part_lse,
+                              hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (!tr.child_off || !tr.cursor || V < 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(trie_select_kernel, dim3(B), dim3(TRIE_NT), 0, s, logits, ldl, V, ids, ld_ids, cur_len, plen, eos, tr,
+                       part_val, part_idx, part_lse);
     return hipGetLastError();
 }
 

@@ -158,6 +158,16 @@ hipError_t launch_sample_rows(const float* logits, int ldl, int V, int R, float 
                               int ndraw, unsigned long long seed, int step, float* part_val, int* part_idx,
                               float2* part_lse, float* filtered_out, const int* ids, int ld_ids, int cur_len,
                               float rep_penalty, hipStream_t s);
+// token trie on the device (CSR: the children of node n are edges child_off[n] .. child_off[n + 1]) + one cursor per sentence
+struct TrieArgs {
+    const int* child_off; const int* child_tok; const int* child_node;
+    int* cursor;                 // [B] current node of every sentence (0 = root, -1 = unconstrained)
+};
+// trie-constrained greedy selection on materialised logits [B, ldl] (trie_decoder.py:57-71, 115-158): one candidate
+// (log-prob incl. the trie bonus, token) per sentence in the candidate-list format of the search step; moves the cursors
+hipError_t launch_trie_select(const float* logits, int ldl, int V, const int* ids, int ld_ids, int cur_len, const int* plen,
+                              int eos, const TrieArgs& tr, int B, float* part_val, int* part_idx, float2* part_lse,
+                              hipStream_t s);
 hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, int ld_ids, int cur_len,
                            const int* plen, int beams, int suppress_kind, float rep_penalty, int M, int R,
                            float* part_val, int* part_idx, float2* part_lse, hipStream_t s);

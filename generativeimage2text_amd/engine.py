@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libgitmi.so")
 
 PREC_BF16, PREC_F32 = 0, 1
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
-SEARCH_AUTOREGRESSIVE, SEARCH_GENERATOR = 0, 1
+SEARCH_AUTOREGRESSIVE, SEARCH_GENERATOR, SEARCH_TRIE = 0, 1, 2
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
 
 EXPORTED_SYMBOLS = [
@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_op_vocab_topm", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
     "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after", "gitmi_op_sample_rows",
     "gitmi_generate_encode", "gitmi_generate_decode", "gitmi_search_done_count",
-    "gitmi_debug_import_stage", "gitmi_debug_head_from", "gitmi_op_add_layernorm",
+    "gitmi_debug_import_stage", "gitmi_debug_head_from", "gitmi_op_add_layernorm", "gitmi_set_trie",
 ]
 
 
@@ -94,6 +94,7 @@ def load_library() -> C.CDLL:
     lib.gitmi_search_advance.argtypes = [vp, vp, vp]
     lib.gitmi_search_finish.argtypes = [vp, vp, vp, vp, vp]
     lib.gitmi_search_done_count.argtypes = [vp, C.POINTER(C.c_int), vp]
+    lib.gitmi_set_trie.argtypes = [vp, i32, vp, vp, vp]
     lib.gitmi_debug_import_stage.argtypes = [vp, vp, i32, vp]
     lib.gitmi_debug_head_from.argtypes = [vp, vp, i32, vp, vp]
     lib.gitmi_profile_enable.argtypes = [vp, i32]
@@ -263,7 +264,8 @@ class Engine:
                     length_penalty: float = 1.0, do_sample: bool = False, top_k: int = 0, top_p: float = 1.0,
                     temperature: float = 1.0, seed: int = 0, repetition_penalty: float = 1.0) -> GitmiSearch:
         s = GitmiSearch()
-        s.kind = SEARCH_AUTOREGRESSIVE if kind in ("greedy", "autoregressive") else SEARCH_GENERATOR
+        s.kind = (SEARCH_AUTOREGRESSIVE if kind in ("greedy", "autoregressive") else SEARCH_TRIE if kind == "trie"
+                  else SEARCH_GENERATOR)
         s.beam_size, s.per_node_beam_size, s.max_steps = int(beam_size), int(per_node_beam_size), int(max_steps)
         s.length_penalty = float(length_penalty)
         s.do_sample, s.top_k, s.top_p = int(bool(do_sample)), int(top_k or 0), float(1.0 if top_p is None else top_p)
@@ -383,6 +385,18 @@ class Engine:
         logits = logits.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
         self._keep_logits = logits
         _ck(self.lib.gitmi_search_advance(self._h, logits.data_ptr(), _stream()))
+
+    def set_trie(self, child_off, child_tok, child_node) -> None:
+        """Token trie of the "trie" search kind as CSR int32 arrays (include/gitmi.h gitmi_set_trie); None removes it."""
+        if child_off is None:
+            _ck(self.lib.gitmi_set_trie(self._h, 0, None, None, None))
+            return
+        off = torch.as_tensor(child_off, dtype=torch.int32).cpu().contiguous()
+        tok = torch.as_tensor(child_tok, dtype=torch.int32).cpu().contiguous()
+        node = torch.as_tensor(child_node, dtype=torch.int32).cpu().contiguous()
+        assert off.numel() >= 2 and tok.numel() == node.numel() == int(off[-1])
+        _ck(self.lib.gitmi_set_trie(self._h, int(off.numel()) - 1, off.data_ptr(), tok.data_ptr() if tok.numel() else None,
+                                    node.data_ptr() if node.numel() else None))
 
     # -- error attribution hooks (tools/error_attribution.py) ---------------------------------------
     def debug_import_stage(self, src: "Engine", stage: int) -> None:

@@ -58,6 +58,8 @@ def _begin_and_run(decoder, start_predictions, step, search_struct, first_step_r
         raise ValueError(f"prefix of {P} tokens exceeds max_steps={T}")
     dev = start_predictions.device
     eng = _search_engine(decoder._eos_index, int(start[0, 0]), B, k, T, engine_factory)
+    if getattr(decoder, "kind", "") == "trie":
+        eng.set_trie(*decoder.trie.csr())
     # the vocabulary size is only known from the first logits: the first `step` call is made on the start rows as the
     # reference makes it (one row per sentence for AutoRegressiveBeamSearch, decoder.py:259; B*k rows for the generator,
     # decoder.py:1101-1102), then the device search begins and receives those logits as its first advance
@@ -113,6 +115,97 @@ class AutoRegressiveBeamSearch:
             raise NotImplementedError("AutoRegressiveBeamSearch.search: only the inference form "
                                       "(only_return_best=True, do_sample=False) is implemented")
         s = Engine.make_search("autoregressive", self.max_steps, self.beam_size, self.per_node_beam_size)
+        return _begin_and_run(self, start_predictions, step, s, first_step_rows_per_sentence=True, stop_when_all_eos=True,
+                              fmt="autoregressive", engine_factory=_engine_factory)
+
+
+class TokenTrie:
+    """Same interface as the reference's TokenTrie (trie_decoder.py:224-257): construct / insert / get_valid / reset /
+    get_curr_valid / move.  The search itself walks a CSR copy of it on the device (`csr()` -> gitmi_set_trie)."""
+
+    def __init__(self):
+        self._children = [{}]                  # node -> {token: child node}; node 0 is the root
+        self.curr = 0
+
+    @classmethod
+    def construct(cls, all_tokens):
+        ret = cls()
+        for ts in all_tokens:
+            ret.insert(ts)
+        return ret
+
+    def insert(self, tokens):
+        cur = 0
+        for t in tokens:
+            nxt = self._children[cur].get(int(t))
+            if nxt is None:
+                nxt = len(self._children)
+                self._children.append({})
+                self._children[cur][int(t)] = nxt
+            cur = nxt
+
+    def get_valid(self, tokens):
+        cur = 0
+        for t in tokens:
+            cur = self._children[cur].get(int(t))
+            if cur is None:
+                return []
+        return list(self._children[cur].keys())
+
+    def reset(self):
+        self.curr = 0
+
+    def get_curr_valid(self):
+        return list(self._children[self.curr].keys())
+
+    def move(self, t):
+        assert int(t) in self._children[self.curr]
+        self.curr = self._children[self.curr][int(t)]
+
+    def csr(self):
+        off, tok, node = [0], [], []
+        for ch in self._children:
+            tok.extend(ch.keys())
+            node.extend(ch.values())
+            off.append(len(tok))
+        return off, tok, node
+
+
+def get_output_vocab_tokens(tokenizer, texts):
+    """trie_decoder.py:18-25: every allowed answer as its token ids + [SEP]."""
+    return [tokenizer(a, padding="do_not_pad", add_special_tokens=False)["input_ids"] + [tokenizer.sep_token_id] for a in texts]
+
+
+def get_trie(tokenizer, texts=None, fname="./aux_data/imagenet/imagenet_unique_readable_names.txt"):
+    """trie_decoder.py:6-16: the trie over the allowed output texts (default: the ImageNet names file of the reference)."""
+    if texts is None:
+        with open(fname, "r") as fp:
+            texts = list(fp)
+    return TokenTrie.construct(get_output_vocab_tokens(tokenizer, texts))
+
+
+class TrieAutoRegressiveBeamSearch:
+    """Constructor-compatible with the reference class (trie_decoder.py:27-39): greedy decoding (beam_size == 1) restricted
+    to the token sequences of `trie`.  Every sentence of a batch walks its own trie cursor, i.e. gets what its own batch-1
+    reference call returns (the reference's single cursor follows row 0)."""
+
+    def __init__(self, eos_index: int, max_steps: int = 50, beam_size: int = 5, trie=None) -> None:
+        self._eos_index = eos_index
+        self.max_steps = max_steps
+        assert beam_size == 1                                       # trie_decoder.py:37
+        self.beam_size = beam_size
+        self.per_node_beam_size = 1
+        self.trie = trie
+        self.kind = "trie"
+        self.length_penalty = 1.0
+
+    def search(self, start_predictions: torch.Tensor, step, only_return_best: bool = True, do_sample: bool = False,
+               top_k: int = 0, top_p=None, num_return_sequences: int = 1, temperature: float = 1, _engine_factory=None):
+        """trie_decoder.py:41-218 with a caller-supplied `step`: -> (predictions [B, length <= max_steps] incl. the start
+        tokens, logprobs [B]); ([B, 1], [B, 1]) when every first prediction is EOS."""
+        if do_sample or not only_return_best or num_return_sequences != 1 or temperature != 1:
+            raise NotImplementedError("TrieAutoRegressiveBeamSearch.search: only the inference form is implemented")
+        s = Engine.make_search("trie", self.max_steps, 1, 1)
         return _begin_and_run(self, start_predictions, step, s, first_step_rows_per_sentence=True, stop_when_all_eos=True,
                               fmt="autoregressive", engine_factory=_engine_factory)
 
@@ -270,11 +363,14 @@ class CaptioningModel:
         if prefix is not None:
             assert len(prefix) == 1, "not supported"                       # decoder.py:988
         search = self._search_struct(search_param)
+        if self.decoder.kind == "trie" and getattr(self, "_trie_loaded", None) is not self.decoder.trie:
+            self.engine.set_trie(*self.decoder.trie.csr())
+            self._trie_loaded = self.decoder.trie
         tokens, logprobs, info = self.engine.generate(frames, search, prefix=prefix)
         seq_len, early, _, _ = info.tolist()
         P = 1 if prefix is None else int(prefix.numel())
-        if self.decoder.kind == "autoregressive":
-            if early:                                                       # decoder.py:279-291
+        if self.decoder.kind in ("autoregressive", "trie"):
+            if early:                                                       # decoder.py:279-291 / trie_decoder.py:76-83
                 predictions = tokens[:, P:P + 1]
                 logprobs = logprobs[:, None]
             else:
@@ -302,6 +398,9 @@ class CaptioningModel:
         Q = len(prefixes)
         if Q > self.engine.c.max_batch:
             raise ValueError(f"{Q} questions exceed max_batch={self.engine.c.max_batch}")
+        if self.decoder.kind == "trie" and getattr(self, "_trie_loaded", None) is not self.decoder.trie:
+            self.engine.set_trie(*self.decoder.trie.csr())
+            self._trie_loaded = self.decoder.trie
         tokens, logprobs, sent, info = self.engine.generate_prefixed(frames, self._search_struct(), prefixes,
                                                                      image_of=[0] * Q)
         tokens, sent = tokens.cpu(), sent.cpu()
@@ -309,7 +408,7 @@ class CaptioningModel:
         for q, p in enumerate(prefixes):
             P = len(p)
             L, early = int(sent[q, 0]), int(sent[q, 1])
-            if self.decoder.kind == "autoregressive":
+            if self.decoder.kind in ("autoregressive", "trie"):
                 row = (tokens[q, P:P + 1] if early else tokens[q, :L])[P:]     # decoder.py:279-291, then :1004-1006
             else:
                 row = tokens[q, P:]

@@ -43,6 +43,7 @@ extern "C" {
 /* search strategies (layers/decoder.py) */
 #define GITMI_SEARCH_AUTOREGRESSIVE 0  /* AutoRegressiveBeamSearch   decoder.py:208-440  */
 #define GITMI_SEARCH_GENERATOR      1  /* GeneratorWithBeamSearch    decoder.py:1056-1290 */
+#define GITMI_SEARCH_TRIE           2  /* TrieAutoRegressiveBeamSearch (beam 1, token trie: gitmi_set_trie)  trie_decoder.py:27-218 */
 
 typedef struct gitmi_engine gitmi_engine;
 
@@ -220,6 +221,15 @@ int  gitmi_generate_prefixed(gitmi_engine* e, const float* const* frames, int F,
 /* ---- search with caller-supplied logits: the seam decoder.search(start, step)
  * (decoder.py:224-231, 1083-1092) for scripted-step parity tests of the device search.
  * begin -> [ next_input -> (caller computes logits) -> advance ]* -> finish. */
+/* ---- token trie of GITMI_SEARCH_TRIE: replaces TokenTrie (trie_decoder.py:224-257) as CSR arrays on the host (copied):
+ * node 0 is the root; the children of node n are the edges child_off[n] .. child_off[n+1]-1, edge i = (token
+ * child_tok[i] -> node child_node[i]), children in insertion order.  At every search step the log-probabilities of the
+ * cursor's child tokens are raised by (max - min + 1) of the step's logits before the top-1 (trie_decoder.py:57-71,
+ * 115-158) and the cursor follows the choice.  EVERY sentence of a call has its own cursor, i.e. behaves like its own
+ * batch-1 reference call (the reference moves one cursor with row 0's choice).  n_nodes == 0 removes the trie. */
+int  gitmi_set_trie(gitmi_engine* e, int n_nodes, const int32_t* child_off, const int32_t* child_tok,
+                    const int32_t* child_node);
+
 int  gitmi_search_begin(gitmi_engine* e, const gitmi_search* search, int B,
                         const int64_t* start_host, int P, int vocab, void* stream);
 /* current rows the `step` callable would receive: int64 [R, cur_len]; returns cur_len via *t */

@@ -589,6 +589,108 @@ def search_generator(start: Tensor, step: Callable[[Tensor], Tensor], eos: int, 
 
 
 # ----------------------------------------------------------------------------
+# trie-constrained greedy decoding (trie_decoder.py:27-257)
+class TokenTrie:
+    """trie_decoder.py:224-257: children keyed by token id; a cursor `curr` that search() resets and moves."""
+
+    def __init__(self):
+        self.children: List[Dict[int, int]] = [{}]          # node -> {token: child node}; node 0 = root
+        self.curr = 0
+
+    @classmethod
+    def construct(cls, all_tokens: Sequence[Sequence[int]]) -> "TokenTrie":
+        t = cls()
+        for ts in all_tokens:
+            t.insert(ts)
+        return t
+
+    def insert(self, tokens: Sequence[int]) -> None:
+        cur = 0
+        for tok in tokens:
+            nxt = self.children[cur].get(int(tok))
+            if nxt is None:
+                nxt = len(self.children)
+                self.children.append({})
+                self.children[cur][int(tok)] = nxt
+            cur = nxt
+
+    def get_valid(self, tokens: Sequence[int]) -> List[int]:
+        cur = 0
+        for tok in tokens:
+            cur = self.children[cur].get(int(tok))
+            if cur is None:
+                return []
+        return list(self.children[cur].keys())
+
+    def reset(self) -> None:
+        self.curr = 0
+
+    def get_curr_valid(self) -> List[int]:
+        return list(self.children[self.curr].keys())
+
+    def move(self, tok: int) -> None:
+        assert int(tok) in self.children[self.curr]
+        self.curr = self.children[self.curr][int(tok)]
+
+    def csr(self):
+        """(child_off int32 [nodes + 1], child_tok int32 [edges], child_node int32 [edges]) -- the device layout of
+        gitmi_set_trie; the children of a node in insertion order."""
+        off, tok, node = [0], [], []
+        for ch in self.children:
+            for t, n in ch.items():
+                tok.append(t)
+                node.append(n)
+            off.append(len(tok))
+        return (torch.tensor(off, dtype=torch.int32), torch.tensor(tok, dtype=torch.int32),
+                torch.tensor(node, dtype=torch.int32))
+
+
+def search_trie(start: Tensor, step: Callable[[Tensor], Tensor], eos: int, max_steps: int,
+                trie: TokenTrie) -> Tuple[Tensor, Tensor]:
+    """TrieAutoRegressiveBeamSearch.search (trie_decoder.py:41-218), beam_size = 1, only_return_best=True.  At every
+    step the log-probabilities of ROW 0's trie-valid tokens are raised by (max - min + 1) of the step's (modified) logits
+    and the trie cursor follows row 0's choice -- so the class is meaningful for batch 1 (with more rows, `trie.move`
+    asserts as soon as row 0 has ended while another row has not).
+
+    Returns (predictions int64 [B, len <= max_steps] incl. the start tokens, logprobs fp32 [B] = summed (bonus
+    included) log-prob / num_valid); when every first prediction is EOS: ([B, 1], [B, 1]) (:76-83)."""
+    trie.reset()
+    B, P = start.shape
+    preds = start[:, None, :]                                                    # [B, 1, P]
+    logits0 = step(start)
+    lp0 = torch.log_softmax(logits0, dim=1)
+    idx = trie.get_curr_valid()
+    lp0[0, idx] += logits0.max() - logits0.min() + 1                             # :64
+    last_lp, cls0 = lp0.topk(1)                                                  # :69-71
+    trie.move(int(cls0[0, 0]))
+    if bool((cls0 == eos).all()):
+        return cls0, last_lp
+    preds = torch.cat([preds, cls0[:, :, None]], dim=-1)
+    V = lp0.shape[1]
+    after_end = torch.full((V,), float("-inf"))
+    after_end[eos] = 0.0
+    while preds.shape[-1] < max_steps:                                           # :106
+        last = preds[:, :, -1].reshape(B)
+        if bool((last == eos).all()):
+            break
+        flat = preds.reshape(B, -1)
+        logits = step(flat)
+        logits = logits.scatter(1, last[:, None], -10000.0)                      # :121
+        logits = torch.where((last == eos)[:, None], after_end[None, :], logits)  # :138-142
+        lp = torch.log_softmax(logits, dim=1)
+        idx = trie.get_curr_valid()
+        lp[0, idx] += logits.max() - logits.min() + 1                            # :151
+        top_lp, top_cls = lp.topk(1)
+        trie.move(int(top_cls[0, 0]))
+        last_lp = top_lp + last_lp                                               # :170-176 (beam 1)
+        preds = torch.cat([preds, top_cls[:, :, None]], dim=-1)
+    best = preds[:, 0, :]
+    best_lp = last_lp[:, 0]
+    n_valid = (best != eos).sum(dim=-1) + ((best == eos).sum(dim=-1) > 0).long() - P   # :210-213
+    return best, best_lp / n_valid.clamp(min=1)
+
+
+# ----------------------------------------------------------------------------
 # sampling branch helpers (decoder.py:1146-1166, 1343-1375)
 # ----------------------------------------------------------------------------
 def top_k_top_p_filtering(logits: Tensor, top_k: int = 0, top_p: Optional[float] = 1.0,
@@ -639,9 +741,11 @@ BEAM4 = SearchConfig("beam", 20, 4, 2, 0.6)                      # model.py:34-4
 
 def caption(cfg: GitConfig, w: Weights, frames: Sequence[Tensor], search: SearchConfig = GREEDY,
             prefix: Optional[Tensor] = None, cached: bool = False,
-            feats: Optional[Tensor] = None, trace: Optional[List[Tensor]] = None) -> Dict[str, Tensor]:
+            feats: Optional[Tensor] = None, trace: Optional[List[Tensor]] = None,
+            trie: Optional["TokenTrie"] = None) -> Dict[str, Tensor]:
     """model({'image': ..., 'prefix': ...}) -> {'predictions','logprobs'} exactly as
-    CaptioningModel.infer returns them (prefix stripped, decoder.py:1004-1006)."""
+    CaptioningModel.infer returns them (prefix stripped, decoder.py:1004-1006).  search.kind == "trie": the model's
+    decoder is TrieAutoRegressiveBeamSearch(trie=trie) (trie_decoder.py)."""
     if feats is None:
         feats = visual_features(cfg, w, frames)
     B = feats.shape[0]
@@ -651,7 +755,9 @@ def caption(cfg: GitConfig, w: Weights, frames: Sequence[Tensor], search: Search
         assert prefix.shape[0] == 1 and B == 1, "reference asserts len(prefix)==1 (decoder.py:988)"
         start = prefix.long()
     step = make_step(cfg, w, feats, cached=cached)
-    if search.kind == "greedy":
+    if search.kind == "trie":
+        preds, lps = search_trie(start, step, cfg.eos, search.max_steps, trie)
+    elif search.kind == "greedy":
         preds, lps = search_autoregressive(start, step, cfg.eos, search.max_steps,
                                            search.beam_size, search.per_node_beam_size, trace=trace)
     else:

@@ -395,6 +395,58 @@ def run_scripted():
     np.savez_compressed(os.path.join(GOLD, "scripted_search.npz"), **out)
 
 
+# ---- trie-constrained greedy search (trie_decoder.py): scripted step + a small trie, reference vs oracle ----------
+# name: (P, V, eos, max_steps, seed, n_seqs, (min_len, max_len))   (batch 1: the class follows ROW 0's trie cursor only)
+SCRIPTED_TRIE = {
+    "s3_trie_plain": (1, 80, 2, 12, 21, 60, (3, 7)),
+    "s3_trie_prefix": (3, 80, 2, 14, 22, 80, (4, 9)),
+    "s3_trie_truncated": (1, 80, 2, 5, 23, 40, (7, 9)),       # max_steps cuts the trie path short
+    "s3_trie_single_path": (1, 80, 2, 10, 24, 1, (6, 6)),      # one allowed sequence
+    "s3_trie_eos_first": (1, 80, 2, 8, 25, 3, (1, 1)),         # every allowed sequence is [eos]: first-step early return
+    "s3_trie_repeat": (1, 12, 2, 10, 26, 200, (5, 8)),         # tiny vocabulary: the no-repeat rule meets valid tokens
+}
+
+
+def scripted_trie_sequences(seed: int, V: int, eos: int, n_seqs: int, len_range):
+    g = torch.Generator().manual_seed(1000 + seed)
+    seqs = []
+    for _ in range(n_seqs):
+        L = int(torch.randint(len_range[0], len_range[1] + 1, (1,), generator=g))
+        body = torch.randint(3, V, (L - 1,), generator=g).tolist()
+        seqs.append(body + [eos])
+    return seqs
+
+
+def run_scripted_trie():
+    _, D = import_reference()
+    from generativeimage2text import trie_decoder as TD
+    out = {}
+    for name, (P, V, eos, T, seed, n_seqs, len_range) in SCRIPTED_TRIE.items():
+        g = torch.Generator().manual_seed(100 + seed)
+        start = torch.randint(3, V, (1, P), generator=g)
+        step = scripted_step_factory(seed, V, eos)
+        seqs = scripted_trie_sequences(seed, V, eos, n_seqs, len_range)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref_dec = TD.TrieAutoRegressiveBeamSearch(eos_index=eos, max_steps=T, beam_size=1,
+                                                      trie=TD.TokenTrie.construct(seqs))
+            rp, rl = ref_dec.search(start, step)
+            op, ol = O.search_trie(start, step, eos, T, O.TokenTrie.construct(seqs))
+            un_p, _ = D.AutoRegressiveBeamSearch(eos_index=eos, max_steps=T, beam_size=1, per_node_beam_size=1,
+                                                 fix_missing_prefix=True).search(start, step)
+        assert rp.shape == op.shape and torch.equal(rp, op), (name, rp, op)
+        assert rl.shape == ol.shape and (rl - ol).abs().max().item() <= 1e-6 * rl.abs().max().item() + 1e-5, (name, rl, ol)
+        gen = rp[0, P:].tolist() if rp.shape[1] > 1 else rp[0].tolist()
+        allowed = any(gen == sq[:len(gen)] for sq in seqs)
+        assert allowed, (name, "the reference left the trie", gen)
+        print(f"[trie {name}] OK shape {tuple(rp.shape)} row0 {rp[0].tolist()} lp {rl.flatten().tolist()} "
+              f"(unconstrained greedy: {un_p[0].tolist()})")
+        out[name + ".start"] = start.numpy()
+        out[name + ".pred"] = rp.numpy()
+        out[name + ".logprob"] = rl.numpy()
+    np.savez_compressed(os.path.join(GOLD, "scripted_trie.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -407,6 +459,8 @@ def main():
         run_scripted()
     if args.only in (None, "sampling_filter"):
         write_sampling_filter_fixture()
+    if args.only in (None, "trie"):
+        run_scripted_trie()
     for name in CASES:
         if args.only is None or name in args.only.split(","):
             run_case(name)

@@ -765,3 +765,63 @@ def test_search_method_scripted(name):
                 D.GeneratorWithBeamSearch(eos_index=eos, max_steps=T, beam_size=k, per_node_beam_size=pn, length_penalty=lpn,
                                           repetition_penalty=MG.SCRIPTED_RP.get(name, 1.0)).search(start, ref_step)
         assert calls == ref_calls, (calls, ref_calls)
+
+
+# ---- trie-constrained greedy decoding (trie_decoder.py:27-257) -----------------------------------------------------
+@pytest.mark.parametrize("name", sorted(MG.SCRIPTED_TRIE))
+def test_device_trie_search_scripted(name):
+    """The device trie search (gitmi_set_trie + GITMI_SEARCH_TRIE behind decoder.search(start, step)) against the
+    reference's TrieAutoRegressiveBeamSearch.search on scripted `step` functions (goldens frozen from the reference)."""
+    from generativeimage2text_amd.model import TokenTrie, TrieAutoRegressiveBeamSearch
+    P, V, eos, T, seed, n_seqs, len_range = MG.SCRIPTED_TRIE[name]
+    gold = load_golden("scripted_trie")
+    start = torch.from_numpy(gold[name + ".start"])
+    step = MG.scripted_step_factory(seed, V, eos)
+    seqs = MG.scripted_trie_sequences(seed, V, eos, n_seqs, len_range)
+    dec = TrieAutoRegressiveBeamSearch(eos_index=eos, max_steps=T, beam_size=1, trie=TokenTrie.construct(seqs))
+    got_p, got_l = dec.search(start.cuda(), lambda rows: step(rows.cpu()).cuda())
+    exp_p, exp_l = gold[name + ".pred"], gold[name + ".logprob"]
+    assert got_p.shape == exp_p.shape, (got_p.shape, exp_p.shape)
+    assert np.array_equal(got_p.cpu().numpy(), exp_p), (got_p, exp_p)
+    assert np.allclose(got_l.cpu().numpy().reshape(exp_l.shape), exp_l, rtol=2e-6, atol=1e-4), (got_l, exp_l)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_model_with_trie_decoder_matches_oracle(precision):
+    """model(batch) with decoder = TrieAutoRegressiveBeamSearch (how the reference classifies with a caption model:
+    the answer is forced onto the token sequences of a vocabulary trie): every image of a batch gets what its own batch-1
+    reference call returns (f32: ids bit for bit; bf16: an id may differ only where the constrained choice was a near-tie,
+    which these seeded cases do not contain), and every answer is a path of the trie."""
+    from oracle import git_oracle as O
+    from generativeimage2text_amd.model import CaptioningModel, TokenTrie, TrieAutoRegressiveBeamSearch
+    cfg = O.CONFIGS["TINY"]
+    w = O.make_weights(cfg, seed=91, tie_output=False, successor=2.0)
+    frames = O.make_images(cfg, 3, 1, seed=7)
+    g = torch.Generator().manual_seed(4)
+    seqs = []
+    for _ in range(120):
+        L = int(torch.randint(3, 9, (1,), generator=g))
+        seqs.append(torch.randint(3, cfg.vocab, (L - 1,), generator=g).tolist() + [cfg.eos])
+    T = 12
+    want = []
+    with torch.no_grad():
+        for i in range(3):
+            ref = O.caption(cfg, w, [frames[0][i:i + 1]], O.SearchConfig("trie", T, 1, 1), cached=True,
+                            trie=O.TokenTrie.construct(seqs))
+            want.append((ref["predictions"][0].tolist(), float(ref["logprobs"].flatten()[0])))
+    dec = TrieAutoRegressiveBeamSearch(eos_index=cfg.eos, max_steps=T, beam_size=1, trie=TokenTrie.construct(seqs))
+    model = CaptioningModel(cfg, dec, precision=precision, max_batch=3)
+    model.load_state_dict(w)
+    out = model({"image": frames[0].cuda()})
+    preds, lps = out["predictions"].cpu(), out["logprobs"].cpu()
+    for i in range(3):
+        row = preds[i].tolist()
+        Lw = len(want[i][0])
+        assert row[:Lw] == want[i][0] and all(t == cfg.eos for t in row[Lw:]), (precision, i, row, want[i][0])
+        gen = want[i][0][1:]
+        assert any(gen == sq[:len(gen)] for sq in seqs)
+        if precision == "f32":
+            assert abs(float(lps[i]) - want[i][1]) < 2e-6 * abs(want[i][1]) + 1e-3, (float(lps[i]), want[i][1])
+    # a second call (graph replay) resets the cursors
+    out2 = model({"image": frames[0].cuda()})
+    assert torch.equal(out2["predictions"].cpu(), preds)

@@ -613,6 +613,38 @@ def test_search_methods_host_loop(monkeypatch):
     model._SEARCH_ENGINES.clear()
 
 
+def test_token_trie_mirror_matches_the_oracle_restatement():
+    """model.TokenTrie (the reference's interface, trie_decoder.py:224-257) and its CSR export for gitmi_set_trie."""
+    from oracle import git_oracle as O
+    seqs = [[5, 6, 2], [5, 7, 9, 2], [8, 2], [5, 6, 4, 2], [5, 6, 2]]
+    a, b = model.TokenTrie.construct(seqs), O.TokenTrie.construct(seqs)
+    assert a.get_curr_valid() == b.get_curr_valid() == [5, 8]
+    assert a.get_valid([5]) == b.get_valid([5]) == [6, 7] and a.get_valid([5, 6]) == [2, 4] and a.get_valid([9]) == []
+    a.move(5); a.move(6)
+    assert a.get_curr_valid() == [2, 4]
+    a.reset()
+    assert a.get_curr_valid() == [5, 8]
+    with pytest.raises(AssertionError):
+        a.move(77)
+    off, tok, node = a.csr()
+    bo, bt, bn = b.csr()
+    assert off == bo.tolist() and tok == bt.tolist() and node == bn.tolist()
+    # CSR walk == dictionary walk
+    cur = 0
+    for t in [5, 7, 9, 2]:
+        edges = range(off[cur], off[cur + 1])
+        cur = next(node[e] for e in edges if tok[e] == t)
+    assert off[cur + 1] == off[cur]                                       # [SEP] is a leaf
+
+    class Tok:
+        sep_token_id = 2
+
+        def __call__(self, text, padding=None, add_special_tokens=False):
+            return {"input_ids": [10 + len(w) for w in text.split()]}
+    trie = model.get_trie(Tok(), texts=["a bb", "a ccc", "dddd"])
+    assert trie.get_curr_valid() == [11, 14] and trie.get_valid([11]) == [12, 13] and trie.get_valid([14]) == [2]
+
+
 def test_header_is_plain_c_and_links_against_the_library(tmp_path):
     """include/gitmi.h is a C header (C99, no C++ or HIP types in any signature): a C translation unit that includes it
     and takes the address of every declared entry point compiles with gcc and links against libgitmi.so."""
