@@ -352,6 +352,9 @@ __global__ __launch_bounds__(256, 2) void attn_full_mfma_short_kernel(AttnFullAr
                 sacc[u][st_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[u][0], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 sacc[u][st_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[u][1], sacc[u][st_], 0, 0, 0);
             }
+            // many sub-tiles (GIT_LARGE: 17): keep the scheduler from hoisting every K fragment load to the top of the
+            // unrolled loop -- with 136 score registers live that spilled
+            if constexpr (NSUB > 13) { if (st_ % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
         }
         // ---- softmax: the lane holds keys st*16 + lg*4 + r of its query; only the last sub-tile can hold keys >= N
         float inv_l[NT];
@@ -381,6 +384,16 @@ __global__ __launch_bounds__(256, 2) void attn_full_mfma_short_kernel(AttnFullAr
             psum += __shfl_xor(psum, 32, 64);
             inv_l[u] = 1.0f / psum;
         }
+        // ---- P packed to bf16 right away: halves the registers that stay live across the second product (the 17-sub-tile
+        // instantiation of GIT_LARGE's 257 tokens spilled 36 B/lane with fp32 scores held until their block's turn)
+        uint32_t pk2[NT][NSUB][2];
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int st_ = 0; st_ < NSUB; ++st_) {
+                pk2[u][st_][0] = pack2bf(sacc[u][st_][0], sacc[u][st_][1]);
+                pk2[u][st_][1] = pack2bf(sacc[u][st_][2], sacc[u][st_][3]);
+            }
         // ---- O^T = V^T . P^T ------------------------------------------------------------------
         f32x4_t o_acc[NT][4];
 #pragma unroll
@@ -393,12 +406,12 @@ __global__ __launch_bounds__(256, 2) void attn_full_mfma_short_kernel(AttnFullAr
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
                 union { bf16x8_t v; uint32_t w[4]; } pk;
-                pk.w[0] = pack2bf(sacc[u][2 * blk][0], sacc[u][2 * blk][1]);
-                pk.w[1] = pack2bf(sacc[u][2 * blk][2], sacc[u][2 * blk][3]);
+                pk.w[0] = pk2[u][2 * blk][0];
+                pk.w[1] = pk2[u][2 * blk][1];
                 const bool has1 = 2 * blk + 1 < NSUB;              // odd NSUB: the last block has one sub-tile
                 const int s1 = has1 ? 2 * blk + 1 : 0;
-                pk.w[2] = has1 ? pack2bf(sacc[u][s1][0], sacc[u][s1][1]) : 0u;
-                pk.w[3] = has1 ? pack2bf(sacc[u][s1][2], sacc[u][s1][3]) : 0u;
+                pk.w[2] = has1 ? pk2[u][s1][0] : 0u;
+                pk.w[3] = has1 ? pk2[u][s1][1] : 0u;
                 pf[u] = pk.v;
             }
 #pragma unroll

@@ -75,7 +75,8 @@ template <int IMM> __device__ __forceinline__ f32x4_t asm_load_f32x4(const float
 
 // MH = rows of an activation half tile: 128 -> 256x256 tile, 96 -> 192x256 tile (kernels_gemm10.hip)
 // S  = ring slots (10: all 160 KiB; 8: the 128 KiB / four-half-tiles-in-flight schedule of kernels_gemm10.hip, for A/B)
-template <typename TOut, int ACT, int MH, int S>
+// DBG (measurement builds, tools/gemm_p9_diag.py): 1 no output stores, 2 no quadrant output at all (results are wrong)
+template <typename TOut, int ACT, int MH, int S, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     constexpr int BM = 2 * MH, MI = MH / 32;
     constexpr int D = S - 2;                           // issue distance in phases
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
     };
     auto flush_quadrant = [&](auto qm_c, auto qn_c) {
         constexpr int qm = decltype(qm_c)::value, qn = decltype(qn_c)::value;
+        if constexpr (DBG & 2) return;
         const int col0 = en0 + qn * 128 + wc * 32 + lg * 4;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -250,7 +252,8 @@ __global__ __launch_bounds__(512) void gemm_p9_kernel(GemmArgs g) {
                 uint2 t2;
                 t2.x = pack2_16<TOut>(v[0], v[1]);
                 t2.y = pack2_16<TOut>(v[2], v[3]);
-                if (m < g.M) *reinterpret_cast<uint2*>(cp + j * 16) = t2;
+                if constexpr (DBG & 1) asm volatile("" ::"v"(t2.x), "v"(t2.y));
+                else if (m < g.M) *reinterpret_cast<uint2*>(cp + j * 16) = t2;
                 acc[qm][qn][j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -366,7 +369,8 @@ static void launch_p9_t(const GemmArgs& g, int nwg, hipStream_t s) {
 }
 
 // dbg bits (A/B, tests): 64 / 128 force the 192- / 256-row tile; 512 the 8-slot ring (128 KiB, four half tiles in flight);
-// bits 12.. : workgroups per XCD (default 32 = one per CU)
+// bits 12.. : workgroups per XCD (default 32 = one per CU); 1 / 2 (bf16, no activation, 256-row tile, 10 slots only):
+// measurement builds without output stores / without any quadrant output
 hipError_t launch_gemm_p9(GemmArgs g, hipStream_t s) {
     // the 192-row tile also on a tie when an activation is fused: the 256-row tile + activation temporaries does not fit
     // the register file without scratch, and hipcc waits vmcnt(0) for its scratch reloads -- a drained DMA queue per tile
@@ -384,6 +388,11 @@ hipError_t launch_gemm_p9(GemmArgs g, hipStream_t s) {
     const int nwg = 8 * wpx;
     g.nwg = nwg;
     const bool f16 = g.out_f16 != 0;
+    if ((g.dbg & 3) && !f16 && g.act == GITMI_ACT_NONE && mh == 128 && !ring8) {        // measurement builds
+        if (g.dbg & 2) hipLaunchKernelGGL((gemm_p9_kernel<bf16_t, GITMI_ACT_NONE, 128, 10, 2>), dim3(nwg), dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((gemm_p9_kernel<bf16_t, GITMI_ACT_NONE, 128, 10, 1>), dim3(nwg), dim3(512), 0, s, g);
+        return hipGetLastError();
+    }
 #define GITMI_P9(MHH, SS)                                             \
     do {                                                              \
         if (f16) launch_p9_t<f16_t, MHH, SS>(g, nwg, s);              \
