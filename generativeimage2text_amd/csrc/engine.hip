@@ -338,6 +338,7 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     if (const char* env = getenv("GITMI_ADDLN")) e->addln = !e->f32 && atoi(env) != 0;
     if (const char* env = getenv("GITMI_STREAM_F16")) e->stream_f16 = !e->f32 && atoi(env) != 0;
     if (const char* env = getenv("GITMI_GEMM_IMPL")) set_gemm_impl(atoi(env));
+    if (const char* env = getenv("GITMI_P8_SCHED")) set_gemm_p8_schedule(atoi(env));
     if (attn_decode_configure() != hipSuccess) { delete e; return fail("hipFuncSetAttribute failed"); }
     *out = e;
     return 0;

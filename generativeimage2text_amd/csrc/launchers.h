@@ -23,6 +23,7 @@ hipError_t launch_gemm_ring(GemmArgs g, bool out_f32, hipStream_t s);   // 256x1
 hipError_t launch_gemm_ring256(GemmArgs g, bool out_f32, hipStream_t s); // 256x256x32, 8 waves of 128x64, 4-stage ring
 hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s);     // 256x256x64, half-tile pipeline, staggered wave groups
 bool gemm_p8_supports(const GemmArgs& g);
+void set_gemm_p8_schedule(int sched);   // 0: two K-tile buffers / 4 phases (round 2); 1: 10-slot LDS ring, 4 phases; 2: ring, 2 merged phases
 // persistent form of the p8 tile: 16-bit outputs (bf16, or fp16 with out_f16), bias + activation, no residual
 hipError_t launch_gemm_p9(GemmArgs g, hipStream_t s);
 bool gemm_p9_supports(const GemmArgs& g);

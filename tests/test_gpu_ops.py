@@ -104,7 +104,9 @@ def test_add_layernorm_fused(rows, D, sdt):
 
 @pytest.mark.parametrize("M,N,K", [(1000, 512, 128), (777, 256, 192), (2100, 768, 768), (515, 1024, 3072)])
 @pytest.mark.parametrize("act", [0, 1, 2])
-@pytest.mark.parametrize("tile", [9 | (128 << 8), 9 | (64 << 8)])          # forced 256x256 / 192x256 tile
+@pytest.mark.parametrize("tile", [9 | (128 << 8), 9 | (64 << 8),           # forced 256x256 / 192x256 tile
+                                  9 | ((128 | 1024) << 8), 9 | ((64 | 1024) << 8),      # ... on the 10-slot LDS ring
+                                  9 | ((128 | 2048) << 8), 9 | ((64 | 2048) << 8)])     # ... ring + two merged phases per K tile
 def test_gemm_bf16_p8_variant(M, N, K, act, tile):
     """The 256x256 half-tile pipeline kernel (kernels_gemm10.hip), forced: shortest K (2 and 3 K tiles), ragged M,
     every epilogue; it must also equal the 256x128 ring kernel bit for bit (same K order)."""
