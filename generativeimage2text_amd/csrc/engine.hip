@@ -1221,9 +1221,9 @@ static int sample_candidates(gitmi_engine* e, const float* logits, int ldl, int 
     const float temp = sp.temperature > 0 ? (float)sp.temperature : 1.0f;
     HIPCK(launch_sample_rows(logits, ldl, e->ss.V, R, temp, sp.top_k, (float)sp.top_p, e->ss.pn, sp.seed, step,
                              e->part_val, e->part_idx, e->part_lse, nullptr, e->ss.ids[e->ss_cur], e->ss.T, step,
-                             rep_penalty_of(e), s));
+                             rep_penalty_of(e), row_topm_slots(e->ss.pn), s));
     cands->part_val = e->part_val; cands->part_idx = e->part_idx; cands->part_lse = e->part_lse;
-    cands->nparts = 1; cands->slots = e->ss.pn;
+    cands->nparts = 1; cands->slots = row_topm_slots(e->ss.pn);
     return 0;
 }
 
@@ -1817,7 +1817,7 @@ extern "C" int gitmi_op_sample_rows(const float* logits, int R, int V, float tem
     float2* lse = nullptr;
     HIPCK(hipMalloc((void**)&lse, (size_t)R * sizeof(float2)));
     hipError_t err = launch_sample_rows(logits, V, V, R, temperature, top_k, top_p, ndraw, seed, step, draw_logprob, draw_token,
-                                        lse, filtered_out, nullptr, 0, 0, 0.f, (hipStream_t)stream);
+                                        lse, filtered_out, nullptr, 0, 0, 0.f, ndraw, (hipStream_t)stream);
     if (err == hipSuccess) err = hipStreamSynchronize((hipStream_t)stream);
     hipFree(lse);
     HIPCK(err);

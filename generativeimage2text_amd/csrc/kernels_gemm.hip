@@ -304,7 +304,7 @@ hipError_t launch_gemm(const GemmArgs& g_in, bool in_f32, bool out_f32, hipStrea
         // fp16 residual-stream rows out (and in, as the residual): the p8 kernel for the large-M phases, the generic
         // kernel otherwise (the ring / direct-to-LDS generations have no fp16 epilogue)
         if (in_f32 || out_f32 || g.K % 64 != 0) return hipErrorInvalidValue;
-        if ((g_gemm_impl == 11 || (g_gemm_impl == -1 && g.M > 512)) && !g.res && gemm_p9_supports(g)) return launch_gemm_p9(g, s);
+        if (g_gemm_impl == 11 && !g.res && gemm_p9_supports(g)) return launch_gemm_p9(g, s);
         if (g_gemm_impl != 0 && g.M > 512 && gemm_dlds_supported(g, false, false) && (!g.res || g.ldr % 8 == 0) &&
             gemm_p8_supports(g))
             return launch_gemm_p8(g, false, s);

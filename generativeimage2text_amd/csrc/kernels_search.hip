@@ -194,7 +194,7 @@ __global__ __launch_bounds__(SMP_NT) void sample_rows_kernel(const float* __rest
                                                              float* __restrict__ part_val, int* __restrict__ part_idx,
                                                              float2* __restrict__ part_lse, float* __restrict__ filtered_out,
                                                              const int* __restrict__ ids, int ld_ids, int cur_len,
-                                                             float rep_penalty) {
+                                                             float rep_penalty, int stride) {
     __shared__ int s_hist[HIST_SLOTS];
     __shared__ float sh_f[SMP_NT / 64];
     __shared__ int sh_i[SMP_NT / 64];
@@ -337,15 +337,20 @@ __global__ __launch_bounds__(SMP_NT) void sample_rows_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < SMP_PER; ++i) {
             if (tid + i * SMP_NT == bi) {
-                part_val[(size_t)r * ndraw + d] = xv[i] - lse;
-                part_idx[(size_t)r * ndraw + d] = bi;
+                part_val[(size_t)r * stride + d] = xv[i] - lse;
+                part_idx[(size_t)r * stride + d] = bi;
                 gk[i] = -INFINITY;
             }
         }
         if (bi == 0x7fffffff && tid == 0) {       // fewer kept tokens than draws (cannot happen with min_tokens_to_keep = 2 <= ndraw ...)
-            part_val[(size_t)r * ndraw + d] = -INFINITY;
-            part_idx[(size_t)r * ndraw + d] = 0;
+            part_val[(size_t)r * stride + d] = -INFINITY;
+            part_idx[(size_t)r * stride + d] = 0;
         }
+    }
+    // list entries beyond the draws (the search step reads lists of 1 / 2 / 4 / 8 / 16 entries)
+    for (int d = ndraw + tid; d < stride; d += SMP_NT) {
+        part_val[(size_t)r * stride + d] = -INFINITY;
+        part_idx[(size_t)r * stride + d] = 0x7fffffff;
     }
 }
 
@@ -465,15 +470,10 @@ constexpr int SS_CMAX = 16;       // candidates per row (beam_size * per_node_be
 __device__ __forceinline__ int ids_at(const SearchState& st, int buf, int r, int s) { return st.ids[buf][(size_t)r * st.T + s]; }
 
 // grid = B (one workgroup per sentence), block = 256.  cur_len = tokens currently in ids (before appending).
-template <typename TOut>
+// SLOTS = entries per partial list (compile time: the per-lane lists live in registers and are popped by static shifts)
+template <typename TOut, int SLOTS>
 __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int src, int cur_len, StepCands in,
                                                           EmbedArgs em) {
-    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];   // sorted partial lists: [256][slots] values, then indices
-    float* s_hv = reinterpret_cast<float*>(dyn_lds);
-    int* s_hi = reinterpret_cast<int*>(dyn_lds + (size_t)256 * in.slots * sizeof(float));
-    __shared__ float s_red[8];
-    __shared__ int s_redi[8];
-    __shared__ int s_owner;
     __shared__ float c_val[SS_KMAX][SS_CMAX];  // merged top-M log-probabilities per beam row
     __shared__ int c_idx[SS_KMAX][SS_CMAX];
     __shared__ int sel_src[SS_KMAX], sel_word[SS_KMAX];
@@ -492,70 +492,74 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
 
     if (tid == 0) s_hyp_row = -1;
 
-    // ---- phase A: merged top-M log-probabilities of every beam row of the sentence --------------------------
+    // ---- phase A: merged top-M log-probabilities of every beam row of the sentence.  ONE WAVE PER ROW (rows j = wave,
+    // wave + 4): a lane holds the sorted partial lists of parts lane, lane + 64, lane + 128, lane + 192 in registers, a
+    // round = lane-local best head -> wave arg-max (value, then lower token) -> the owner pops its head.  No workgroup
+    // barrier inside (round 2: the four beams of a sentence were merged one after the other with three __syncthreads
+    // per round: 63 us per step for beam 4; profiles/r02_d_beam4_kernel_stats.txt).
     if (!forced) {
-        for (int j = 0; j < k; ++j) {
+        for (int j = wave; j < k; j += 4) {
             const int r = b * k + j;
             if (st.kind == 0 && first && j > 0) break;     // the first step expands beam 0 only (decoder.py:257-271)
             const int last = ids_at(st, src, r, cur_len - 1);
             if (st.kind == 0 && !first && last == st.eos) {
                 // one-hot distribution on EOS (decoder.py:300-310, 347-351): log-prob 0, everything else -inf
-                if (tid < M) {
-                    c_val[j][tid] = tid == 0 ? 0.f : -INFINITY;
-                    c_idx[j][tid] = tid == 0 ? st.eos : (tid - 1 < st.eos ? tid - 1 : tid);
+                if (lane < M) {
+                    c_val[j][lane] = lane == 0 ? 0.f : -INFINITY;
+                    c_idx[j][lane] = lane == 0 ? st.eos : (lane - 1 < st.eos ? lane - 1 : lane);
                 }
-                __syncthreads();
                 continue;
             }
-            // log-sum-exp over the parts (fixed order: part index -> lane/wave tree)
+            // this lane's lists + the log-sum-exp over the parts (fixed order: part index -> lane tree)
+            float hv[4][SLOTS];
+            int hi[4][SLOTS];
             float pm = -INFINITY, ps = 0.f;
-            for (int p = tid; p < in.nparts; p += 256) {          // nparts <= 256 (checked by the launcher)
-                const float2 ml = in.part_lse[(size_t)r * in.nparts + p];
-                if (ml.x > pm) { ps = ps * __expf(pm - ml.x) + ml.y; pm = ml.x; }
-                else if (ml.x != -INFINITY) ps += ml.y * __expf(ml.x - pm);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = lane + 64 * q;
+                const bool ok = p < in.nparts;
+                if (ok) {
+                    const float2 ml = in.part_lse[(size_t)r * in.nparts + p];
+                    if (ml.x > pm) { ps = ps * __expf(pm - ml.x) + ml.y; pm = ml.x; }
+                    else if (ml.x != -INFINITY) ps += ml.y * __expf(ml.x - pm);
+                }
+                const size_t base = ((size_t)r * in.nparts + (ok ? p : 0)) * SLOTS;
+#pragma unroll
+                for (int e = 0; e < SLOTS; ++e) {
+                    hv[q][e] = ok ? in.part_val[base + e] : -INFINITY;
+                    hi[q][e] = ok ? in.part_idx[base + e] : 0x7fffffff;
+                }
             }
-            float bm = wave_max(pm);
-            if (lane == 0) s_red[wave] = bm;
-            __syncthreads();
-            bm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-            float part = pm == -INFINITY ? 0.f : ps * __expf(pm - bm);
-            part = wave_sum(part);
-            if (lane == 0) s_red[4 + wave] = part;
-            // heads of this thread's part (parts beyond 256 are folded in by the owning thread below)
-            const int slots = in.slots;
-            for (int q = 0; q < slots; ++q) { s_hv[tid * slots + q] = -INFINITY; s_hi[tid * slots + q] = 0x7fffffff; }
-            if (tid < in.nparts) {
-                const size_t base = ((size_t)r * in.nparts + tid) * slots;
-                for (int q = 0; q < slots; ++q) { s_hv[tid * slots + q] = in.part_val[base + q]; s_hi[tid * slots + q] = in.part_idx[base + q]; }
-            }
-            __syncthreads();
-            const float lse = bm + logf(s_red[4] + s_red[5] + s_red[6] + s_red[7]);
-            int head = 0;
+            const float bm = wave_max(pm);
+            const float part = wave_sum(pm == -INFINITY ? 0.f : ps * __expf(pm - bm));
+            const float lse = bm + logf(part);
             for (int round = 0; round < M; ++round) {
-                float v = head < slots ? s_hv[tid * slots + head] : -INFINITY;
-                int id = head < slots ? s_hi[tid * slots + head] : 0x7fffffff;
-                int who = tid;
+                float v = hv[0][0];
+                int id = hi[0][0], who = 0;
+#pragma unroll
+                for (int q = 1; q < 4; ++q)
+                    if (hv[q][0] > v || (hv[q][0] == v && hi[q][0] < id)) { v = hv[q][0]; id = hi[q][0]; who = q; }
+                int own = lane;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
                     const float ov = __shfl_xor(v, o, 64);
                     const int oi = __shfl_xor(id, o, 64);
-                    const int ow = __shfl_xor(who, o, 64);
-                    if (ov > v || (ov == v && oi < id)) { v = ov; id = oi; who = ow; }
+                    const int ow = __shfl_xor(own, o, 64);
+                    if (ov > v || (ov == v && oi < id)) { v = ov; id = oi; own = ow; }
                 }
-                if (lane == 0) { s_part[wave] = v; s_redi[wave] = id; s_redi[4 + wave] = who; }
-                __syncthreads();
-                if (tid == 0) {
-                    float bv = s_part[0]; int bi = s_redi[0], bw = s_redi[4];
+                if (lane == 0) {
+                    c_val[j][round] = v - lse;
+                    c_idx[j][round] = id == 0x7fffffff ? 0 : id;
+                }
+                if (own == lane) {                          // pop the winner's head (static shifts)
 #pragma unroll
-                    for (int w = 1; w < 4; ++w)
-                        if (s_part[w] > bv || (s_part[w] == bv && s_redi[w] < bi)) { bv = s_part[w]; bi = s_redi[w]; bw = s_redi[4 + w]; }
-                    c_val[j][round] = bv - lse;
-                    c_idx[j][round] = bi == 0x7fffffff ? 0 : bi;
-                    s_owner = bw;
+                    for (int q = 0; q < 4; ++q)
+                        if (q == who) {
+#pragma unroll
+                            for (int e = 0; e + 1 < SLOTS; ++e) { hv[q][e] = hv[q][e + 1]; hi[q][e] = hi[q][e + 1]; }
+                            hv[q][SLOTS - 1] = -INFINITY; hi[q][SLOTS - 1] = 0x7fffffff;
+                        }
                 }
-                __syncthreads();
-                if (tid == s_owner) ++head;
-                __syncthreads();
             }
         }
     }
@@ -863,13 +867,14 @@ hipError_t launch_row_topm(const float* logits, int ldl, int V, const int* ids, 
 hipError_t launch_sample_rows(const float* logits, int ldl, int V, int R, float temperature, int top_k, float top_p,
                               int ndraw, unsigned long long seed, int step, float* part_val, int* part_idx,
                               float2* part_lse, float* filtered_out, const int* ids, int ld_ids, int cur_len,
-                              float rep_penalty, hipStream_t s) {
+                              float rep_penalty, int stride, hipStream_t s) {
     if (R <= 0) return hipSuccess;
+    if (stride < ndraw) return hipErrorInvalidValue;
     if (rep_penalty != 0.f && rep_penalty != 1.f && ids && cur_len > HIST_SLOTS / 2) return hipErrorInvalidValue;
     if (V > SMP_NT * SMP_PER || V < 2 || ndraw < 1 || ndraw > SS_CMAX || !(temperature > 0.f)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sample_rows_kernel, dim3(R), dim3(SMP_NT), 0, s, logits, ldl, V, 1.0f / temperature, top_k, top_p, ndraw,
                        (unsigned int)(seed & 0xffffffffu), (unsigned int)(seed >> 32), step, part_val, part_idx, part_lse,
-                       filtered_out, ids, ld_ids, cur_len, rep_penalty);
+                       filtered_out, ids, ld_ids, cur_len, rep_penalty, stride);
     return hipGetLastError();
 }
 
@@ -888,9 +893,20 @@ hipError_t launch_search_step(const SearchState& st, int src, int cur_len, const
     if (st.k > SS_KMAX || in.slots < 1 || in.slots > SS_CMAX || in.nparts < 1 || in.nparts > 256) return hipErrorInvalidValue;
     if (st.k * st.pn > SS_CMAX) return hipErrorInvalidValue;
     if (em.words && (em.D > 1024 || (em.D & 3))) return hipErrorInvalidValue;
-    const size_t lds = (size_t)256 * in.slots * 8;
-    if (t_is_f32) hipLaunchKernelGGL(search_step_kernel<float>, dim3(st.B), dim3(256), lds, s, st, src, cur_len, in, em);
-    else hipLaunchKernelGGL(search_step_kernel<bf16_t>, dim3(st.B), dim3(256), lds, s, st, src, cur_len, in, em);
+#define GITMI_SSTEP(SL)                                                                                               \
+    do {                                                                                                                \
+        if (t_is_f32) hipLaunchKernelGGL((search_step_kernel<float, SL>), dim3(st.B), dim3(256), 0, s, st, src, cur_len, in, em); \
+        else hipLaunchKernelGGL((search_step_kernel<bf16_t, SL>), dim3(st.B), dim3(256), 0, s, st, src, cur_len, in, em);          \
+    } while (0)
+    switch (in.slots) {
+        case 1: GITMI_SSTEP(1); break;
+        case 2: GITMI_SSTEP(2); break;
+        case 4: GITMI_SSTEP(4); break;
+        case 8: GITMI_SSTEP(8); break;
+        case 16: GITMI_SSTEP(16); break;
+        default: return hipErrorInvalidValue;       // list lengths are 1, 2, 4, 8, 16 (vocab_mtop_slots / row_topm_slots) or pn
+    }
+#undef GITMI_SSTEP
     return hipGetLastError();
 }
 hipError_t launch_search_init(const SearchState& st, hipStream_t s) {

@@ -158,7 +158,7 @@ int row_topm_slots(int M);
 hipError_t launch_sample_rows(const float* logits, int ldl, int V, int R, float temperature, int top_k, float top_p,
                               int ndraw, unsigned long long seed, int step, float* part_val, int* part_idx,
                               float2* part_lse, float* filtered_out, const int* ids, int ld_ids, int cur_len,
-                              float rep_penalty, hipStream_t s);
+                              float rep_penalty, int stride, hipStream_t s);      // stride >= ndraw: entries of a row's list
 // token trie on the device (CSR: the children of node n are edges child_off[n] .. child_off[n + 1]) + one cursor per sentence
 struct TrieArgs {
     const int* child_off; const int* child_tok; const int* child_node;
