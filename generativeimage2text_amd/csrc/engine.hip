@@ -161,13 +161,6 @@ struct gitmi_engine {
     // rounding.  Measured (profiles/r03_a_bench_f16_*.json, interleaved A/B): encode + prefill 5.31 -> 5.03 ms,
     // 9.48k -> 9.82k captions/s, logit error 0.01118 -> 0.01094, the same 50 of 64 rows identical to the reference.
     bool stream_f16 = false;
-    // bf16 mode: the N = hidden GEMMs of the image encoder and the prefill (out-proj, c_proj, visual projection, the
-    // decoder's attention-output / FFN-output dense) write their result as plain fp16 rows (`v_y` / `p_y`) and the
-    // LayerNorm kernel that follows adds them to the residual stream (launch_add_layernorm) -- no read-modify-write of
-    // the stream inside a GEMM epilogue, every large GEMM of the pass has the same 16-bit epilogue and runs on the
-    // persistent kernel (kernels_gemm11.hip).  GITMI_ADDLN=0: the round-2 schedule (residual added in the GEMM epilogue).
-    bool addln = false;
-    void* v_y = nullptr;                // fp16 [Mv, D] branch output of the image encoder
     hipEvent_t gev[3] = {nullptr, nullptr, nullptr};
     // serving schedule: this context's image encoder starts only after `enc_after`'s has finished (at most one encoder
     // in flight on the device; decode chains of the other contexts fill in beside it)
@@ -268,26 +261,6 @@ static int ln_stream(gitmi_engine* e, hipStream_t s, const void* x, int ldx, con
     return 0;
 }
 
-// addln schedule: GEMM whose output is a BRANCH result, written as fp16 rows (bias added, no residual)
-static int gemm_branch(gitmi_engine* e, hipStream_t s, const void* A, int lda, const void* W, const float* bias, void* Y,
-                       int ldy, int M, int N, int K, int tag) {
-    GemmArgs g{};
-    g.A = A; g.W = W; g.bias = bias; g.res = nullptr; g.C = Y;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldy; g.ldr = 0; g.act = 0;
-    g.out_f16 = 1;
-    SpanGuard sp(e, s, tag, 2.0 * (double)M * (double)N * (double)K);
-    HIPCK(launch_gemm(g, false, false, s));
-    return 0;
-}
-// addln schedule: x_new = x + y (-> x_out), LayerNorm(x_new) -> operand rows y_t [+ stream copy y_s]
-static int add_ln(gitmi_engine* e, hipStream_t s, const void* x, int ldx, const void* y, int ldy, void* x_out, const float* gamma,
-                  const float* beta, float eps, const float* add_after, void* y_t, int ld_t, void* y_s, int ld_s, int rows, int D,
-                  int map_n_in = 0, int map_n_out = 0, int map_off = 0, float* y32 = nullptr, int ld32 = 0) {
-    HIPCK(launch_add_layernorm(x, e->stream_f16, ldx, y, ldy, x_out, ldx, gamma, beta, eps, add_after, y_t, ld_t, y_s, ld_s, y32,
-                               ld32, rows, D, map_n_in, map_n_out, map_off, s));
-    return 0;
-}
-
 // ---------------------------------------------------------------------------------------
 extern "C" int gitmi_abi_version(void) { return GITMI_ABI_VERSION; }
 extern "C" const char* gitmi_last_error(void) { return g_err; }
@@ -335,10 +308,8 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     if (const char* env = getenv("GITMI_DGEMM_DBG")) e->dgemm_dbg = atoi(env);
     if (const char* env = getenv("GITMI_SKINNY")) e->skinny = atoi(env) != 0;
     e->stream_f16 = !e->f32;
-    if (const char* env = getenv("GITMI_ADDLN")) e->addln = !e->f32 && atoi(env) != 0;
     if (const char* env = getenv("GITMI_STREAM_F16")) e->stream_f16 = !e->f32 && atoi(env) != 0;
     if (const char* env = getenv("GITMI_GEMM_IMPL")) set_gemm_impl(atoi(env));
-    if (const char* env = getenv("GITMI_P8_SCHED")) set_gemm_p8_schedule(atoi(env));
     if (attn_decode_configure() != hipSuccess) { delete e; return fail("hipFuncSetAttribute failed"); }
     *out = e;
     return 0;
@@ -484,7 +455,6 @@ static int alloc_workspaces(gitmi_engine* e) {
     RCK(dev_alloc(e, &e->v_qkv, Mv * 3 * D * esz));
     RCK(dev_alloc(e, &e->v_ctx, Mv * D * esz));
     RCK(dev_alloc(e, &e->v_u, Mv * 4 * D * esz));
-    RCK(dev_alloc(e, &e->v_y, Mv * D * 2));
     RCK(dev_alloc(e, &e->feats, Mp * D * esz));
     RCK(dev_alloc_t(e, &e->p_y, Mp * d));
     RCK(dev_alloc_t(e, &e->p_hf, Mp * d));
@@ -542,6 +512,7 @@ static int alloc_workspaces(gitmi_engine* e) {
     RCK(dev_alloc_t(e, &s.stop, (size_t)c.max_batch));
     RCK(dev_alloc_t(e, &s.early, (size_t)c.max_batch));
     RCK(dev_alloc_t(e, &s.info, 4));
+    RCK(dev_alloc_t(e, &s.len_norm, (size_t)T + 1));
     RCK(dev_alloc_t(e, &e->start_dev, (size_t)c.max_batch * T));
     RCK(dev_alloc_t(e, &e->plen_dev, (size_t)c.max_batch));
     RCK(dev_alloc_t(e, &e->img_of_dev, (size_t)c.max_batch));
@@ -766,7 +737,7 @@ extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
     if (!src->finalized) return fail("gitmi_clone: source weights not finalized");
     HIPCK(hipSetDevice(src->device));
     gitmi_engine* e = new gitmi_engine();
-    e->cfg = src->cfg; e->device = src->device; e->f32 = src->f32; e->esz = src->esz; e->stream_f16 = src->stream_f16; e->addln = src->addln;
+    e->cfg = src->cfg; e->device = src->device; e->f32 = src->f32; e->esz = src->esz; e->stream_f16 = src->stream_f16;
     e->attn_impl = src->attn_impl; e->Kp = src->Kp; e->Kp_pad = src->Kp_pad;
     // a clone starts at the native resolution (its own gitmi_set_image_shape state and resized table)
     e->N_nat = e->N = src->N_nat; e->g_nat = e->gh = e->gw = src->g_nat; e->H = e->W = src->cfg.image_size;
@@ -831,74 +802,40 @@ static int encode_frames_impl(gitmi_engine* e, const float* const* frames, int F
     RCK(gemm(e, s, e->patches, e->Kp_pad, e->conv_w, nullptr, nullptr, 0, e->patch_out, D, true, BI * g2, D, e->Kp_pad, 0,
              TAG_GEMM_VIT));
     HIPCK(launch_vit_assemble_ln(e->patch_out, e->cls, e->pos_cur, e->lnpre_g, e->lnpre_b, 1e-5f, e->v_x, e->stream_f16, BI, N, D, s));
-    const size_t ssz = e->stream_f16 ? 2 : 4;                      // bytes per element of a residual-stream row
-    if (e->addln) {
-        // x lives in v_x; every N = D GEMM leaves its branch result in v_y (fp16) and the LayerNorm that follows adds it
-        RCK(ln_stream(e, s, e->v_x, D, e->vit[0].ln1g, e->vit[0].ln1b, 1e-5f, e->v_h, D, nullptr, 0, M, D));
-        for (int l = 0; l < c.vit_layers; ++l) {
-            const VitLayerW& L = e->vit[l];
-            RCK(gemm(e, s, e->v_h, D, L.wqkv, L.bqkv, nullptr, 0, e->v_qkv, 3 * D, false, M, 3 * D, D, 0, TAG_GEMM_VIT));
-            AttnFullArgs a{};
-            a.q = e->v_qkv;
-            a.k = (char*)e->v_qkv + (size_t)D * e->esz;
-            a.v = (char*)e->v_qkv + (size_t)2 * D * e->esz;
-            a.out = e->v_ctx;
-            a.ldq = a.ldk = a.ldv = 3 * D;
-            a.ldo = D;
-            a.N = N; a.H = c.vit_heads; a.scale = 0.125f;
-            HIPCK(launch_attn_full(a, BI, false, e->attn_impl, s));
-            RCK(gemm_branch(e, s, e->v_ctx, D, L.wo, L.bo, e->v_y, D, M, D, D, TAG_GEMM_VIT));
-            RCK(add_ln(e, s, e->v_x, D, e->v_y, D, e->v_x, L.ln2g, L.ln2b, 1e-5f, nullptr, e->v_h, D, nullptr, 0, M, D));
-            RCK(gemm(e, s, e->v_h, D, L.w1, L.b1, nullptr, 0, e->v_u, 4 * D, false, M, 4 * D, D, 1, TAG_GEMM_VIT));
-            RCK(gemm_branch(e, s, e->v_u, 4 * D, L.w2, L.b2, e->v_y, D, M, D, 4 * D, TAG_GEMM_VIT));
-            if (l + 1 < c.vit_layers) {
-                const VitLayerW& Ln = e->vit[l + 1];
-                RCK(add_ln(e, s, e->v_x, D, e->v_y, D, e->v_x, Ln.ln1g, Ln.ln1b, 1e-5f, nullptr, e->v_h, D, nullptr, 0, M, D));
-            }
-        }
-        // last residual add fused into ln_post (+ temporal embedding of the frame), scattered into [B, F*N, D]
-        for (int fr = 0; fr < F_eff; ++fr) {
-            const float* te = (c.num_frames > 0 && e->use_temb) ? e->temb[fr] : nullptr;
-            const char* xs = (const char*)e->v_x + (size_t)fr * B * N * D * ssz;
-            const char* ys = (const char*)e->v_y + (size_t)fr * B * N * D * 2;
-            RCK(add_ln(e, s, xs, D, ys, D, nullptr, e->lnpost_g, e->lnpost_b, 1e-5f, te, e->feats, D, nullptr, 0, B * N, D, N,
-                       Nimg, fr * N, feats_out, D));       // feats_out: the parity hook's fp32 copy
-        }
-    } else {
-        for (int l = 0; l < c.vit_layers; ++l) {
-            const VitLayerW& L = e->vit[l];
-            RCK(ln_stream(e, s, e->v_x, D, L.ln1g, L.ln1b, 1e-5f, e->v_h, D, nullptr, 0, M, D));
-            RCK(gemm(e, s, e->v_h, D, L.wqkv, L.bqkv, nullptr, 0, e->v_qkv, 3 * D, e->f32, M, 3 * D, D, 0, TAG_GEMM_VIT));
-            AttnFullArgs a{};
-            a.q = e->v_qkv;
-            a.k = (char*)e->v_qkv + (size_t)D * e->esz;
-            a.v = (char*)e->v_qkv + (size_t)2 * D * e->esz;
-            a.out = e->v_ctx;
-            a.ldq = a.ldk = a.ldv = 3 * D;
-            a.ldo = D;
-            a.N = N; a.H = c.vit_heads; a.scale = 0.125f;
-            HIPCK(launch_attn_full(a, BI, e->f32, e->attn_impl, s));
-            RCK(gemm_stream(e, s, e->v_ctx, D, L.wo, L.bo, e->v_x, D, e->v_x, D, M, D, D, TAG_GEMM_VIT));
-            RCK(ln_stream(e, s, e->v_x, D, L.ln2g, L.ln2b, 1e-5f, e->v_h, D, nullptr, 0, M, D));
-            RCK(gemm(e, s, e->v_h, D, L.w1, L.b1, nullptr, 0, e->v_u, 4 * D, e->f32, M, 4 * D, D, 1, TAG_GEMM_VIT));
-            RCK(gemm_stream(e, s, e->v_u, 4 * D, L.w2, L.b2, e->v_x, D, e->v_x, D, M, D, 4 * D, TAG_GEMM_VIT));
-        }
-        // ln_post (+ temporal embedding of the frame), scattered into the concatenated [B, F*N, D] feature tensor
-        for (int fr = 0; fr < F_eff; ++fr) {
-            const float* te = (c.num_frames > 0 && e->use_temb) ? e->temb[fr] : nullptr;
-            if (e->stream_f16) {
-                const char* xs = (const char*)e->v_x + (size_t)fr * B * N * D * 2;      // fp16 rows
-                HIPCK(launch_layernorm_s16(xs, D, e->lnpost_g, e->lnpost_b, 1e-5f, te, e->feats, D, false, nullptr, 0, B * N, D, N,
-                                           Nimg, fr * N, s));
-                if (feats_out)      // parity hook: the fp32 copy of the features comes from a second pass over the same rows
-                    HIPCK(launch_layernorm_s16(xs, D, e->lnpost_g, e->lnpost_b, 1e-5f, te, feats_out, D, true, nullptr, 0, B * N, D,
-                                               N, Nimg, fr * N, s));
-            } else {
-                HIPCK(launch_layernorm(e->v_x + (size_t)fr * B * N * D, D, e->lnpost_g, e->lnpost_b, 1e-5f, te, e->feats, D, e->f32,
-                                       feats_out, D, B * N, D, N, Nimg, fr * N, s));
-            }
+    for (int l = 0; l < c.vit_layers; ++l) {
+        const VitLayerW& L = e->vit[l];
+        RCK(ln_stream(e, s, e->v_x, D, L.ln1g, L.ln1b, 1e-5f, e->v_h, D, nullptr, 0, M, D));
+        RCK(gemm(e, s, e->v_h, D, L.wqkv, L.bqkv, nullptr, 0, e->v_qkv, 3 * D, e->f32, M, 3 * D, D, 0, TAG_GEMM_VIT));
+        AttnFullArgs a{};
+        a.q = e->v_qkv;
+        a.k = (char*)e->v_qkv + (size_t)D * e->esz;
+        a.v = (char*)e->v_qkv + (size_t)2 * D * e->esz;
+        a.out = e->v_ctx;
+        a.ldq = a.ldk = a.ldv = 3 * D;
+        a.ldo = D;
+        a.N = N; a.H = c.vit_heads; a.scale = 0.125f;
+        HIPCK(launch_attn_full(a, BI, e->f32, e->attn_impl, s));
+        RCK(gemm_stream(e, s, e->v_ctx, D, L.wo, L.bo, e->v_x, D, e->v_x, D, M, D, D, TAG_GEMM_VIT));
+        RCK(ln_stream(e, s, e->v_x, D, L.ln2g, L.ln2b, 1e-5f, e->v_h, D, nullptr, 0, M, D));
+        RCK(gemm(e, s, e->v_h, D, L.w1, L.b1, nullptr, 0, e->v_u, 4 * D, e->f32, M, 4 * D, D, 1, TAG_GEMM_VIT));
+        RCK(gemm_stream(e, s, e->v_u, 4 * D, L.w2, L.b2, e->v_x, D, e->v_x, D, M, D, 4 * D, TAG_GEMM_VIT));
+    }
+    // ln_post (+ temporal embedding of the frame), scattered into the concatenated [B, F*N, D] feature tensor
+    for (int fr = 0; fr < F_eff; ++fr) {
+        const float* te = (c.num_frames > 0 && e->use_temb) ? e->temb[fr] : nullptr;
+        if (e->stream_f16) {
+            const char* xs = (const char*)e->v_x + (size_t)fr * B * N * D * 2;      // fp16 rows
+            HIPCK(launch_layernorm_s16(xs, D, e->lnpost_g, e->lnpost_b, 1e-5f, te, e->feats, D, false, nullptr, 0, B * N, D, N,
+                                       Nimg, fr * N, s));
+            if (feats_out)      // parity hook: the fp32 copy of the features comes from a second pass over the same rows
+                HIPCK(launch_layernorm_s16(xs, D, e->lnpost_g, e->lnpost_b, 1e-5f, te, feats_out, D, true, nullptr, 0, B * N, D,
+                                           N, Nimg, fr * N, s));
+        } else {
+            HIPCK(launch_layernorm(e->v_x + (size_t)fr * B * N * D, D, e->lnpost_g, e->lnpost_b, 1e-5f, te, e->feats, D, e->f32,
+                                   feats_out, D, B * N, D, N, Nimg, fr * N, s));
         }
     }
+
     e->cur_B = B; e->cur_F = F_eff; e->cur_Nimg = Nimg;
     e->have_feats = true;
     e->have_prefill = false;
@@ -918,41 +855,6 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
     const int d = c.dec_hidden, ffn = c.dec_ffn, D = c.vit_width;
     const int B = e->cur_B, Nimg = e->cur_Nimg, M = B * Nimg;
     SpanGuard phase(e, s, TAG_PREFILL, 0);
-    if (e->addln) {
-        // every N = d GEMM leaves a fp16 branch result in p_y; the LayerNorm that follows adds the residual (the previous
-        // LayerNorm's output, p_hf) -- BERT post-norm: h = LayerNorm(dense(...) + h_prev)
-        RCK(gemm_branch(e, s, e->feats, D, e->vp_w, e->vp_b, e->p_y, d, M, d, D, TAG_GEMM_OTHER));
-        RCK(add_ln(e, s, nullptr, d, e->p_y, d, nullptr, e->vp_lng, e->vp_lnb, 1e-5f, nullptr, e->p_ht, d, e->p_hf, d, M, d));
-        for (int l = 0; l < c.dec_layers; ++l) {
-            const DecLayerW& L = e->dec[l];
-            const bool last = l + 1 == c.dec_layers;
-            if (!last) {
-                RCK(gemm(e, s, e->p_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->img_kv[l], 3 * d, false, M, 3 * d, d, 0, TAG_GEMM_OTHER));
-                RCK(kv_repack(e, l, B, Nimg, s));
-            } else {
-                RCK(gemm(e, s, e->p_ht, d, (char*)L.wqkv + (size_t)d * d * e->esz, L.bqkv + d, nullptr, 0,
-                         (char*)e->img_kv[l] + (size_t)d * e->esz, 3 * d, false, M, 2 * d, d, 0, TAG_GEMM_OTHER));
-                RCK(kv_repack(e, l, B, Nimg, s));
-                break;
-            }
-            AttnFullArgs a{};
-            a.q = e->img_kv[l];
-            a.k = (char*)e->img_kv[l] + (size_t)d * e->esz;
-            a.v = (char*)e->img_kv[l] + (size_t)2 * d * e->esz;
-            a.out = e->p_ctx;
-            a.ldq = a.ldk = a.ldv = 3 * d;
-            a.ldo = d;
-            a.N = Nimg; a.H = c.dec_heads; a.scale = 0.125f;
-            HIPCK(launch_attn_full(a, B, false, e->attn_impl, s));
-            RCK(gemm_branch(e, s, e->p_ctx, d, L.wo, L.bo, e->p_y, d, M, d, d, TAG_GEMM_OTHER));
-            RCK(add_ln(e, s, e->p_hf, d, e->p_y, d, nullptr, L.lnag, L.lnab, 1e-12f, nullptr, e->p_ht, d, e->p_hf, d, M, d));
-            RCK(gemm(e, s, e->p_ht, d, L.w1, L.b1, nullptr, 0, e->p_u, ffn, false, M, ffn, d, 2, TAG_GEMM_OTHER));
-            RCK(gemm_branch(e, s, e->p_u, ffn, L.w2, L.b2, e->p_y, d, M, d, ffn, TAG_GEMM_OTHER));
-            RCK(add_ln(e, s, e->p_hf, d, e->p_y, d, nullptr, L.lnog, L.lnob, 1e-12f, nullptr, e->p_ht, d, e->p_hf, d, M, d));
-        }
-        e->have_prefill = true;
-        return 0;
-    }
     RCK(gemm_stream(e, s, e->feats, D, e->vp_w, e->vp_b, nullptr, 0, e->p_y, d, M, d, D, TAG_GEMM_OTHER));
     RCK(ln_stream(e, s, e->p_y, d, e->vp_lng, e->vp_lnb, 1e-5f, e->p_ht, d, e->p_hf, d, M, d));
     for (int l = 0; l < c.dec_layers; ++l) {
@@ -1723,15 +1625,6 @@ extern "C" int gitmi_op_gemm(const void* A, const void* W, const float* bias, co
         g.out_f16 = 1;
     }
     HIPCK(launch_gemm(g, in_f32, out_dtype == GITMI_DTYPE_F32, (hipStream_t)stream));
-    return 0;
-}
-// residual add + LayerNorm in one pass (kernels_norm.hip add_layernorm_kernel): x_new = x + yadd (fp16) [-> x_out, may
-// alias x]; y_t = LayerNorm(x_new) as bf16 rows [, y_s in the stream type].  stream_dtype: GITMI_DTYPE_F32 / _F16.
-extern "C" int gitmi_op_add_layernorm(const void* x, const void* yadd_f16, void* x_out, const float* gamma, const float* beta,
-                                      float eps, void* y_t_bf16, void* y_s, int rows, int D, int stream_dtype, void* stream) {
-    if (stream_dtype != GITMI_DTYPE_F32 && stream_dtype != GITMI_DTYPE_F16) return fail("op_add_layernorm: bad stream dtype");
-    HIPCK(launch_add_layernorm(x, stream_dtype == GITMI_DTYPE_F16, D, yadd_f16, D, x_out, D, gamma, beta, eps, nullptr, y_t_bf16, D,
-                               y_s, D, nullptr, 0, rows, D, 0, 0, 0, (hipStream_t)stream));
     return 0;
 }
 extern "C" int gitmi_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, void* y_t,

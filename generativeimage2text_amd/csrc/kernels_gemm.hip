@@ -304,7 +304,6 @@ hipError_t launch_gemm(const GemmArgs& g_in, bool in_f32, bool out_f32, hipStrea
         // fp16 residual-stream rows out (and in, as the residual): the p8 kernel for the large-M phases, the generic
         // kernel otherwise (the ring / direct-to-LDS generations have no fp16 epilogue)
         if (in_f32 || out_f32 || g.K % 64 != 0) return hipErrorInvalidValue;
-        if (g_gemm_impl == 11 && !g.res && gemm_p9_supports(g)) return launch_gemm_p9(g, s);
         if (g_gemm_impl != 0 && g.M > 512 && gemm_dlds_supported(g, false, false) && (!g.res || g.ldr % 8 == 0) &&
             gemm_p8_supports(g))
             return launch_gemm_p8(g, false, s);
@@ -312,8 +311,6 @@ hipError_t launch_gemm(const GemmArgs& g_in, bool in_f32, bool out_f32, hipStrea
     }
     // impl: -1 auto | 0 register-staged (also fp32, odd shapes) | 1 direct-to-LDS 128x128 | 2 256x128 3-stage ring |
     //       6 256x256x32 4-stage ring | 9 256x256x64 half-tile pipeline (kernels_gemm10.hip)
-    //       11 persistent p8 tile, 10-slot LDS ring, quadrant epilogues inside the stream (kernels_gemm11.hip; 16-bit outputs)
-    if (g_gemm_impl == 11 && !in_f32 && !out_f32 && !g.res && gemm_p9_supports(g)) return launch_gemm_p9(g, s);
     if (g_gemm_impl != 0 && gemm_dlds_supported(g, in_f32, out_f32)) {
         if (g_gemm_impl == 6) return launch_gemm_ring256(g, out_f32, s);
         if (g_gemm_impl == 9 && gemm_p8_supports(g)) return launch_gemm_p8(g, out_f32, s);

@@ -94,23 +94,10 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // their 16 KiB; with MH = 96 the last four 1-KiB pieces of a slot are loaded (clamped rows) but never read, so every
 // wave still issues two loads per half tile and the vmcnt arithmetic is unchanged.
 // EPI (fp32 outputs only): 1 direct epilogue from the accumulators, 0 the LDS-staged one (A/B: dbg bit 256)
-// S / PH (schedule variants, round 3): S = LDS half-tile slots, PH = phases (MFMA segments per wave group) per K tile.
-//   S = 8, PH = 4: the schedule described in the header (two K-tile buffers, four half tiles in flight).
-//   S = 10 (all 160 KiB): the slots form a RING -- half tile h = 4 t + j (j: 0 = A0, 1 = B0, 2 = B1, 3 = A1: the order
-//     of issue AND of first use) lives in slot h % 10.
-//       PH = 4: phase p of K tile t requests half tile 4t + p + 8 and waits `vmcnt(12)`: six half tiles in flight.
-//       PH = 2: two MERGED phases per K tile -- [read B0, A0, B1 | 32 MFMAs: quadrants (0,0), (0,1)] and [read A1 | 32
-//               MFMAs: (1,1), (1,0)] -- i.e. half the barriers and wave-group hand-overs per FLOP; a phase requests TWO
-//               half tiles (2f + 6, 2f + 7 in phase f) and waits `vmcnt(8)` / `vmcnt(6)` (even / odd phase): the half
-//               tiles of the next phase have landed, 3-4 are in flight.
-//     Slot reuse in both: half tile h + 10 is requested no earlier than two phases after the phase that read h (the
-//     other wave group runs one barrier behind).
-template <typename TOut, int ACT, int DBG = 0, int MH = 128, int EPI = 1, int S = 8, int PH = 4>
+template <typename TOut, int ACT, int DBG = 0, int MH = 128, int EPI = 1>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     constexpr int BM = 2 * MH, MI = MH / 32;            // row fragments of a 64/48-row quadrant
-    static_assert((S == 8 && PH == 4) || (S == 10 && (PH == 4 || PH == 2)), "unsupported schedule");
-    constexpr int LDS_ALL = S * HALF_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_ALL];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -251,127 +238,14 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     };
 
     const int nk = g.K / BK;                                       // >= 2 (launcher)
-    if constexpr (S == 8) {
-        issue(0, 0, 0); issue(1, 0, 0); issue(1, 1, 0); issue(0, 1, 0); issue(0, 0, 1); issue(1, 0, 1);
-        wait_vm<8>();                                                  // A0(0), B0(0) of this wave have landed
-        P8_BARRIER();
-        if (grp == 1) P8_BARRIER();                                    // group 1 runs one barrier behind
-        for (int t = 0; t < nk - 2; ++t) ktile(std::integral_constant<int, 0>{}, t);
-        ktile(std::integral_constant<int, 1>{}, nk - 2);
-        ktile(std::integral_constant<int, 2>{}, nk - 1);
-        if (grp == 0) P8_BARRIER();
-    } else {
-        // ---- ring schedule (S = 10) ----------------------------------------------------------------------------------
-        const int total_h = 4 * nk;                                    // half tiles of this tile's stream
-        int is_h = 0, is_slot = 0;                                     // next half tile to request, its slot
-        // J = is_h % 4, known at every call site: 0 = A half 0, 1 = W half 0, 2 = W half 1, 3 = A half 1
-        auto ring_issue = [&](auto j_c) {
-            constexpr int J = decltype(j_c)::value;
-            constexpr bool isw = J == 1 || J == 2;
-            constexpr int half = J >> 1;
-            if constexpr (!(DBG & 8)) {
-                const char* src = (isw ? Wb : Ab) + (size_t)(is_h >> 2) * (BK * 2);
-                unsigned char* dst = smem + is_slot * HALF_BYTES + wave * 2048;
-                const uint32_t o0 = isw ? w_off[half][0] : a_off[half][0];
-                const uint32_t o1 = isw ? w_off[half][1] : a_off[half][1];
-                __builtin_amdgcn_global_load_lds((const void*)(src + o0), (lds_void_t*)(dst), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const void*)(src + o1), (lds_void_t*)(dst + 1024), 16, 0, 0);
-            }
-            ++is_h;
-            is_slot = is_slot + 1 == S ? 0 : is_slot + 1;
-        };
-        auto rd_a = [&](int slot) {
-            if constexpr (DBG & 4) return;
-            const unsigned char* sb = smem + slot * HALF_BYTES + a_rd;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                af[i][0] = *reinterpret_cast<const bf16x8_t*>(sb + i * 2048 + ch0);
-                af[i][1] = *reinterpret_cast<const bf16x8_t*>(sb + i * 2048 + ch1);
-            }
-        };
-        auto rd_w = [&](int slot, bf16x8_t (&wf)[2][2]) {
-            if constexpr (DBG & 4) return;
-            const unsigned char* sb = smem + slot * HALF_BYTES + (w_rd - SLOT_B0);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                wf[j][0] = *reinterpret_cast<const bf16x8_t*>(sb + j * 2048 + ch0);
-                wf[j][1] = *reinterpret_cast<const bf16x8_t*>(sb + j * 2048 + ch1);
-            }
-        };
-        auto slot_add = [&](int sl, int d) { const int t = sl + d; return t >= S ? t - S : t; };
-        using J0 = std::integral_constant<int, 0>;
-        using J1 = std::integral_constant<int, 1>;
-        using J2 = std::integral_constant<int, 2>;
-        using J3 = std::integral_constant<int, 3>;
-        int rd_slot = 0;
-        if constexpr (PH == 4) {
-            // request 8 half tiles (nk >= 2), the first two confirmed
-            ring_issue(J0{}); ring_issue(J1{}); ring_issue(J2{}); ring_issue(J3{});
-            ring_issue(J0{}); ring_issue(J1{}); ring_issue(J2{}); ring_issue(J3{});
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            P8_BARRIER();
-            if (grp == 1) P8_BARRIER();
-            // phase p requests half tile 4t + p + 8 (j = p); nothing left to request in the last two K tiles
-            auto req = [&](auto j_c) {
-                if (is_h < total_h) { ring_issue(j_c); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            };
-            for (int t = 0; t < nk; ++t) {
-                rd_w(slot_add(rd_slot, 1), wf0);
-                __builtin_amdgcn_sched_barrier(0);
-                rd_a(rd_slot);
-                req(J0{});
-                P8_BARRIER();
-                mma(acc[0][0], wf0);
-                P8_BARRIER();
-                rd_w(slot_add(rd_slot, 2), wf1);
-                req(J1{});
-                P8_BARRIER();
-                mma(acc[0][1], wf1);
-                P8_BARRIER();
-                rd_a(slot_add(rd_slot, 3));
-                req(J2{});
-                P8_BARRIER();
-                mma(acc[1][1], wf1);
-                P8_BARRIER();
-                req(J3{});
-                P8_BARRIER();
-                mma(acc[1][0], wf0);
-                P8_BARRIER();
-                rd_slot = slot_add(rd_slot, 4);
-            }
-        } else {
-            // request 6 half tiles (K tile 0 and A0, B0 of K tile 1), the first three confirmed
-            ring_issue(J0{}); ring_issue(J1{}); ring_issue(J2{}); ring_issue(J3{}); ring_issue(J0{}); ring_issue(J1{});
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            P8_BARRIER();
-            if (grp == 1) P8_BARRIER();
-            for (int t = 0; t < nk; ++t) {
-                // ---- phase A: half tiles 4t (A0), 4t+1 (B0), 4t+2 (B1) -> quadrants (0,0), (0,1); requests 4t+6, 4t+7
-                rd_w(slot_add(rd_slot, 1), wf0);
-                __builtin_amdgcn_sched_barrier(0);
-                rd_a(rd_slot);
-                __builtin_amdgcn_sched_barrier(0);
-                rd_w(slot_add(rd_slot, 2), wf1);
-                if (is_h < total_h) { ring_issue(J2{}); ring_issue(J3{}); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                P8_BARRIER();
-                mma(acc[0][0], wf0);
-                mma(acc[0][1], wf1);
-                P8_BARRIER();
-                // ---- phase B: half tile 4t+3 (A1) -> quadrants (1,1), (1,0); requests 4t+8, 4t+9
-                rd_a(slot_add(rd_slot, 3));
-                if (is_h < total_h) { ring_issue(J0{}); ring_issue(J1{}); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                P8_BARRIER();
-                mma(acc[1][1], wf1);
-                mma(acc[1][0], wf0);
-                P8_BARRIER();
-                rd_slot = slot_add(rd_slot, 4);
-            }
-        }
-        if (grp == 0) P8_BARRIER();
-    }
+    issue(0, 0, 0); issue(1, 0, 0); issue(1, 1, 0); issue(0, 1, 0); issue(0, 0, 1); issue(1, 0, 1);
+    wait_vm<8>();                                                  // A0(0), B0(0) of this wave have landed
+    P8_BARRIER();
+    if (grp == 1) P8_BARRIER();                                    // group 1 runs one barrier behind
+    for (int t = 0; t < nk - 2; ++t) ktile(std::integral_constant<int, 0>{}, t);
+    ktile(std::integral_constant<int, 1>{}, nk - 2);
+    ktile(std::integral_constant<int, 2>{}, nk - 1);
+    if (grp == 0) P8_BARRIER();
 
     // ---- epilogue through LDS: slab = MH rows (qm) x WCOL columns ---------------------------------
     constexpr int NQN = sizeof(TOut) == 2 ? 2 : 1;                 // weight halves per slab
@@ -379,7 +253,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     constexpr int EPC = 16 / (int)sizeof(TOut);                    // elements per 16-byte chunk
     constexpr int EPS = WCOL + EPC;                                // padded row stride (elements)
     constexpr int CPR = WCOL / EPC;                                // chunks per row
-    static_assert(MH * EPS * sizeof(TOut) <= LDS_ALL && (MH * CPR) % 512 == 0, "epilogue slab does not fit");
+    static_assert(MH * EPS * sizeof(TOut) <= LDS_BYTES && (MH * CPR) % 512 == 0, "epilogue slab does not fit");
     TOut* ep = reinterpret_cast<TOut*>(smem);
     TOut* __restrict__ C = reinterpret_cast<TOut*>(g.C);
 
@@ -527,29 +401,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 
 }  // namespace
 
-template <typename TOut, int MH, int EPI, int S, int PH>
-static void launch_p8_sched(const GemmArgs& g, hipStream_t s) {
-    switch (g.act) {
-        case GITMI_ACT_QUICKGELU:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_QUICKGELU, 0, MH, EPI, S, PH>), dim3(g.nwg), dim3(512), 0, s, g); break;
-        case GITMI_ACT_GELU_ERF:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_GELU_ERF, 0, MH, EPI, S, PH>), dim3(g.nwg), dim3(512), 0, s, g); break;
-        default:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_NONE, 0, MH, EPI, S, PH>), dim3(g.nwg), dim3(512), 0, s, g); break;
-    }
-}
-
-static int g_p8_sched = 0;        // 0: S = 8 / PH = 4 (round-2 schedule); 1: ring of 10 slots, 4 phases; 2: ring, 2 merged phases
-void set_gemm_p8_schedule(int sched) { g_p8_sched = sched; }
-
 template <typename TOut, int MH, int EPI = 1>
-static void launch_p8_t(const GemmArgs& g_in, hipStream_t s) {
-    GemmArgs g = g_in;
-    int sched = g_p8_sched;
-    if (g.dbg & 1024) { sched = 1; g.dbg &= ~1024; }
-    if (g.dbg & 2048) { sched = 2; g.dbg &= ~2048; }
-    if (sched == 1) { launch_p8_sched<TOut, MH, EPI, 10, 4>(g, s); return; }
-    if (sched == 2) { launch_p8_sched<TOut, MH, EPI, 10, 2>(g, s); return; }
+static void launch_p8_t(const GemmArgs& g, hipStream_t s) {
     if (g.dbg) {      // measurement builds (tools/gemm_dbg.py); act is ignored
         if constexpr (MH == 128) {
             switch (g.dbg) {

@@ -87,78 +87,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TS* __restrict__ x
     }
 }
 
-// Residual add fused into the LayerNorm that follows it (bf16 engine mode with 16-bit branch outputs, engine.hip):
-//   x_new = x + yadd          x: residual-stream rows (TS = float or f16_t; nullptr: x_new = yadd), yadd: fp16 GEMM output
-//   x_out <- x_new            (optional; may alias x: a lane reads its elements of the row before it writes them)
-//   y_t   <- LayerNorm(x_new) (+ add_after) as bf16 operand rows, y_f <- the same in the stream type (optional; may alias x)
-// so that the N = hidden GEMMs of the encoder / prefill write plain 16-bit rows (no read-modify-write of the stream in
-// their epilogue) and the stream is touched once per LayerNorm, by a kernel that streams at HBM rate.
-template <typename TS>
-__global__ __launch_bounds__(256) void add_layernorm_kernel(const TS* x, int ldx, const f16_t* __restrict__ yadd,
-                                                            int ldy, TS* x_out, int ldxo, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float eps,
-                                                            const float* __restrict__ add_after, bf16_t* __restrict__ y_t,
-                                                            int ld_t, TS* y_f, int ld_f, float* __restrict__ y32, int ld32,
-                                                            int rows, int D, RowMap map) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    constexpr int NV = LN_MAXV / 4;
-    f32x4_t v[NV];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        v[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (c < D) {
-            if (x) v[i] = ld4s(x + (size_t)row * ldx + c);
-            if (yadd) {
-                const f32x4_t t = ld4s(yadd + (size_t)row * ldy + c);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[i][r] += t[r];
-            }
-            if (x_out) st4s(x_out + (size_t)row * ldxo + c, v[i]);
-        }
-        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-    }
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < D) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float d = v[i][r] - mean; q += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-    const size_t orow = map_row(map, row);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < D) {
-            const f32x4_t g4 = *reinterpret_cast<const f32x4_t*>(gamma + c);
-            const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(beta + c);
-            float o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (v[i][r] - mean) * rstd * g4[r] + b4[r];
-            if (add_after) {
-                const f32x4_t a4 = *reinterpret_cast<const f32x4_t*>(add_after + c);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] += a4[r];
-            }
-            if (y_t) {
-                uint2 t;
-                t.x = pack2bf(o[0], o[1]);
-                t.y = pack2bf(o[2], o[3]);
-                *reinterpret_cast<uint2*>(y_t + orow * ld_t + c) = t;
-            }
-            if (y_f) st4s(y_f + orow * ld_f + c, f32x4_t{o[0], o[1], o[2], o[3]});
-            if (y32) *reinterpret_cast<f32x4_t*>(y32 + orow * ld32 + c) = f32x4_t{o[0], o[1], o[2], o[3]};
-        }
-    }
-}
-
 // patches[(b*gh*gw + gy*gw + gx), c*p*p + ky*p + kx] = img[b, c, gy*p + ky, gx*p + kx]; zero pad to Kpad.
 // img is [B, C, H, W]; gh = H / p, gw = W / p (floor): like the stride-p convolution of CLIP/model.py:242 the
 // H % p bottom rows and W % p right columns are never read.
@@ -474,26 +402,6 @@ hipError_t launch_layernorm_s16(const void* x, int ldx, const float* gamma, cons
     else
         hipLaunchKernelGGL((layernorm_kernel<bf16_t, f16_t>), grid, block, 0, s, (const f16_t*)x, ldx, gamma, beta, eps,
                            add_after, (bf16_t*)y_t, ld_t, (f16_t*)y_s, ld_s, rows, D, m);
-    return hipGetLastError();
-}
-
-hipError_t launch_add_layernorm(const void* x, bool s_f16, int ldx, const void* yadd_f16, int ldy, void* x_out, int ldxo,
-                                const float* gamma, const float* beta, float eps, const float* add_after, void* y_t_bf16,
-                                int ld_t, void* y_f, int ld_f, float* y32, int ld32, int rows, int D, int map_n_in,
-                                int map_n_out, int map_off, hipStream_t s) {
-    if (rows <= 0) return hipSuccess;
-    if (!x && !yadd_f16) return hipErrorInvalidValue;
-    if (D > 64 * LN_MAXV || (D & 3) || (x && (ldx & 3)) || (yadd_f16 && (ldy & 3)) || (x_out && (ldxo & 3)) || (ld_t & 3) ||
-        (y_f && (ld_f & 3)) || (y32 && (ld32 & 3)))
-        return hipErrorInvalidValue;
-    RowMap m{map_n_in > 0 ? map_n_in : rows, map_n_in > 0 ? map_n_out : rows, map_off};
-    dim3 grid((rows + 3) / 4), block(256);
-    if (s_f16)
-        hipLaunchKernelGGL(add_layernorm_kernel<f16_t>, grid, block, 0, s, (const f16_t*)x, ldx, (const f16_t*)yadd_f16, ldy,
-                           (f16_t*)x_out, ldxo, gamma, beta, eps, add_after, (bf16_t*)y_t_bf16, ld_t, (f16_t*)y_f, ld_f, y32, ld32, rows, D, m);
-    else
-        hipLaunchKernelGGL(add_layernorm_kernel<float>, grid, block, 0, s, (const float*)x, ldx, (const f16_t*)yadd_f16, ldy,
-                           (float*)x_out, ldxo, gamma, beta, eps, add_after, (bf16_t*)y_t_bf16, ld_t, (float*)y_f, ld_f, y32, ld32, rows, D, m);
     return hipGetLastError();
 }
 

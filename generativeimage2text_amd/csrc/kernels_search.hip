@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
             int is_done = st.done[b];
             if (!is_done && st.hyp_n[b] >= 1) {
                 // BeamHypotheses.is_done(max next score); self.max_length = max_length - 1
-                is_done = st.hyp_score[b] >= (double)n_max / length_norm(T - 1, st.length_penalty);
+                is_done = st.hyp_score[b] >= (double)n_max / st.len_norm[T - 1];
             }
             if (is_done && !st.done[b]) atomicAdd(&st.info[0], 1);
             st.done[b] = is_done;
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
                     const int word = n_word[c];
                     if (word == st.eos || cur_len + 1 == T) {
                         // hyps.add(input_ids[row, :cur_len], score)
-                        const double sc = (double)n_score[c] / length_norm(cur_len, st.length_penalty);
+                        const double sc = (double)n_score[c] / st.len_norm[cur_len];
                         if (st.hyp_n[b] < 1 || sc > st.hyp_score[b]) {
                             st.hyp_n[b] = 1;
                             st.hyp_score[b] = sc;
@@ -753,6 +753,9 @@ __global__ void search_init_kernel(SearchState st) {
             st.done[b] = 0; st.hyp_n[b] = 0; st.hyp_score[b] = 0.0; st.hyp_len[b] = 0; st.stop[b] = 0; st.early[b] = 0;
         }
         if (threadIdx.x < 4) st.info[threadIdx.x] = 0;
+        // BeamHypotheses length norm ((5 + len) / 6) ** length_penalty for every length, once per search: the step kernel's
+        // single bookkeeping thread otherwise evaluates several double-precision pow() per step
+        for (int len = threadIdx.x; len <= st.T; len += blockDim.x) st.len_norm[len] = length_norm(len, st.length_penalty);
     }
 }
 

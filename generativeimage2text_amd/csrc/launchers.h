@@ -23,10 +23,6 @@ hipError_t launch_gemm_ring(GemmArgs g, bool out_f32, hipStream_t s);   // 256x1
 hipError_t launch_gemm_ring256(GemmArgs g, bool out_f32, hipStream_t s); // 256x256x32, 8 waves of 128x64, 4-stage ring
 hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s);     // 256x256x64, half-tile pipeline, staggered wave groups
 bool gemm_p8_supports(const GemmArgs& g);
-void set_gemm_p8_schedule(int sched);   // 0: two K-tile buffers / 4 phases (round 2); 1: 10-slot LDS ring, 4 phases; 2: ring, 2 merged phases
-// persistent form of the p8 tile: 16-bit outputs (bf16, or fp16 with out_f16), bias + activation, no residual
-hipError_t launch_gemm_p9(GemmArgs g, hipStream_t s);
-bool gemm_p9_supports(const GemmArgs& g);
 int gemm_p8_cost(const GemmArgs& g, int mh);   // rounds x relative tile time of the 256-row (mh=128) / 192-row (96) tile
 void set_gemm_impl(int impl);   // -1 auto, 0 first-generation kernel only, 1 force direct-to-LDS kernel
 
@@ -74,12 +70,6 @@ hipError_t launch_vit_assemble_ln(const float* patch_out, const float* cls, cons
 hipError_t launch_layernorm_s16(const void* x, int ldx, const float* gamma, const float* beta, float eps,
                                 const float* add_after, void* y_t, int ld_t, bool t_is_f32, void* y_s, int ld_s,
                                 int rows, int D, int map_n_in, int map_n_out, int map_off, hipStream_t s);
-// residual add + LayerNorm in one pass (bf16 engine mode with fp16 branch outputs): x_new = x + yadd [-> x_out],
-// LayerNorm(x_new) -> y_t (bf16) [, y_f (stream type), y32 (fp32 copy, parity hook)]; x == nullptr: x_new = yadd
-hipError_t launch_add_layernorm(const void* x, bool s_f16, int ldx, const void* yadd_f16, int ldy, void* x_out, int ldxo,
-                                const float* gamma, const float* beta, float eps, const float* add_after, void* y_t_bf16,
-                                int ld_t, void* y_f, int ld_f, float* y32, int ld32, int rows, int D, int map_n_in,
-                                int map_n_out, int map_off, hipStream_t s);
 hipError_t launch_embed_ln(const int* ids, int ld_ids, int pos, const float* words, const float* positions,
                            const float* gamma, const float* beta, float eps, float* h_f, void* h_t, bool t_is_f32,
                            int R, int D, int vocab, bool frag, hipStream_t s);
@@ -124,6 +114,7 @@ struct SearchState {
     int ragged;                         // 1: every sentence stands for its own batch-1 reference call (own prefix)
     int sampled;                        // GENERATOR sampling branch: candidates arrive as per_node draws per beam, in draw order
     double length_penalty;
+    double* len_norm;                   // [T_max + 1] ((5 + len) / 6) ** length_penalty, filled by search_init
     const long long* start;             // [B][ld_start] start tokens of every sentence (its prefix, or [CLS])
     int ld_start;
     const int* plen;                    // [B] prefix length of every sentence (>= 1)

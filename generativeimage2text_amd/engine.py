@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_op_vocab_topm", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
     "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after", "gitmi_op_sample_rows",
     "gitmi_generate_encode", "gitmi_generate_decode", "gitmi_search_done_count",
-    "gitmi_debug_import_stage", "gitmi_debug_head_from", "gitmi_op_add_layernorm", "gitmi_set_trie",
+    "gitmi_debug_import_stage", "gitmi_debug_head_from", "gitmi_set_trie",
 ]
 
 
@@ -105,7 +105,6 @@ def load_library() -> C.CDLL:
     lib.gitmi_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_attention.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
-    lib.gitmi_op_add_layernorm.argtypes = [vp, vp, vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_dgemm.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, vp, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_dgemm_res.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_vocab_topm.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
@@ -474,22 +473,6 @@ def op_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: 
     _ck(lib.gitmi_op_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, out.data_ptr(), None, rows, D,
                                _torch_dtype_code(out), _stream()))
     return out
-
-
-def op_add_layernorm(x: Optional[torch.Tensor], yadd: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
-                     write_x: bool = True):
-    """x_new = x + yadd (fp16), LayerNorm(x_new): -> (x_new in x's dtype or None, LayerNorm output bf16, the same in the
-    stream dtype).  x: fp32 or fp16 [rows, D] (None: x_new = yadd, stream dtype fp16)."""
-    lib = load_library()
-    rows, D = yadd.shape
-    sdt = torch.float16 if x is None else x.dtype
-    x_out = torch.empty(rows, D, device=yadd.device, dtype=sdt) if (write_x and x is not None) else None
-    y_t = torch.empty(rows, D, device=yadd.device, dtype=torch.bfloat16)
-    y_s = torch.empty(rows, D, device=yadd.device, dtype=sdt)
-    _ck(lib.gitmi_op_add_layernorm(_ptr(x), yadd.data_ptr(), _ptr(x_out), gamma.data_ptr(), beta.data_ptr(), eps,
-                                   y_t.data_ptr(), y_s.data_ptr(), rows, D, DTYPE_F16 if sdt == torch.float16 else DTYPE_F32,
-                                   _stream()))
-    return x_out, y_t, y_s
 
 
 def op_attention(qkv: torch.Tensor, B: int, N: int, H: int, impl: int) -> torch.Tensor:

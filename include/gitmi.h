@@ -262,12 +262,7 @@ int  gitmi_op_gemm(const void* A, const void* W, const float* bias, const float*
 /* y = LayerNorm(x) (biased variance, eps), x fp32 [rows, D]; y_t (in out_dtype) and/or y_f32 */
 int  gitmi_op_layernorm(const float* x, const float* gamma, const float* beta, float eps,
                         void* y_t, float* y_f32, int rows, int D, int out_dtype, void* stream);
-/* residual add fused into the LayerNorm behind it (bf16 engine mode with fp16 branch outputs): x_new = x + yadd (fp16 rows;
- * x: fp32 or fp16 stream rows, NULL = none) [-> x_out, may alias x]; LayerNorm(x_new) -> y_t (bf16 rows) [, y_s (stream
- * type)].  Replaces `x = x + attn(...)` / `x = x + mlp(...)` + the following ln_* of CLIP/model.py:181-202 and
- * `LayerNorm(dense(h) + input)` of modeling_bert.py:171-178, 243-250. */
-int  gitmi_op_add_layernorm(const void* x, const void* yadd_f16, void* x_out, const float* gamma, const float* beta, float eps,
-                            void* y_t_bf16, void* y_s, int rows, int D, int stream_dtype, void* stream);
+
 /* full (unmasked) multi-head attention over packed qkv [B*N, 3*D] (q|k|v, head h = cols h*64..);
  * out [B*N, D].  impl: 0 = reference VALU kernel, 1 = MFMA flash kernel (bf16 only). */
 int  gitmi_op_attention(const void* qkv, void* out, int B, int N, int H, int dtype, int impl,

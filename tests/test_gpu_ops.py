@@ -40,73 +40,9 @@ def test_gemm_bf16(M, N, K, act):
     assert (out_b - ref_b).abs().max().item() < 1e-2 * max(1.0, ref_b.abs().max().item())
 
 
-P9_SHAPES = [(12608, 2304, 768), (12608, 768, 3072), (12608, 3072, 768), (12608, 768, 768), (8224, 1024, 4096),
-             (2100, 768, 256), (515, 1024, 3072), (777, 256, 320), (1, 256, 256), (40000, 256, 256)]
-
-
-@pytest.mark.parametrize("M,N,K", P9_SHAPES)
-@pytest.mark.parametrize("act", [0, 1, 2])
-@pytest.mark.parametrize("variant", [11, 11 | (64 << 8), 11 | (128 << 8), 11 | (512 << 8), 11 | ((512 | 64) << 8),
-                                     11 | ((5 << 12) << 8)])
-def test_gemm_p9_persistent(M, N, K, act, variant):
-    """The persistent 16-bit-output kernel (kernels_gemm11.hip): default / forced 192- and 256-row tiles / the 8-slot ring /
-    5 workgroups per XCD (long tile lists per workgroup: many tile boundaries inside one stream).  bf16 rows must equal the
-    p8 kernel's bit for bit (same K order, same epilogue arithmetic); fp16 rows (branch outputs) are compared with the fp64
-    reference at fp16 resolution.  Shapes: the encoder / prefill GEMMs at the benchmark batch, GIT_LARGE's c_proj, the
-    shortest K (4 K tiles), ragged M, one row, 157 M tiles."""
-    from generativeimage2text_amd import engine as E
-    if M * N > 40e6 and variant not in (11, 11 | ((5 << 12) << 8)):
-        pytest.skip("big shapes: default + long-list variants only")
-    A = _rand(M, K, seed=21).bfloat16().cuda()
-    W = _rand(N, K, seed=22, scale=K ** -0.5).bfloat16().cuda()
-    bias = _rand(N, seed=23).cuda()
-    try:
-        E.set_gemm_impl(variant)
-        out_b = E.op_gemm(A, W, bias, None, act, torch.bfloat16)
-        out_h = E.op_gemm(A, W, bias, None, act, torch.float16)
-        out_nb = E.op_gemm(A, W, None, None, act, torch.float16)
-        out_b2 = E.op_gemm(A, W, bias, None, act, torch.bfloat16)
-        E.set_gemm_impl(9)
-        p8_b = E.op_gemm(A, W, bias, None, act, torch.bfloat16)
-    finally:
-        E.set_gemm_impl(-1)
-    assert torch.equal(out_b, out_b2)                                   # deterministic
-    assert torch.equal(out_b, p8_b)
-    step = 2048
-    for r0 in list(range(0, M, step * 4))[:8] + [max(0, M - step)]:           # fp64 reference on row slabs
-        sl = slice(r0, min(M, r0 + step))
-        lin = A[sl].double() @ W.double().t()
-        ref = _act(lin + bias.double(), act)
-        tol = 2e-3 * max(1.0, ref.abs().max().item())
-        assert (out_h[sl].double() - ref).abs().max().item() < tol
-        assert (out_nb[sl].double() - _act(lin, act)).abs().max().item() < tol
-
-
-@pytest.mark.parametrize("rows,D", [(1000, 768), (12608, 768), (257, 1024), (3, 128)])
-@pytest.mark.parametrize("sdt", [torch.float32, torch.float16])
-def test_add_layernorm_fused(rows, D, sdt):
-    """x + yadd -> stream, LayerNorm of the sum -> bf16 operand rows + stream copy, against fp64 torch; also the
-    no-residual form (x = None) and in-place use (the engine passes x_out = x)."""
-    from generativeimage2text_amd import engine as E
-    x = _rand(rows, D, seed=31, scale=3.0).to(sdt).cuda()
-    y = _rand(rows, D, seed=32).half().cuda()
-    gamma, beta = (1 + 0.1 * _rand(D, seed=33)).cuda(), (0.1 * _rand(D, seed=34)).cuda()
-    xs = x.double() + y.double()
-    ref = torch.nn.functional.layer_norm(xs, (D,), gamma.double(), beta.double(), 1e-5)
-    x_out, y_t, y_s = E.op_add_layernorm(x, y, gamma, beta, 1e-5)
-    assert (x_out.double() - xs).abs().max().item() < (1e-6 if sdt == torch.float32 else 1.5e-2)
-    # the statistics are taken from the unrounded fp32 sum, so the outputs only carry their own storage rounding
-    assert (y_t.double() - ref).abs().max().item() < 4e-2 and (y_s.double() - ref).abs().max().item() < (1e-4 if sdt == torch.float32 else 8e-3)
-    _, y_t0, y_s0 = E.op_add_layernorm(None, y, gamma, beta, 1e-5)
-    ref0 = torch.nn.functional.layer_norm(y.double(), (D,), gamma.double(), beta.double(), 1e-5)
-    assert (y_t0.double() - ref0).abs().max().item() < 4e-2 and (y_s0.double() - ref0).abs().max().item() < 8e-3
-
-
 @pytest.mark.parametrize("M,N,K", [(1000, 512, 128), (777, 256, 192), (2100, 768, 768), (515, 1024, 3072)])
 @pytest.mark.parametrize("act", [0, 1, 2])
-@pytest.mark.parametrize("tile", [9 | (128 << 8), 9 | (64 << 8),           # forced 256x256 / 192x256 tile
-                                  9 | ((128 | 1024) << 8), 9 | ((64 | 1024) << 8),      # ... on the 10-slot LDS ring
-                                  9 | ((128 | 2048) << 8), 9 | ((64 | 2048) << 8)])     # ... ring + two merged phases per K tile
+@pytest.mark.parametrize("tile", [9 | (128 << 8), 9 | (64 << 8)])          # forced 256x256 / 192x256 tile
 def test_gemm_bf16_p8_variant(M, N, K, act, tile):
     """The 256x256 half-tile pipeline kernel (kernels_gemm10.hip), forced: shortest K (2 and 3 K tiles), ragged M,
     every epilogue; it must also equal the 256x128 ring kernel bit for bit (same K order)."""
