@@ -263,6 +263,14 @@ static int ln_stream(gitmi_engine* e, hipStream_t s, const void* x, int ldx, con
 
 // ---------------------------------------------------------------------------------------
 extern "C" int gitmi_abi_version(void) { return GITMI_ABI_VERSION; }
+// 16-bit operand type this library was built for: GITMI_DTYPE_BF16 (libgitmi.so) or GITMI_DTYPE_F16 (libgitmi_f16.so)
+extern "C" int gitmi_operand_dtype(void) {
+#ifdef GITMI_OPS_F16
+    return GITMI_DTYPE_F16;
+#else
+    return GITMI_DTYPE_BF16;
+#endif
+}
 extern "C" const char* gitmi_last_error(void) { return g_err; }
 
 extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** out) {
@@ -531,8 +539,11 @@ static int alloc_workspaces(gitmi_engine* e) {
 }
 
 // ---- LayerNorm folding for the decode chain (kernels_dgemm.hip) ------------------------------------------------
-// bf16 round-to-nearest-even of an fp32 value, as v_cvt_pk_bf16_f32 does it (the column sums must be taken over
-// exactly the values the MFMA will see)
+// An fp32 value rounded to the 16-bit operand type of this build (round-to-nearest-even, as the device conversions do
+// it): the column sums of a folded LayerNorm must be taken over exactly the values the MFMA will see.
+#ifdef GITMI_OPS_F16
+static inline float bf16_round(float f) { return (float)(_Float16)f; }
+#else
 static inline float bf16_round(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -542,6 +553,7 @@ static inline float bf16_round(float f) {
     memcpy(&f, &u, 4);
     return f;
 }
+#endif
 // W [rows, K], bias [rows], LayerNorm (gamma, beta) [K] in front of it  ->  device W' (bf16), folded bias, column sums
 static int fold_layernorm(gitmi_engine* e, const std::vector<float>& W, const std::vector<float>& bias,
                           const std::vector<float>& gamma, const std::vector<float>& beta, int64_t rows, int K,

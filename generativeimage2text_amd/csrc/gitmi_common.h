@@ -10,9 +10,38 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 #define GITMI_WAVE 64
 
-// ---- bf16 <-> f32: gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even, NaN-safe);
-// a (__bf16) cast is what makes hipcc emit it -- no branches, one instruction per pair
+// ---- the 16-bit OPERAND type of the fast engine mode.  Default: bfloat16 (the benchmarked mode).  With -DGITMI_OPS_F16
+// the very same kernels are built for IEEE fp16 operands (libgitmi_f16.so: `v_mfma_f32_16x16x32_f16` runs at the bf16
+// rate and carries 3 more mantissa bits; every operand of this path -- LayerNorm outputs, attention probabilities,
+// weights of N(0, 0.02) / width^-0.5 scale -- is far inside fp16's range).  `bf16_t` stays the name of the raw 16-bit
+// storage type in both builds; pack2bf / f2bf / bf2f / unpack2op convert to and from the OPERAND encoding of the build.
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+#ifdef GITMI_OPS_F16
+#define GITMI_OPERAND_NAME "f16"
+__device__ __forceinline__ float bf2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    const _Float16 b = (_Float16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    const f16x2_t v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ void unpack2op(uint32_t u, float& lo, float& hi) {
+    const f16x2_t v = __builtin_bit_cast(f16x2_t, u);
+    lo = (float)v[0];
+    hi = (float)v[1];
+}
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+#else
+#define GITMI_OPERAND_NAME "bf16"
+// bf16 <-> f32: gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even, NaN-safe); a (__bf16) cast is
+// what makes hipcc emit it -- no branches, one instruction per pair
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
     const __bf16 b = (__bf16)f;
@@ -22,11 +51,17 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(uint32_t, v);
 }
+__device__ __forceinline__ void unpack2op(uint32_t u, float& lo, float& hi) {
+    lo = __uint_as_float(u << 16);
+    hi = __uint_as_float(u & 0xffff0000u);
+}
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+#endif
 
 // ---- fp16: storage type of the residual stream in bf16 engine mode (GITMI_STREAM_F16): half the bytes of fp32 at
 // 2^-11 relative rounding -- tools/residual_precision_study.py: +0.002 max feature error, a bf16 stream costs 3x
-typedef _Float16 f16_t;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 __device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
     const f16x2_t v = {(_Float16)lo, (_Float16)hi};
     return __builtin_bit_cast(uint32_t, v);
@@ -67,10 +102,7 @@ template <> __device__ __forceinline__ void st<f16_t>(f16_t* p, float v) { *p = 
 __device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
     u32x4_t r = *reinterpret_cast<const u32x4_t*>(p);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v[2 * i] = __uint_as_float(r[i] << 16);
-        v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
-    }
+    for (int i = 0; i < 4; ++i) unpack2op(r[i], v[2 * i], v[2 * i + 1]);
 }
 __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
     f32x4_t a = *reinterpret_cast<const f32x4_t*>(p);

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_full_mfma_kernel(AttnFullArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (st_ * 16 + l15) * FA_LDK + ks * 32 + lg * 8);
-                    s_acc[st_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s_acc[st_], 0, 0, 0);
+                    s_acc[st_] = mfma16(kf, qf[t][ks], s_acc[st_]);
                 }
             }
             // lane holds keys kt + st*16 + lg*4 + r for its query
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void attn_full_mfma_kernel(AttnFullArgs a) {
                     const bf16_t* vp = Vt + (dt * 16 + l15) * FA_LDV + hf * 32 + lg * 4;
                     vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
                     vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 16);
-                    o_acc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf, o_acc[t][dt], 0, 0, 0);
+                    o_acc[t][dt] = mfma16(vf.v, pf, o_acc[t][dt]);
                 }
             }
         }
@@ -349,8 +349,8 @@ __global__ __launch_bounds__(256, 2) void attn_full_mfma_short_kernel(AttnFullAr
             const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t*>(Ks + (st_ * 16 + l15) * FA_LDK + 32 + lg * 8);
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
-                sacc[u][st_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[u][0], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                sacc[u][st_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[u][1], sacc[u][st_], 0, 0, 0);
+                sacc[u][st_] = mfma16(kf0, qf[u][0], f32x4_t{0.f, 0.f, 0.f, 0.f});
+                sacc[u][st_] = mfma16(kf1, qf[u][1], sacc[u][st_]);
             }
             // many sub-tiles (GIT_LARGE: 17): keep the scheduler from hoisting every K fragment load to the top of the
             // unrolled loop -- with 136 score registers live that spilled
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_mfma_short_kernel(AttnFullAr
                 vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 16);
 #pragma unroll
                 for (int u = 0; u < NT; ++u)
-                    o_acc[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[u], o_acc[u][dt], 0, 0, 0);
+                    o_acc[u][dt] = mfma16(vf.v, pf[u], o_acc[u][dt]);
             }
         }
 #pragma unroll
@@ -482,8 +482,7 @@ template <> struct Raw8<bf16_t> {
     __device__ __forceinline__ void get(float (&v)[8]) const {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[2 * i] = __uint_as_float(r[i] << 16);
-            v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+            unpack2op(r[i], v[2 * i], v[2 * i + 1]);
         }
     }
 };

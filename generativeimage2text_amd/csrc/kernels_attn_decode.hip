@@ -62,8 +62,7 @@ __device__ __forceinline__ void ld8bf(const bf16_t* p, float (&v)[8]) {
     const u32x4_t r = *reinterpret_cast<const u32x4_t*>(p);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        v[2 * i] = __uint_as_float(r[i] << 16);
-        v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+        unpack2op(r[i], v[2 * i], v[2 * i + 1]);
     }
 }
 
@@ -184,8 +183,8 @@ __global__ __launch_bounds__(128) void attn_decode_mfma_kernel(AttnDecodeArgs a)
             const int s = s0 + 2 * c;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                sc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kq[c][t][0], qf[0], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                sc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kq[c][t][1], qf[1], sc[c][t], 0, 0, 0);
+                sc[c][t] = mfma16(kq[c][t][0], qf[0], f32x4_t{0.f, 0.f, 0.f, 0.f});
+                sc[c][t] = mfma16(kq[c][t][1], qf[1], sc[c][t]);
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(128) void attn_decode_mfma_kernel(AttnDecodeArgs a)
                 continue;
             }
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vq[c][dt], pf, oacc[dt], 0, 0, 0);
+            for (int dt = 0; dt < 4; ++dt) oacc[dt] = mfma16(vq[c][dt], pf, oacc[dt]);
         }
     }
     l_i += __shfl_xor(l_i, 16, 64);
@@ -273,8 +272,7 @@ __global__ __launch_bounds__(128) void attn_decode_mfma_kernel(AttnDecodeArgs a)
     auto unpack = [&](const u32x4_t& r, float (&v)[8]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[2 * i] = __uint_as_float(r[i] << 16);
-            v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+            unpack2op(r[i], v[2 * i], v[2 * i + 1]);
         }
     };
 #pragma unroll

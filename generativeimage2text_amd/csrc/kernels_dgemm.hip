@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs g) {
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[u][i], acc[i], 0, 0, 0);
+                acc[i] = mfma16(wf[u], xf[u][i], acc[i]);
     };
     constexpr int UBIG = MT >= 4 ? 6 : 12;       // <= 30 sixteen-byte loads in flight per lane
     int k = kb;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
             for (int u = 0; u < VKS; ++u)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[st][u], xf[u][i], acc[i], 0, 0, 0);
+                    acc[i] = mfma16(wf[st][u], xf[u][i], acc[i]);
             const int buf = st & 1;
 #pragma unroll
             for (int i = 0; i < MT; ++i) red[buf][wave][i][lane] = acc[i];

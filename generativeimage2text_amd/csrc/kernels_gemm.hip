@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+                        acc[j][i] = mfma16(wf[j], af[i], acc[j][i]);
             }
         } else {
             // four 4-deep f32 MFMA steps per 16-deep tile (exact fp32 fmaf chain)

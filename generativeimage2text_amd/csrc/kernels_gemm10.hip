@@ -78,7 +78,7 @@ template <typename T> __device__ __forceinline__ uint32_t pack2o(float lo, float
 }
 template <typename T> __device__ __forceinline__ void unpack2o(uint32_t u, float& lo, float& hi) {
     if constexpr (std::is_same<T, f16_t>::value) unpack2h(u, lo, hi);
-    else { lo = __uint_as_float(u << 16); hi = __uint_as_float(u & 0xffff0000u); }
+    else unpack2op(u, lo, hi);
 }
 
 template <int N> __device__ __forceinline__ void wait_vm() {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
-                    c[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], af[i][kk], c[j][i], 0, 0, 0);
+                    c[j][i] = mfma16(wf[j][kk], af[i][kk], c[j][i]);
         __builtin_amdgcn_s_setprio(0);
     };
 

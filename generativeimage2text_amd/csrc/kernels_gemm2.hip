@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dlds_kernel(GemmArgs g) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+                    acc[j][i] = mfma16(wf[j], af[i], acc[j][i]);
         }
         __syncthreads();   // (a) next stage landed (own loads drained before the barrier) (b) this stage free
     }
@@ -173,8 +173,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dlds_kernel(GemmArgs g) {
                         float f[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            f[2 * e] = __uint_as_float(v[e] << 16);
-                            f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
+                            unpack2op(v[e], f[2 * e], f[2 * e + 1]);
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { f[e] += r0[e]; f[4 + e] += r1[e]; }

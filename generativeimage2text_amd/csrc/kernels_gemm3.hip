@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+                    acc[j][i] = mfma16(wf[j], af[i], acc[j][i]);
         }
         // this wave's loads of step kt+1 have landed; the ones just issued (kt+2) may stay in flight
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -225,8 +225,7 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g) {
                     float f[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        f[2 * e] = __uint_as_float(v[e] << 16);
-                        f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
+                        unpack2op(v[e], f[2 * e], f[2 * e + 1]);
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { f[e] += r0[e]; f[4 + e] += r1[e]; }

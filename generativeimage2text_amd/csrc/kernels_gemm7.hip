@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512) void gemm_ring256_kernel(GemmArgs g) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+                    acc[j][i] = mfma16(wf[j], af[i], acc[j][i]);
         }
         // this wave's loads of step kt+1 have landed; steps kt+2 and kt+3 may stay in flight
         if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");

@@ -87,6 +87,91 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TS* __restrict__ x
     }
 }
 
+// The same LayerNorm for the wide rows of the bf16 engine mode (D = 768 / 1024: D % 256 == 0), one row per HALF wave:
+// a lane owns NCH chunks of 8 consecutive elements (chunk lane32 + 32 i), i.e. 16-byte loads of fp16 stream rows and
+// 16-byte bf16 stores -- the one-wave-per-row kernel above moves 8 bytes per lane and instruction and reached 2.8 TB/s on
+// the 36 launches per encode + prefill pass (13.8 us each for 12608 x 768; profiles/r03_a_solo_graph_kernel_stats.txt).
+// Statistics as above (fp32, centred second pass); only the order of the partial sums differs.
+template <typename TS, int NCH>
+__global__ __launch_bounds__(256) void layernorm_wide_kernel(const TS* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             const float* __restrict__ add_after, bf16_t* __restrict__ y_t,
+                                                             int ld_t, TS* __restrict__ y_f, int ld_f, int rows, RowMap map) {
+    constexpr int D = NCH * 256;
+    const int l32 = threadIdx.x & 31;
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= rows) return;
+    const TS* xr = x + (size_t)row * ldx;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (l32 + 32 * i) * 8;
+        if constexpr (sizeof(TS) == 2) {
+            const u32x4_t u = *reinterpret_cast<const u32x4_t*>(xr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) unpack2h(u[e], v[i][2 * e], v[i][2 * e + 1]);
+        } else {
+            ld8(reinterpret_cast<const float*>(xr) + c, v[i]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)D + eps);
+    const size_t orow = map_row(map, row);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (l32 + 32 * i) * 8;
+        float g8[8], b8[8], o[8];
+        ld8(gamma + c, g8);
+        ld8(beta + c, b8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g8[e] + b8[e];
+        if (add_after) {
+            float a8[8];
+            ld8(add_after + c, a8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += a8[e];
+        }
+        if (y_t) st8(y_t + orow * ld_t + c, o);
+        if (y_f) {
+            if constexpr (sizeof(TS) == 2) {
+                u32x4_t u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[e] = pack2h(o[2 * e], o[2 * e + 1]);
+                *reinterpret_cast<u32x4_t*>(y_f + orow * ld_f + c) = u;
+            } else {
+                st8(reinterpret_cast<float*>(y_f) + orow * ld_f + c, o);
+            }
+        }
+    }
+}
+
+// bf16 operand rows out, D = 768 / 1024, 16-byte aligned rows: the wide kernel; false: not applicable
+template <typename TS>
+static bool launch_layernorm_wide(const TS* x, int ldx, const float* gamma, const float* beta, float eps, const float* add_after,
+                                  bf16_t* y_t, int ld_t, TS* y_f, int ld_f, int rows, int D, RowMap m, hipStream_t s) {
+    if ((D != 768 && D != 1024) || (ldx & 7) || (ld_t & 7) || (y_f && (ld_f & 7))) return false;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y_t) & 15) || (reinterpret_cast<uintptr_t>(y_f) & 15) ||
+        (reinterpret_cast<uintptr_t>(gamma) & 15) || (reinterpret_cast<uintptr_t>(beta) & 15) ||
+        (reinterpret_cast<uintptr_t>(add_after) & 15))
+        return false;
+    dim3 grid((rows + 7) / 8), block(256);
+    if (D == 768) hipLaunchKernelGGL((layernorm_wide_kernel<TS, 3>), grid, block, 0, s, x, ldx, gamma, beta, eps, add_after, y_t, ld_t, y_f, ld_f, rows, m);
+    else hipLaunchKernelGGL((layernorm_wide_kernel<TS, 4>), grid, block, 0, s, x, ldx, gamma, beta, eps, add_after, y_t, ld_t, y_f, ld_f, rows, m);
+    return true;
+}
+
 // patches[(b*gh*gw + gy*gw + gx), c*p*p + ky*p + kx] = img[b, c, gy*p + ky, gx*p + kx]; zero pad to Kpad.
 // img is [B, C, H, W]; gh = H / p, gw = W / p (floor): like the stride-p convolution of CLIP/model.py:242 the
 // H % p bottom rows and W % p right columns are never read.
@@ -346,6 +431,8 @@ hipError_t launch_layernorm(const float* x, int ldx, const float* gamma, const f
     if (t_is_f32)
         hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, s, x, ldx, gamma, beta, eps, add_after,
                            (float*)y_t, ld_t, y_f, ld_f, rows, D, m);
+    else if (y_t && launch_layernorm_wide<float>(x, ldx, gamma, beta, eps, add_after, (bf16_t*)y_t, ld_t, y_f, ld_f, rows, D, m, s))
+        ;
     else
         hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, block, 0, s, x, ldx, gamma, beta, eps, add_after,
                            (bf16_t*)y_t, ld_t, y_f, ld_f, rows, D, m);
@@ -399,6 +486,9 @@ hipError_t launch_layernorm_s16(const void* x, int ldx, const float* gamma, cons
     if (t_is_f32)
         hipLaunchKernelGGL((layernorm_kernel<float, f16_t>), grid, block, 0, s, (const f16_t*)x, ldx, gamma, beta, eps,
                            add_after, (float*)y_t, ld_t, (f16_t*)y_s, ld_s, rows, D, m);
+    else if (y_t && launch_layernorm_wide<f16_t>((const f16_t*)x, ldx, gamma, beta, eps, add_after, (bf16_t*)y_t, ld_t, (f16_t*)y_s, ld_s,
+                                                 rows, D, m, s))
+        ;
     else
         hipLaunchKernelGGL((layernorm_kernel<bf16_t, f16_t>), grid, block, 0, s, (const f16_t*)x, ldx, gamma, beta, eps,
                            add_after, (bf16_t*)y_t, ld_t, (f16_t*)y_s, ld_s, rows, D, m);

@@ -13,7 +13,8 @@ from typing import Dict, List, Mapping, Optional, Sequence, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgitmi.so")
+LIB_PATH = os.path.join(_HERE, "libgitmi.so")                 # bf16 operands: the benchmarked build
+LIB_PATH_F16 = os.path.join(_HERE, "libgitmi_f16.so")         # the same sources built for fp16 operands (-DGITMI_OPS_F16)
 
 PREC_BF16, PREC_F32 = 0, 1
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
@@ -29,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_op_vocab_topm", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
     "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after", "gitmi_op_sample_rows",
     "gitmi_generate_encode", "gitmi_generate_decode", "gitmi_search_done_count",
-    "gitmi_debug_import_stage", "gitmi_debug_head_from", "gitmi_set_trie",
+    "gitmi_debug_import_stage", "gitmi_debug_head_from", "gitmi_set_trie", "gitmi_operand_dtype",
 ]
 
 
@@ -62,19 +63,20 @@ class GitmiError(RuntimeError):
     pass
 
 
-_lib = None
+_libs: Dict[str, C.CDLL] = {}
 
 
-def load_library() -> C.CDLL:
-    """dlopen libgitmi.so; raises (never falls back) when it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load_library(operands: str = "bf16") -> C.CDLL:
+    """dlopen libgitmi.so (operands="bf16") or libgitmi_f16.so (operands="f16"); raises (never falls back) when it has
+    not been built."""
+    if operands in _libs:
+        return _libs[operands]
+    path = {"bf16": LIB_PATH, "f16": LIB_PATH_F16}[operands]
+    if not os.path.exists(path):
         raise GitmiError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C generativeimage2text_amd/csrc`.  There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, i64p, fp = C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p
     lib.gitmi_abi_version.restype = C.c_int
     lib.gitmi_last_error.restype = C.c_char_p
@@ -123,13 +125,19 @@ def load_library() -> C.CDLL:
             getattr(lib, name).restype = C.c_int
     if lib.gitmi_abi_version() != 5:
         raise GitmiError("libgitmi.so ABI version mismatch")
-    _lib = lib
+    lib.gitmi_operand_dtype.restype = C.c_int
+    if lib.gitmi_operand_dtype() != {"bf16": DTYPE_BF16, "f16": DTYPE_F16}[operands]:
+        raise GitmiError(f"{path} was not built for {operands} operands")
+    _libs[operands] = lib
     return lib
 
 
 def _ck(rc: int) -> None:
     if rc != 0:
-        raise GitmiError(load_library().gitmi_last_error().decode("utf-8", "replace"))
+        # the message is thread-local per library: report whichever loaded library holds one
+        msgs = [(k, lib.gitmi_last_error().decode("utf-8", "replace")) for k, lib in _libs.items()]
+        msgs = [(k, m) for k, m in msgs if m]
+        raise GitmiError(msgs[0][1] if len(msgs) == 1 else " | ".join(f"[{k} library] {m}" for k, m in msgs) or "gitmi call failed")
 
 
 def _stream() -> int:
@@ -154,7 +162,8 @@ class Engine:
         (MinMaxResizeForTest models); default: the model config's max_image_hw, else the native square."""
         if not torch.cuda.is_available():
             raise GitmiError("no GPU visible: the GIT engine runs on MI355X (gfx950) only, there is no CPU fallback")
-        self.lib = load_library()
+        # precision: "bf16" (benchmarked mode) / "f16" (the fp16-operand build of the same kernels) / "f32" (exact parity mode)
+        self.lib = load_library("f16" if precision in ("f16", "fp16") else "bf16")
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.cfg = model_cfg
         self.precision = precision
@@ -162,7 +171,7 @@ class Engine:
         for name in ("image_size", "patch", "vit_width", "vit_layers", "vit_heads", "dec_hidden", "dec_layers",
                      "dec_heads", "dec_ffn", "vocab", "max_pos", "num_frames", "sos", "eos"):
             setattr(c, name, int(getattr(model_cfg, name)))
-        c.precision = {"bf16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32}[precision]
+        c.precision = {"bf16": PREC_BF16, "f16": PREC_BF16, "fp16": PREC_BF16, "f32": PREC_F32, "fp32": PREC_F32}[precision]
         c.max_batch, c.max_beams = int(max_batch), int(max_beams)
         c.max_frames, c.max_text_len = int(max_frames), int(max_text_len)
         if max_image_hw is None:

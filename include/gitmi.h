@@ -115,6 +115,11 @@ typedef struct gitmi_profile {
 
 /* ---- lifecycle ------------------------------------------------------------------- */
 int  gitmi_abi_version(void);
+/* The 16-bit operand type of the library's fast mode (GITMI_PREC_BF16 of gitmi_config.precision means "the 16-bit operand
+ * mode of this build"): GITMI_DTYPE_BF16 for libgitmi.so -- the benchmarked build --, GITMI_DTYPE_F16 for libgitmi_f16.so,
+ * the same sources built with -DGITMI_OPS_F16 (IEEE fp16 operands on v_mfma_f32_16x16x32_f16: same rate, 3 more
+ * mantissa bits; 16-bit operands handed to the gitmi_op_* entry points are then fp16 too). */
+int  gitmi_operand_dtype(void);
 const char* gitmi_last_error(void);
 /* replaces get_git_model(tokenizer, param) + model.cuda()  (model.py:9-61, inference.py:83-87) */
 int  gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** out);

@@ -90,7 +90,7 @@ def test_gemm_detects_transpose():
     assert torch.equal(out, W.float().t())
 
 
-@pytest.mark.parametrize("rows,D", [(5, 768), (1000, 1024), (33, 128), (7, 192)])
+@pytest.mark.parametrize("rows,D", [(5, 768), (1000, 1024), (33, 128), (7, 192), (12608, 768), (8224, 1024)])
 @pytest.mark.parametrize("eps", [1e-5, 1e-12])
 def test_layernorm(rows, D, eps):
     from generativeimage2text_amd import engine as E

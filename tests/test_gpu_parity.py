@@ -101,10 +101,14 @@ def check_f32(name):
     assert np.allclose(lps.numpy(), g["logprobs"], atol=1e-4), (lps, g["logprobs"])
 
 
-def check_bf16(name):
-    from generativeimage2text_amd.parity import bf16_bounds, ids_parity, lerr_frac_bound
-    g, cfg, feats, logits, preds, lps = run_case(name, "bf16")
-    bnd = bf16_bounds(cfg.name)
+def check_bf16(name, precision="bf16"):
+    """precision "bf16" (benchmarked build) or "f16" (the fp16-operand build of the same kernels: scaled bounds)"""
+    from generativeimage2text_amd.parity import F16_SCALE, bf16_bounds, ids_parity, lerr_frac_bound
+    g, cfg, feats, logits, preds, lps = run_case(name, precision)
+    bnd = dict(bf16_bounds(cfg.name))
+    if precision == "f16":
+        bnd["thr"] *= F16_SCALE["thr"]
+        bnd["ferr"] *= F16_SCALE["ferr"]
     big = cfg.vocab > 5000
     fs = feats[:, ::7, ::5] if big else feats
     ferr = float(np.abs(fs.numpy() - g["feat_sample"]).max())
@@ -112,11 +116,11 @@ def check_bf16(name):
     ref = g["tf_logits"]
     lerr = float(np.abs(ls.numpy() - ref).max())
     span = float(ref.max() - ref.min())
-    rec = {"case": name, "config": cfg.name, "ferr": round(ferr, 5), "lerr": round(lerr, 5), "span": round(span, 3),
-           "lerr_frac": round(lerr / span, 6)}
+    rec = {"case": name if precision == "bf16" else name + "@" + precision, "config": cfg.name, "ferr": round(ferr, 5),
+           "lerr": round(lerr, 5), "span": round(span, 3), "lerr_frac": round(lerr / span, 6)}
     try:
         assert ferr < bnd["ferr"], ferr
-        assert lerr < lerr_frac_bound(name, cfg.name) * span, (lerr, span)
+        assert lerr < lerr_frac_bound(name, cfg.name, precision) * span, (lerr, span)
         # token identity wherever the reference's own margin is resolvable at bf16 precision
         am = logits.argmax(-1).numpy()
         for r in range(am.shape[0]):
@@ -159,6 +163,13 @@ def test_full_size_bf16_within_tolerance(name):
     check_bf16(name)
 
 
+@pytest.mark.parametrize("name", TINY_CASES + BIG_CASES)
+def test_f16_operand_build_within_tolerance(name):
+    """libgitmi_f16.so: the same kernels built for fp16 operands (Engine(precision="f16")); bounds 0.3x / threshold 0.4x
+    of the bf16 build's."""
+    check_bf16(name, "f16")
+
+
 def _scripted_module():
     import importlib.util, os
     from conftest import ROOT
@@ -185,7 +196,7 @@ def test_full_batch_ids_against_reference(name):
     ref_p, ref_l = g["predictions"], g["logprobs"]
     chained = search.kind != "greedy"
     tf = torch.from_numpy(g["tf_tokens"])
-    for prec in ("f32", "bf16"):
+    for prec in ("f32", "bf16", "f16"):
         eng = make_engine(cfg, w, prec, B, search, frames=F)
         tokens, logprobs, info = eng.generate(dev, search_struct(search))
         preds, lps = format_like_reference(search, tokens, logprobs, info, None)
@@ -197,15 +208,18 @@ def test_full_batch_ids_against_reference(name):
             assert preds.shape == ref_p.shape and np.array_equal(preds.numpy(), ref_p)
             assert np.allclose(lps.numpy(), ref_l, atol=1e-4)
         else:
-            from generativeimage2text_amd.parity import IDENTICAL_FLOORS, bf16_bounds, lerr_frac_bound
+            from generativeimage2text_amd.parity import (F16_SCALE, IDENTICAL_FLOORS, IDENTICAL_FLOORS_F16, bf16_bounds,
+                                                         lerr_frac_bound)
             bnd = bf16_bounds(cfg.name)
+            thr = bnd["thr"] * (F16_SCALE["thr"] if prec == "f16" else 1.0)
+            floors = IDENTICAL_FLOORS_F16 if prec == "f16" else IDENTICAL_FLOORS
             span = float(g["tf_logits"].max() - g["tf_logits"].min())
-            rec = {"case": name, "config": cfg.name, "lerr": round(lerr, 5), "span": round(span, 3),
-                   "lerr_frac": round(lerr / span, 6)}
+            rec = {"case": name if prec == "bf16" else name + "@" + prec, "config": cfg.name, "lerr": round(lerr, 5),
+                   "span": round(span, 3), "lerr_frac": round(lerr / span, 6)}
             try:
-                assert lerr < lerr_frac_bound(name, cfg.name) * span, (lerr, span)
-                stats = ids_parity(preds.numpy(), ref_p, g["step_margin"], bnd["thr"] * (2 if chained else 1), chained,
-                                   min_identical=IDENTICAL_FLOORS[name])
+                assert lerr < lerr_frac_bound(name, cfg.name, prec) * span, (lerr, span)
+                stats = ids_parity(preds.numpy(), ref_p, g["step_margin"], thr * (2 if chained else 1), chained,
+                                   min_identical=floors[name])
                 rec.update(stats)
                 print(name, prec, "logit err %.4f of span %.2f" % (lerr, span), stats)
             finally:

@@ -322,9 +322,19 @@ def test_every_entry_point_has_ctypes_prototypes():
     # a missing argtypes list makes ctypes pass 64-bit pointers as C ints (truncated): every bound symbol must declare them
     lib = engine.load_library()
     for name in engine.EXPORTED_SYMBOLS:
-        if name in ("gitmi_abi_version", "gitmi_last_error"):
+        if name in ("gitmi_abi_version", "gitmi_last_error", "gitmi_operand_dtype"):      # no arguments
             continue
         assert getattr(lib, name).argtypes is not None, name
+
+
+def test_both_operand_builds_load_and_identify_themselves():
+    """libgitmi.so (bf16 operands, the benchmarked build) and libgitmi_f16.so (the same sources with -DGITMI_OPS_F16):
+    same ABI, every declared symbol, and each says which 16-bit operand type it was built for."""
+    a, b = engine.load_library("bf16"), engine.load_library("f16")
+    assert a.gitmi_operand_dtype() == engine.DTYPE_BF16 and b.gitmi_operand_dtype() == engine.DTYPE_F16
+    assert a.gitmi_abi_version() == b.gitmi_abi_version() == 5
+    for name in engine.EXPORTED_SYMBOLS:
+        getattr(b, name)
 
 
 def test_config_struct_fields_agree_across_header_binding_and_integration_doc():

@@ -25,7 +25,7 @@ import collections
 import sqlite3
 import statistics
 
-ENCODER_MARKS = ("gemm_p8", "gemm_ring", "gemm_dlds", "gemm_kernel", "layernorm_kernel", "attn_full", "im2col", "vit_assemble",
+ENCODER_MARKS = ("gemm_p8", "gemm_ring", "gemm_dlds", "gemm_kernel", "layernorm_kernel", "layernorm_wide", "attn_full", "im2col", "vit_assemble",
                  "kv_repack", "convert_pad", "pos_bicubic")
 DECODE_MARKS = ("dgemm_kernel", "attn_decode", "vocab_topm", "search_step", "search_init", "search_finish", "embed_ln",
                 "row_topm", "sample_rows", "fill_start", "fill_i32", "load_ids")
