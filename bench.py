@@ -285,6 +285,8 @@ def main(argv=None, engine_factory=None):
     ap.add_argument("--contexts", type=int, default=4,
                     help="engine contexts (shared weights) kept in flight on separate HIP streams")
     ap.add_argument("--free-run", action="store_true", help="do not chain the contexts' image encoders at all")
+    ap.add_argument("--solo-policy", action="store_true",
+                    help="A/B: keep the kernel shapes of a context that has the device to itself (no gitmi_set_shared_device)")
     ap.add_argument("--encoder-chains", type=int, default=2,
                     help="image encoders of the contexts in flight are chained (context i starts its encoder after "
                          "context i - chains has finished its own): at most this many encoders run at a time")
@@ -292,6 +294,11 @@ def main(argv=None, engine_factory=None):
                     help="N > 1: N requests of --batch images are served by ONE engine pass over N x batch rows "
                          "(Engine.generate_coalesced; the concatenation is inside the timed region).  A step is still one "
                          "request of --batch images; the default 1 is the BASELINE configuration (one pass per request)")
+    ap.add_argument("--decode-group", type=int, default=1,
+                    help="G > 1: the contexts are MEMBERS of decode groups of G (gitmi_set_decode_group): every request "
+                         "of --batch images is encoded + prefilled by its own context as it is submitted, and the G "
+                         "requests of a group share ONE decode chain over G x batch rows (gitmi_group_decode).  A step is "
+                         "still one request of --batch images; --contexts must be a multiple of G")
     ap.add_argument("--phased", type=int, default=0,
                     help="G > 0: schedule the contexts in groups of G batches -- the image encoders (+ prefill) of a group "
                          "first (at most --encoder-chains at a time), then its G decode chains side by side with no "
@@ -339,6 +346,13 @@ def main(argv=None, engine_factory=None):
     coalesce = max(1, args.coalesce)
     if coalesce > 1 and args.phased > 0:
         raise SystemExit("--coalesce and --phased are separate schedules")
+    dgroup = max(1, args.decode_group)
+    if dgroup > 1:
+        if coalesce > 1 or args.phased > 0:
+            raise SystemExit("--decode-group, --coalesce and --phased are separate schedules")
+        if args.contexts % dgroup or args.steps % dgroup:
+            raise SystemExit(f"--contexts {args.contexts} and --steps {args.steps} must be multiples of --decode-group {dgroup}")
+        args.warmup = (args.warmup + dgroup - 1) // dgroup * dgroup
     if args.steps % coalesce:
         raise SystemExit(f"--steps {args.steps} is not a multiple of --coalesce {coalesce} (a partial pass would re-capture "
                          f"the context's hipGraph inside the timed region)")
@@ -362,8 +376,18 @@ def main(argv=None, engine_factory=None):
     # one batch overlap the MFMA-bound encoder of the next (weights are shared, workspaces are not)
     if args.phased > 0:
         args.contexts = args.phased
-    ctxs = [eng] + [eng.clone() for _ in range(max(1, args.contexts) - 1)]
-    for c in ctxs[1:]:
+    if args.contexts > 1 and not args.solo_policy and not standin:
+        eng.set_shared_device(True)             # before cloning: the clones inherit it
+    groups = []
+    if dgroup > 1:
+        # `eng` stays a plain context (solo passes, profiling); members and group contexts are clones of it
+        ctxs = [eng.clone() for _ in range(args.contexts)]
+        groups = [eng.clone(max_batch=dgroup * args.batch) for _ in range(args.contexts // dgroup)]
+        for i, c in enumerate(ctxs):
+            c.set_decode_group(groups[i // dgroup], (i % dgroup) * args.batch)
+    else:
+        ctxs = [eng] + [eng.clone() for _ in range(max(1, args.contexts) - 1)]
+    for c in ctxs[1:] + groups:
         if args.no_graph:
             c.set_graph(False)
     chains = max(1, args.encoder_chains)
@@ -376,6 +400,8 @@ def main(argv=None, engine_factory=None):
     stride = int(os.environ.get("BENCH_STREAM_STRIDE", "1"))
     pool = [dev.Stream() for _ in range(len(ctxs) * stride)]
     streams = pool[::stride][:len(ctxs)]
+    gstreams = [dev.Stream() for _ in groups]
+    pending = [[] for _ in groups]
     counter = [0]
     if args.search == "greedy":
         search = Engine.make_search("greedy", args.max_steps, 1, 1)
@@ -398,6 +424,32 @@ def main(argv=None, engine_factory=None):
                 e1.record()
                 lat_events.append((e0, e1))
         return tokens, info
+
+    def grouped_step(record_latency=False):
+        """one request: its member context encodes + prefills it; the request that completes a group submits the group's
+        decode chain over all G requests"""
+        i = counter[0] % len(ctxs)
+        counter[0] += 1
+        g, slot = divmod(i, dgroup)
+        with dev.stream(streams[i]):
+            if record_latency:
+                e0 = dev.Event(enable_timing=True)
+                e0.record()
+                pending[g].append(e0)
+            ctxs[i].generate_encode(frames, search)
+        if slot != dgroup - 1:
+            return None
+        with dev.stream(gstreams[g]):
+            tokens, logprobs, info = groups[g].group_decode(max(1, args.frames), dgroup * args.batch, search, sync=False)
+            if world > 1:
+                for r in range(dgroup):
+                    gather_results(tokens[r * args.batch:(r + 1) * args.batch], logprobs[r * args.batch:(r + 1) * args.batch])
+            if record_latency:
+                e1 = dev.Event(enable_timing=True)
+                e1.record()
+                lat_events.extend((e0, e1) for e0 in pending[g])
+                pending[g] = []
+        return tokens[-args.batch:], info
 
     def fence():
         if world > 1:
@@ -458,7 +510,10 @@ def main(argv=None, engine_factory=None):
 
     def run_steps(k, record_latency=False):
         out = None
-        if coalesce > 1:
+        if dgroup > 1:
+            for _ in range(k):
+                out = grouped_step(record_latency) or out
+        elif coalesce > 1:
             done = 0
             while done < k:
                 n = min(coalesce, k - done)
@@ -477,6 +532,7 @@ def main(argv=None, engine_factory=None):
 
     # every context captures its hipGraph before anything is timed (a context's first call captures and instantiates)
     run_steps(len(ctxs) * coalesce)
+    run_steps(len(ctxs) if dgroup > 1 else 0)        # a second round: the members' repacks have now waited on a decode
     fence()
     run_steps(args.warmup)
     fence()
@@ -508,8 +564,11 @@ def main(argv=None, engine_factory=None):
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "decode_steps_per_caption": steps_run, "seq_len_returned": info_h[0],
                        "hip_graph": not args.no_graph, "contexts_in_flight": len(ctxs),
+                       "shared_device_policy": bool(args.contexts > 1 and not args.solo_policy),
                        "encoder_chains": 0 if (args.free_run or len(ctxs) <= chains) else chains,
                        "schedule": (f"mixed, {coalesce} requests of {args.batch} images coalesced per engine pass" if coalesce > 1
+                                    else f"mixed, decode groups: every request encoded by its own context, {dgroup} requests "
+                                         f"per decode chain ({dgroup * args.batch} rows)" if dgroup > 1
                                     else "mixed" if args.phased <= 0 else f"phased: groups of {args.phased} batches, "
                                     f"encoders first, then the decode chains side by side")},
             # a batch's own latency (submit -> ids ready) while `contexts_in_flight` batches share the GPU
@@ -562,7 +621,31 @@ def main(argv=None, engine_factory=None):
             "method": "HIP events around the decode hipGraph of one context (production launch path), averaged over "
                       "5 replays; eager_step_ms = the same step with one host launch per kernel",
         }
-        if pmc:
+        if dgroup > 1:
+            # the production decode chain of this schedule runs over the rows of a whole group: time THAT chain (graph
+            # replays of one group context alone; its members publish once, the cache stays valid between replays)
+            for m in ctxs[:dgroup]:
+                m.generate_encode(frames, search)
+            groups[0].group_decode(max(1, args.frames), dgroup * args.batch, search, sync=True)
+            g0, g1 = dev.Event(enable_timing=True), dev.Event(enable_timing=True)
+            g0.record()
+            for _ in range(5):
+                groups[0].group_decode(max(1, args.frames), dgroup * args.batch, search, sync=False)
+            g1.record()
+            dev.synchronize()
+            gstep_ms = g0.elapsed_time(g1) / 5 / max(1, args.max_steps - 1)
+            n_img_tok = max(1, args.frames) * ((cfg.image_size // cfg.patch) ** 2 + 1)
+            kv_row = cfg.dec_layers * 2.0 * (n_img_tok + beams * 0.5 * (1 + args.max_steps)) * cfg.dec_hidden * 2
+            gbytes = gprof["decode_step_bytes"] + (dgroup - 1) * args.batch * kv_row      # weights once, K/V per row
+            ggbs = gbytes / (gstep_ms * 1e-3) / 1e9
+            result["roofline_decode"].update({
+                "achieved": round(ggbs, 1), "frac": round(ggbs / PEAK_HBM_GBS, 4), "bytes_per_step": gbytes,
+                "avg_step_ms": round(gstep_ms, 4), "rows_per_step": dgroup * args.batch * beams,
+                "solo_request_step_ms": round(step_ms, 4),
+                "method": f"HIP events around 5 replays of the decode hipGraph of one GROUP context alone ({dgroup} requests, "
+                          f"{dgroup * args.batch} rows per chain: the production launch path of this schedule); "
+                          "solo_request_step_ms = the chain of one request on its own"})
+        if pmc and dgroup == 1:
             per_step = 0.0
             for key, launches in (("dgemm", 4 * cfg.dec_layers), ("attn_decode", cfg.dec_layers), ("vocab", 1)):
                 if key in pmc and "hbm_bytes" in pmc[key]:

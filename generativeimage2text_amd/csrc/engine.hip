@@ -139,6 +139,10 @@ struct gitmi_engine {
     bool trie_search = false;           // the current search is GITMI_SEARCH_TRIE
     gitmi_search sample{};              // sampling parameters of the current search (do_sample, top_k, top_p, temperature, seed)
     int attn_dbg = 0, dgemm_dbg = 0;    // timing experiments (GITMI_ATTN_DBG, GITMI_DGEMM_DBG)
+    int attn_pw = 0;                    // (sentence, head) pairs per workgroup of the decode attention (GITMI_ATTN_PW; 0 = by policy)
+    bool shared_device = false;         // gitmi_set_shared_device: other contexts run beside this one
+    int decode_skip = 0;                // timing experiment (GITMI_DECODE_SKIP): launches of the decode chain left out --
+                                        // 1 attention, 2 QKV / FFN1 GEMMs, 4 out-proj / FFN2 GEMMs, 8 vocabulary head (ids are garbage)
     bool use_temb = true;               // add img_temperal_embedding[i] to frame i (the reference does so only for a LIST of frames)
     std::vector<int> plen_host, img_of_host;
     const float* const* frames_dummy = nullptr;
@@ -167,6 +171,16 @@ struct gitmi_engine {
     gitmi_engine* enc_after = nullptr;
     std::vector<gitmi_engine*> enc_watchers;   // contexts whose enc_after is this one (they wait on enc_done)
     hipEvent_t enc_done = nullptr;
+    // decode group (gitmi_set_decode_group): the image K/V (decode layout) of this MEMBER context live in `kv_group`'s
+    // cache, images [kv_image_off, kv_image_off + B); the group context runs ONE decode chain over the images of all its
+    // members (gitmi_group_decode).  A member's K/V repack is deferred to the end of its prefill (a graph of its own)
+    // so that only those few launches, not its image encoder, wait for the group's previous decode chain.
+    gitmi_engine* kv_group = nullptr;
+    int kv_image_off = 0;
+    std::vector<gitmi_engine*> kv_members;      // on the group context
+    hipEvent_t kv_published = nullptr;          // member: the K/V of its latest request are in the group's cache
+    hipEvent_t group_dec_done = nullptr;        // group: the latest decode chain over the cache has finished
+    bool graph_is_group = false;
     double split_encode_ms = 0, split_decode_ms = 0;
     int split_calls = 0, split_steps = 0;
     std::vector<TimedSpan> spans;
@@ -234,6 +248,7 @@ static int gemm(gitmi_engine* e, hipStream_t s, const void* A, int lda, const vo
     GemmArgs g{};
     g.A = A; g.W = W; g.bias = bias; g.res = res; g.C = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldr; g.act = act;
+    g.shared = e->shared_device ? 1 : 0;
     SpanGuard sp(e, s, tag, 2.0 * (double)M * (double)N * (double)K);
     HIPCK(launch_gemm(g, e->f32, out_f32, s));
     return 0;
@@ -246,6 +261,7 @@ static int gemm_stream(gitmi_engine* e, hipStream_t s, const void* A, int lda, c
     g.A = A; g.W = W; g.bias = bias; g.res = (const float*)res; g.C = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldr; g.act = 0;
     g.out_f16 = e->stream_f16 ? 1 : 0;
+    g.shared = e->shared_device ? 1 : 0;
     SpanGuard sp(e, s, tag, 2.0 * (double)M * (double)N * (double)K);
     HIPCK(launch_gemm(g, e->f32, !e->stream_f16, s));
     return 0;
@@ -313,6 +329,8 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     if (const char* env = getenv("GITMI_ATTN_IMPL")) e->attn_impl = e->f32 ? 0 : atoi(env);
     if (const char* env = getenv("GITMI_GRAPH")) e->use_graph = atoi(env) != 0;
     if (const char* env = getenv("GITMI_ATTN_DBG")) e->attn_dbg = atoi(env);
+    if (const char* env = getenv("GITMI_ATTN_PW")) e->attn_pw = atoi(env);
+    if (const char* env = getenv("GITMI_DECODE_SKIP")) e->decode_skip = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_DBG")) e->dgemm_dbg = atoi(env);
     if (const char* env = getenv("GITMI_SKINNY")) e->skinny = atoi(env) != 0;
     e->stream_f16 = !e->f32;
@@ -343,6 +361,16 @@ extern "C" void gitmi_destroy(gitmi_engine* e) {
         w.erase(std::remove(w.begin(), w.end(), e), w.end());
     }
     for (gitmi_engine* w : e->enc_watchers) w->enc_after = nullptr;
+    if (e->kv_group) {
+        auto& v = e->kv_group->kv_members;
+        v.erase(std::remove(v.begin(), v.end(), e), v.end());
+    }
+    for (gitmi_engine* m : e->kv_members) {       // members of a destroyed group go back to their own caches
+        m->kv_group = nullptr; m->kv_image_off = 0;
+        destroy_graph(m);
+    }
+    if (e->kv_published) hipEventDestroy(e->kv_published);
+    if (e->group_dec_done) hipEventDestroy(e->group_dec_done);
     destroy_graph(e);
     if (e->own_stream) hipStreamDestroy(e->own_stream);
     if (e->fence_in) hipEventDestroy(e->fence_in);
@@ -744,17 +772,20 @@ extern "C" int gitmi_finalize_weights(gitmi_engine* e) {
 // workspaces, KV caches, search state, streams and graph).  Lets a server keep several batches in
 // flight on different HIP streams: the latency-bound decode steps of one batch overlap the
 // MFMA-bound encoder of the next.  `src` must outlive the clone.
-extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
+static int clone_impl(gitmi_engine* src, int max_batch, gitmi_engine** out) {
     if (!src || !out) return fail("gitmi_clone: null argument");
     if (!src->finalized) return fail("gitmi_clone: source weights not finalized");
+    if (max_batch < 1) return fail("gitmi_clone_sized: max_batch %d", max_batch);
     HIPCK(hipSetDevice(src->device));
     gitmi_engine* e = new gitmi_engine();
-    e->cfg = src->cfg; e->device = src->device; e->f32 = src->f32; e->esz = src->esz; e->stream_f16 = src->stream_f16;
+    e->cfg = src->cfg; e->cfg.max_batch = max_batch; e->device = src->device; e->f32 = src->f32; e->esz = src->esz; e->stream_f16 = src->stream_f16;
     e->attn_impl = src->attn_impl; e->Kp = src->Kp; e->Kp_pad = src->Kp_pad;
     // a clone starts at the native resolution (its own gitmi_set_image_shape state and resized table)
     e->N_nat = e->N = src->N_nat; e->g_nat = e->gh = e->gw = src->g_nat; e->H = e->W = src->cfg.image_size;
     e->Nmax = src->Nmax; e->max_pixels = src->max_pixels;
     e->use_graph = src->use_graph; e->skinny = src->skinny; e->use_temb = src->use_temb;
+    e->attn_dbg = src->attn_dbg; e->dgemm_dbg = src->dgemm_dbg; e->attn_pw = src->attn_pw; e->decode_skip = src->decode_skip;
+    e->shared_device = src->shared_device;
     e->parent = src->parent ? src->parent : src;
     e->conv_w = src->conv_w; e->cls = src->cls; e->pos = src->pos; e->pos_cur = src->pos;
     e->lnpre_g = src->lnpre_g; e->lnpre_b = src->lnpre_b; e->lnpost_g = src->lnpost_g; e->lnpost_b = src->lnpost_b;
@@ -769,6 +800,12 @@ extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
     e->finalized = true;
     *out = e;
     return 0;
+}
+extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
+    return clone_impl(src, src ? src->cfg.max_batch : 0, out);
+}
+extern "C" int gitmi_clone_sized(gitmi_engine* src, int max_batch, gitmi_engine** out) {
+    return clone_impl(src, max_batch, out);
 }
 
 // ---- input resolution (CLIP/model.py:243-251) ---------------------------------------------
@@ -857,8 +894,19 @@ static int encode_frames_impl(gitmi_engine* e, const float* const* frames, int F
 // image K/V of layer l into the decode layout: head-major (fp32 VALU kernel) or the MFMA operand layouts (bf16)
 static int kv_repack(gitmi_engine* e, int l, int B, int Nimg, hipStream_t s) {
     const gitmi_config& c = e->cfg;
-    if (e->f32) HIPCK(launch_kv_repack(e->img_kv[l], e->img_kh[l], e->img_vh[l], B, Nimg, c.dec_heads, c.dec_hidden, true, s));
-    else HIPCK(launch_kv_repack_frag(e->img_kv[l], e->img_kh[l], e->img_vh[l], B, Nimg, round_up(Nimg, 32), c.dec_heads, c.dec_hidden, s));
+    // a member of a decode group writes into the group's cache, at its image offset (per image: all heads x padded keys)
+    gitmi_engine* o = e->kv_group ? e->kv_group : e;
+    const size_t off = (size_t)e->kv_image_off * (e->f32 ? Nimg : round_up(Nimg, 32)) * c.dec_hidden * e->esz;
+    void* kh = (char*)o->img_kh[l] + off;
+    void* vh = (char*)o->img_vh[l] + off;
+    if (e->f32) HIPCK(launch_kv_repack(e->img_kv[l], kh, vh, B, Nimg, c.dec_heads, c.dec_hidden, true, s));
+    else HIPCK(launch_kv_repack_frag(e->img_kv[l], kh, vh, B, Nimg, round_up(Nimg, 32), c.dec_heads, c.dec_hidden, s));
+    return 0;
+}
+
+// decode-group member: the repacks of every layer, after the prefill (its own graph: generate_run)
+static int publish_kv(gitmi_engine* e, hipStream_t s) {
+    for (int l = 0; l < e->cfg.dec_layers; ++l) RCK(kv_repack(e, l, e->cur_B, e->cur_Nimg, s));
     return 0;
 }
 
@@ -867,6 +915,7 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
     const int d = c.dec_hidden, ffn = c.dec_ffn, D = c.vit_width;
     const int B = e->cur_B, Nimg = e->cur_Nimg, M = B * Nimg;
     SpanGuard phase(e, s, TAG_PREFILL, 0);
+    const bool defer = e->kv_group != nullptr;          // publish_kv() follows
     RCK(gemm_stream(e, s, e->feats, D, e->vp_w, e->vp_b, nullptr, 0, e->p_y, d, M, d, D, TAG_GEMM_OTHER));
     RCK(ln_stream(e, s, e->p_y, d, e->vp_lng, e->vp_lnb, 1e-5f, e->p_ht, d, e->p_hf, d, M, d));
     for (int l = 0; l < c.dec_layers; ++l) {
@@ -874,12 +923,12 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
         const bool last = l + 1 == c.dec_layers;
         if (!last) {
             RCK(gemm(e, s, e->p_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->img_kv[l], 3 * d, e->f32, M, 3 * d, d, 0, TAG_GEMM_OTHER));
-            RCK(kv_repack(e, l, B, Nimg, s));
+            if (!defer) RCK(kv_repack(e, l, B, Nimg, s));
         } else {
             // the last layer's image-row outputs are never consumed: only its K and V are needed
             RCK(gemm(e, s, e->p_ht, d, (char*)L.wqkv + (size_t)d * d * e->esz, L.bqkv + d, nullptr, 0,
                      (char*)e->img_kv[l] + (size_t)d * e->esz, 3 * d, e->f32, M, 2 * d, d, 0, TAG_GEMM_OTHER));
-            RCK(kv_repack(e, l, B, Nimg, s));
+            if (!defer) RCK(kv_repack(e, l, B, Nimg, s));
             break;
         }
         AttnFullArgs a{};
@@ -934,7 +983,7 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
             q.bias = L.bqkv_f;
             if (l > 0) { q.colsum = L.cs_qkv; q.stats_in = e->stats_o; q.strips_in = strips; q.inv_d = inv_d; q.eps_in = 1e-12f; }
             q.C = e->d_qkv; q.ldc = 3 * d; q.act = 0; q.M = R; q.N = 3 * d; q.K = d;
-            RCK(dgemm(e, s, q));
+            if (!(e->decode_skip & 2)) RCK(dgemm(e, s, q));
         } else {
             RCK(gemm(e, s, e->d_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->d_qkv, 3 * d, e->f32, R, 3 * d, d, 0, TAG_GEMM_OTHER));
         }
@@ -946,8 +995,9 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
         a.out_frag = chain ? 1 : 0;
         a.N_pad = round_up(e->cur_Nimg, 32);
         a.dbg = e->attn_dbg;
+        a.pairs_per_wg = e->attn_pw > 0 ? e->attn_pw : e->shared_device ? 2 : 1;
         if (e->f32) HIPCK(launch_attn_decode(a, B, c.dec_heads, true, s));
-        else HIPCK(launch_attn_decode_mfma(a, B, c.dec_heads, s));
+        else if (!(e->decode_skip & 1)) HIPCK(launch_attn_decode_mfma(a, B, c.dec_heads, s));
         if (chain) {
             DGemmArgs o{};
             o.A = (const unsigned short*)e->d_ctx; o.lda = d; o.W = (const unsigned short*)L.wo_p; o.bias = L.bo;
@@ -955,19 +1005,19 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
             if (l > 0) { o.res_stats = e->stats_o; o.res_strips = strips; o.res_gamma = Lp->lnog; o.res_beta = Lp->lnob; o.res_inv_d = inv_d; o.res_eps = 1e-12f; }
             o.x_out = e->xa_f; o.xb_out = (unsigned short*)e->xa_b; o.stats_out = e->stats_a;
             o.M = R; o.N = d; o.K = d;
-            RCK(dgemm(e, s, o));
+            if (!(e->decode_skip & 4)) RCK(dgemm(e, s, o));
             DGemmArgs f1{};
             f1.A = (const unsigned short*)e->xa_b; f1.lda = d; f1.W = (const unsigned short*)L.w1_f; f1.bias = L.b1_f; f1.colsum = L.cs_1;
             f1.stats_in = e->stats_a; f1.strips_in = strips; f1.inv_d = inv_d; f1.eps_in = 1e-12f;
             f1.C = e->d_u; f1.ldc = ffn; f1.c_frag = 1; f1.act = 2; f1.M = R; f1.N = ffn; f1.K = d;
-            RCK(dgemm(e, s, f1));
+            if (!(e->decode_skip & 2)) RCK(dgemm(e, s, f1));
             DGemmArgs f2{};
             f2.A = (const unsigned short*)e->d_u; f2.lda = ffn; f2.W = (const unsigned short*)L.w2_p; f2.bias = L.b2;
             f2.res_x = e->xa_f; f2.res_stats = e->stats_a; f2.res_strips = strips; f2.res_gamma = L.lnag; f2.res_beta = L.lnab;
             f2.res_inv_d = inv_d; f2.res_eps = 1e-12f;
             f2.x_out = e->xo_f; f2.xb_out = (unsigned short*)e->xo_b; f2.stats_out = e->stats_o;
             f2.M = R; f2.N = d; f2.K = ffn;
-            RCK(dgemm(e, s, f2));
+            if (!(e->decode_skip & 4)) RCK(dgemm(e, s, f2));
         } else {
             RCK(gemm(e, s, e->d_ctx, d, L.wo, L.bo, e->d_hf, d, e->d_y, d, true, R, d, d, 0, TAG_GEMM_OTHER));
             HIPCK(launch_layernorm(e->d_y, d, L.lnag, L.lnab, 1e-12f, nullptr, e->d_ht, d, e->f32, e->d_hf, d, R, d, 0, 0, 0, s));
@@ -1010,7 +1060,7 @@ static int decode_head_impl(gitmi_engine* e, const int* ids, int ld_ids, int cur
         v.logits_out = logits_out; v.ld_logits = ldl;
         {
             SpanGuard sp(e, s, TAG_GEMM_OTHER, 2.0 * (double)R * (double)c.vocab * (double)d);
-            HIPCK(launch_vocab_topm(v, M, s));
+            if (!(e->decode_skip & 8)) HIPCK(launch_vocab_topm(v, M, s));
         }
         cands->nparts = e->vocab_nparts; cands->slots = vocab_mtop_slots(M);
         if (sampling) RCK(sample_candidates(e, logits_out, ldl, R, cur_len, s, cands));
@@ -1048,6 +1098,7 @@ extern "C" int gitmi_encode_frames(gitmi_engine* e, const float* const* frames, 
 extern "C" int gitmi_prefill(gitmi_engine* e, void* stream) {
     RCK(check_ready(e));
     if (!e->have_feats) return fail("prefill: no encoded frames");
+    if (e->kv_group) return fail("prefill: this context is a member of a decode group (gitmi_generate_encode publishes its K/V)");
     return prefill_impl(e, (hipStream_t)stream);
 }
 
@@ -1335,15 +1386,35 @@ static int generate_body(gitmi_engine* e, const float* const* frames, int F, int
 // common tail of gitmi_generate / gitmi_generate_prefixed: start_dev / plen_dev / img_of_dev are already enqueued on `s`
 // phase 0: the whole call.  phase 1 / 2: its two halves as separate submissions (gitmi_generate_encode /
 // gitmi_generate_decode) -- 1 = stage the frames, image encoder + decoder prefill; 2 = search over the text positions +
-// results -- for schedules that order the halves of several contexts themselves.
+// results -- for schedules that order the halves of several contexts themselves.  phase 3: the decode half on a GROUP
+// context, over the image K/V its member contexts published (gitmi_group_decode).
+// A member of a decode group (e->kv_group) only takes phase 1: encoder + prefill graph, then -- once the group's previous
+// decode chain has released the cache -- the graph of its K/V repacks.
 static int generate_run(gitmi_engine* e, const float* const* frames, int F, int B, int Q, int minP, int maxP, bool ragged,
                         const gitmi_search* sp, int64_t* tokens_out, float* logprob_out, int32_t* info_out,
                         int32_t* sent_out, hipStream_t s, int phase = 0) {
     const gitmi_config& c = e->cfg;
     const bool long_budget = sp->max_steps - minP > 32;
     const bool graph = e->use_graph && !e->profiling && !long_budget;
+    const bool group = phase == 3, member = e->kv_group != nullptr;
+    if (member && phase != 1) return fail("this context is a member of a decode group: gitmi_generate_encode + gitmi_group_decode");
+    const int F_in = c.num_frames > 0 ? std::min(F, c.num_frames) : F;
+    if (group) {        // host-side state a prefill on this context would have left behind
+        e->cur_B = B; e->cur_F = F_in; e->cur_Nimg = F_in * e->N;
+        e->have_feats = e->have_prefill = true;
+    }
     if (!graph) {
+        if (member) {
+            if (e->enc_after && e->enc_after->enc_done) HIPCK(hipStreamWaitEvent(s, e->enc_after->enc_done, 0));
+            RCK(generate_encode(e, frames, F, B, s));
+            if (e->enc_done && !e->enc_watchers.empty()) HIPCK(hipEventRecord(e->enc_done, s));
+            if (e->kv_group->group_dec_done) HIPCK(hipStreamWaitEvent(s, e->kv_group->group_dec_done, 0));
+            RCK(publish_kv(e, s));
+            HIPCK(hipEventRecord(e->kv_published, s));
+            return 0;
+        }
         if (phase == 1) return generate_encode(e, frames, F, B, s);
+        if (group) phase = 2;
         if (phase == 2)
             return generate_decode(e, Q, minP, maxP, ragged, sp, (long long*)tokens_out, logprob_out, info_out,
                                    sent_out ? sent_out : e->out_sent, s, long_budget && !e->profiling);
@@ -1361,7 +1432,7 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     }
     const size_t frame_bytes = (size_t)B * 3 * e->H * e->W * sizeof(float);
     const int F_eff = c.num_frames > 0 ? std::min(F, c.num_frames) : F;
-    if (phase != 2)
+    if (phase == 0 || phase == 1)
         for (int f = 0; f < F_eff; ++f)
             HIPCK(hipMemcpyAsync(e->frame_stage[f], frames[f], frame_bytes, hipMemcpyDeviceToDevice, x));
     gitmi_engine::GraphKey key{};
@@ -1373,18 +1444,19 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     // two graphs (encode + prefill | decode) whenever something has to happen between them: profiling events, the
     // enc_done record other contexts wait for, or the caller submits the halves itself
     const bool split = e->profile_mode == 2 || e->enc_after != nullptr || !e->enc_watchers.empty() || phase != 0;
-    if (phase == 2 && !(e->graph_valid && key == e->graph_key && e->graph_is_split && e->half_submitted))
+    if (phase == 2 && !(e->graph_valid && key == e->graph_key && e->graph_is_split && !e->graph_is_group && e->half_submitted))
         return fail("generate_decode: no matching gitmi_generate_encode was submitted on this context");
-    if (!e->graph_valid || !(key == e->graph_key) || split != e->graph_is_split) {
+    if (!e->graph_valid || !(key == e->graph_key) || split != e->graph_is_split || group != e->graph_is_group) {
         destroy_graph(e);
         std::vector<const float*> fp(F_eff);
         for (int f = 0; f < F_eff; ++f) fp[f] = e->frame_stage[f];
-        auto capture = [&](int part, hipGraph_t* gr_out) -> int {       // part 0: whole call, 1: encode + prefill, 2: decode
+        auto capture = [&](int part, hipGraph_t* gr_out) -> int {       // part 0: whole call, 1: encode + prefill, 2: decode, 4: K/V repacks of a group member
             HIPCK(hipStreamBeginCapture(x, hipStreamCaptureModeThreadLocal));
             int rc = 0;
             if (part == 0) rc = generate_body(e, fp.data(), F_eff, B, Q, minP, maxP, ragged, sp, e->out_tokens, e->out_lp,
                                               e->out_info, e->out_sent, x, false);
             else if (part == 1) rc = generate_encode(e, fp.data(), F_eff, B, x);
+            else if (part == 4) rc = publish_kv(e, x);
             else rc = generate_decode(e, Q, minP, maxP, ragged, sp, e->out_tokens, e->out_lp, e->out_info, e->out_sent, x, false);
             hipGraph_t gr = nullptr;
             hipError_t ce = hipStreamEndCapture(x, &gr);
@@ -1393,25 +1465,38 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
             *gr_out = gr;
             return 0;
         };
-        if (!split) {
+        if (group) {
+            RCK(capture(2, &e->graph_b));
+            HIPCK(hipGraphInstantiate(&e->graph_exec_b, e->graph_b, nullptr, nullptr, 0));
+        } else if (!split) {
             RCK(capture(0, &e->graph));
             HIPCK(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
         } else {
             RCK(capture(1, &e->graph));
             HIPCK(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
-            RCK(capture(2, &e->graph_b));
+            RCK(capture(member ? 4 : 2, &e->graph_b));
             HIPCK(hipGraphInstantiate(&e->graph_exec_b, e->graph_b, nullptr, nullptr, 0));
-
         }
         e->graph_key = key;
         e->graph_valid = true;
         e->graph_is_split = split;
+        e->graph_is_group = group;
     } else {
         // host-side mirror of the state generate_body leaves behind
         e->cur_B = B; e->cur_F = F_eff; e->cur_Nimg = F_eff * e->N;
         e->have_feats = e->have_prefill = true;
     }
-    if (!split) {
+    if (group) {
+        HIPCK(hipGraphLaunch(e->graph_exec_b, x));
+    } else if (member) {
+        if (e->enc_after && e->enc_after->enc_done) HIPCK(hipStreamWaitEvent(x, e->enc_after->enc_done, 0));
+        HIPCK(hipGraphLaunch(e->graph_exec, x));
+        if (e->enc_done && !e->enc_watchers.empty()) HIPCK(hipEventRecord(e->enc_done, x));
+        if (e->kv_group->group_dec_done) HIPCK(hipStreamWaitEvent(x, e->kv_group->group_dec_done, 0));
+        HIPCK(hipGraphLaunch(e->graph_exec_b, x));
+        HIPCK(hipEventRecord(e->kv_published, x));
+        e->half_submitted = false;
+    } else if (!split) {
         HIPCK(hipGraphLaunch(e->graph_exec, x));
     } else if (e->profile_mode != 2 || phase != 0) {
         if (phase != 2) {
@@ -1498,6 +1583,73 @@ extern "C" int gitmi_generate_decode(gitmi_engine* e, int F, int B, const int64_
     return generate_run(e, nullptr, F, B, B, P, P, false, sp, tokens_out, logprob_out, info_out, nullptr, s, 2);
 }
 
+// ---- decode groups: ONE decode chain for the requests of several contexts ----------------------------------------
+static void unlink_decode_group(gitmi_engine* m) {
+    if (!m->kv_group) return;
+    auto& v = m->kv_group->kv_members;
+    v.erase(std::remove(v.begin(), v.end(), m), v.end());
+    m->kv_group = nullptr;
+    m->kv_image_off = 0;
+    destroy_graph(m);                   // its graphs write into the group's cache
+}
+
+extern "C" int gitmi_set_decode_group(gitmi_engine* member, gitmi_engine* group, int image_offset) {
+    if (!member) return fail("set_decode_group: null member");
+    HIPCK(hipSetDevice(member->device));
+    HIPCK(hipDeviceSynchronize());
+    unlink_decode_group(member);
+    if (!group) return 0;
+    if (group == member) return fail("set_decode_group: a context cannot be its own group");
+    if (!member->finalized || !group->finalized) return fail("set_decode_group: weights not finalized");
+    if (group->kv_group) return fail("set_decode_group: the group context is itself a member of a group");
+    if (!member->kv_members.empty()) return fail("set_decode_group: the member context is a group");
+    const gitmi_engine* wm = member->parent ? member->parent : member;
+    const gitmi_engine* wg = group->parent ? group->parent : group;
+    if (wm != wg || member->device != group->device || member->f32 != group->f32)
+        return fail("set_decode_group: member and group must be contexts of the same engine (gitmi_clone / gitmi_clone_sized)");
+    const gitmi_config &a = member->cfg, &b = group->cfg;
+    if (a.max_frames != b.max_frames || member->Nmax != group->Nmax)
+        return fail("set_decode_group: member and group differ in frame / image-token capacity");
+    if (image_offset < 0 || image_offset + a.max_batch > b.max_batch)
+        return fail("set_decode_group: images [%d, %d) do not fit the group's max_batch=%d", image_offset,
+                    image_offset + a.max_batch, b.max_batch);
+    for (const gitmi_engine* o : group->kv_members)
+        if (image_offset < o->kv_image_off + o->cfg.max_batch && o->kv_image_off < image_offset + a.max_batch)
+            return fail("set_decode_group: images [%d, %d) overlap another member's", image_offset, image_offset + a.max_batch);
+    if (!member->kv_published) HIPCK(hipEventCreateWithFlags(&member->kv_published, hipEventDisableTiming));
+    if (!group->group_dec_done) HIPCK(hipEventCreateWithFlags(&group->group_dec_done, hipEventDisableTiming));
+    member->kv_group = group;
+    member->kv_image_off = image_offset;
+    group->kv_members.push_back(member);
+    return 0;
+}
+
+extern "C" int gitmi_group_decode(gitmi_engine* e, int F, int B, const int64_t* prefix, int P, const gitmi_search* sp,
+                                  int64_t* tokens_out, float* logprob_out, int32_t* info_out, void* stream) {
+    RCK(check_ready(e));
+    if (!tokens_out || !logprob_out || !info_out) return fail("group_decode: null argument");
+    if (e->kv_members.empty()) return fail("group_decode: no member contexts (gitmi_set_decode_group)");
+    RCK(check_generate_args(e, F, B, prefix, &P, sp));
+    const int F_in = e->cfg.num_frames > 0 ? std::min(F, e->cfg.num_frames) : F;
+    hipStream_t s = (hipStream_t)stream;
+    // images [0, B) must be covered by members that have published a request of the same geometry
+    std::vector<char> have((size_t)B, 0);
+    for (gitmi_engine* m : e->kv_members) {
+        if (m->kv_image_off >= B) continue;
+        if (m->cur_F != F_in || m->N != e->N || m->cur_B < 1)
+            return fail("group_decode: the member at image %d has no published request of this geometry", m->kv_image_off);
+        for (int i = m->kv_image_off; i < std::min(B, m->kv_image_off + m->cur_B); ++i) have[(size_t)i] = 1;
+        HIPCK(hipStreamWaitEvent(s, m->kv_published, 0));
+    }
+    for (int i = 0; i < B; ++i)
+        if (!have[(size_t)i]) return fail("group_decode: image %d of %d was not published by any member", i, B);
+    RCK(fill_uniform_sentences(e, B, (const long long*)prefix, P, s));
+    e->img_identity = true;
+    RCK(generate_run(e, nullptr, F, B, B, P, P, false, sp, tokens_out, logprob_out, info_out, nullptr, s, 3));
+    HIPCK(hipEventRecord(e->group_dec_done, s));
+    return 0;
+}
+
 // Q sentences with their own prefixes over B encoded images (batched VQA: the questions of one image share its K/V).
 extern "C" int gitmi_generate_prefixed(gitmi_engine* e, const float* const* frames, int F, int B, const int64_t* prefixes,
                                        int ld_prefix, const int32_t* prefix_len_host, const int32_t* image_of_host, int Q,
@@ -1574,6 +1726,20 @@ extern "C" int gitmi_set_encode_after(gitmi_engine* e, gitmi_engine* after) {
 extern "C" int gitmi_set_temporal_embedding(gitmi_engine* e, int on) {
     if (!e) return fail("null engine");
     if ((on != 0) != e->use_temb) { e->use_temb = on != 0; e->have_feats = e->have_prefill = false; }
+    return 0;
+}
+// Serving policy: other contexts keep the device busy beside this one.  Kernel shapes are then chosen for what they cost
+// the device as a whole rather than for their own duration: the encoder GEMMs take the 256-row tile even where it leaves
+// a partial round (the idle CUs are filled by the other contexts), the decode attention packs two (sentence, head) pairs
+// per workgroup.  Results are bit-identical either way.
+extern "C" int gitmi_set_shared_device(gitmi_engine* e, int on) {
+    if (!e) return fail("null engine");
+    if ((on != 0) != e->shared_device) {
+        HIPCK(hipSetDevice(e->device));
+        HIPCK(hipDeviceSynchronize());
+        e->shared_device = on != 0;
+        destroy_graph(e);
+    }
     return 0;
 }
 extern "C" int gitmi_set_graph(gitmi_engine* e, int on) {

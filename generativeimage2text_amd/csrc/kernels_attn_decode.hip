@@ -73,15 +73,21 @@ __device__ __forceinline__ void ld8bf(const bf16_t* p, float (&v)[8]) {
 // halves meet once in LDS.  KB >= beams (1, 2, 4 or 8); TI: text items per 8-lane group loaded up front.
 constexpr int ACS = 4;          // key steps per chunk and wave
 
-template <int KB, int TI = 3>
-__global__ __launch_bounds__(128) void attn_decode_mfma_kernel(AttnDecodeArgs a) {
-    __shared__ float part[1][2][KB][HD + 2];      // [half][beam]: o[64], m, l
+// PW: (sentence, head) pairs per workgroup.  1 spreads a launch over every CU (fastest on an idle device); 8 packs it onto
+// 96 CUs -- next to the image encoder of another context every CU that holds even one of these waves (120 registers) is
+// closed to a GEMM workgroup (8 waves x 232 registers, 128 KiB LDS) until the wave retires, so fewer, full CUs cost the
+// encoder less than all of them lightly loaded ("Round 3: what the mix costs").
+template <int KB, int TI = 3, int PW = 1>
+__global__ __launch_bounds__(128 * PW) void attn_decode_mfma_kernel(AttnDecodeArgs a) {
+    __shared__ float part[PW][2][KB][HD + 2];     // [pair][half][beam]: o[64], m, l
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int hp = 0, half = wave & 1;             // half of the head's keys
-    const int h = blockIdx.x, b = blockIdx.y, H = a.d / HD;
-    const bool head_on = true;
+    const int hp = wave >> 1, half = wave & 1;     // pair of the workgroup, half of the head's keys
+    const int H = a.d / HD;
+    const int pair = PW == 1 ? (int)(blockIdx.y * H + blockIdx.x) : (int)blockIdx.x * PW + hp;
+    const bool head_on = PW == 1 || pair < a.n_pairs;
+    const int h = head_on ? pair % H : 0, b = head_on ? pair / H : 0;
     const int k = a.beams;                       // k <= KB <= 8 < 16 MFMA rows
     const bf16_t* QKV = reinterpret_cast<const bf16_t*>(a.qkv);
     bf16_t* TK = reinterpret_cast<bf16_t*>(a.txt_k);
@@ -370,6 +376,21 @@ hipError_t launch_attn_decode_mfma(const AttnDecodeArgs& a, int B, int H, hipStr
     if (B <= 0) return hipSuccess;
     if (a.beams > 8 || a.N_pad % 32 || a.N_pad < a.N_img || a.N_img < 1) return hipErrorInvalidValue;
     const dim3 grid(H, B);
+    AttnDecodeArgs p = a;
+    p.n_pairs = B * H;
+    const int pw = a.pairs_per_wg;
+    if (pw > 1 && (a.beams <= 1 || (a.beams > 2 && a.beams <= 4))) {
+        if (a.beams <= 1) {
+            if (pw >= 8) hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 8>), dim3((p.n_pairs + 7) / 8), dim3(1024), 0, s, p);
+            else if (pw >= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 4>), dim3((p.n_pairs + 3) / 4), dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 2>), dim3((p.n_pairs + 1) / 2), dim3(256), 0, s, p);
+        } else {
+            if (pw >= 8) hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 8>), dim3((p.n_pairs + 7) / 8), dim3(1024), 0, s, p);
+            else if (pw >= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 4>), dim3((p.n_pairs + 3) / 4), dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 2>), dim3((p.n_pairs + 1) / 2), dim3(256), 0, s, p);
+        }
+        return hipGetLastError();
+    }
     if (a.beams <= 1) hipLaunchKernelGGL((attn_decode_mfma_kernel<1>), grid, dim3(128), 0, s, a);
     else if (a.beams <= 2) hipLaunchKernelGGL((attn_decode_mfma_kernel<2>), grid, dim3(128), 0, s, a);
     else if (a.beams <= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<4>), grid, dim3(128), 0, s, a);

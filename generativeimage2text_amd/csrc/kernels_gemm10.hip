@@ -391,7 +391,15 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = pack2o<TOut>(f[2 * e], f[2 * e + 1]);
                         }
-                        *reinterpret_cast<u32x4_t*>(C + (size_t)m * g.ldc + n) = v;
+                        // sc1: write-through WITHOUT keeping the line in this XCD's L2 (MI355X_MICROARCH.md, store flavours).  The
+                        // 58 - 78 MB a launch writes are never re-read by it; left in the L2 they evict the weight panels every
+                        // tile of the XCD re-reads.  Measured (profiles/r03_r_*): 57.6 -> 56.5 us per encoder launch, +0.6 %
+                        // captions/s; dbg 512 = plain stores (A/B)
+                        TOut* cp = C + (size_t)m * g.ldc + n;
+                        if (g.dbg & 512)
+                            *reinterpret_cast<u32x4_t*>(cp) = v;
+                        else
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(cp), "v"(v) : "memory");
                     }
                 }
             }
@@ -467,7 +475,11 @@ int gemm_p8_cost(const GemmArgs& g, int mh) { return p8_plan(g, mh, nullptr, nul
 hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s) {
     // the 192-row tile when it fills a partial round better (N = 768 at M = 12608: 198 workgroups instead of 150);
     // dbg 64 / 128 force the 192- / 256-row tile (tests, A/B)
-    int mh = gemm_p8_cost(g, 96) < gemm_p8_cost(g, 128) ? 96 : 128;
+    // g.shared (several contexts keep the device busy: gitmi_set_shared_device): always the 256-row tile -- the CUs a
+    // partial round leaves idle are filled by the other contexts' kernels, so the tile with the better FLOP/byte wins
+    // (measured in the mixed schedule, profiles/r03_m_*: 10.05k -> 10.27k captions/s, while the same choice is 3 % slower
+    // for a context that has the device to itself)
+    int mh = g.shared ? 128 : gemm_p8_cost(g, 96) < gemm_p8_cost(g, 128) ? 96 : 128;
     if (g.dbg & 64) { mh = 96; g.dbg &= ~64; }
     if (g.dbg & 128) { mh = 128; g.dbg &= ~128; }
     g.tiles_n = g.N / BN;

@@ -14,6 +14,7 @@ struct GemmArgs {
     int ng;     // XCD tile partition: N split into ng groups, M into 8/ng (kernels_gemm3.hip)
     int dbg;    // timing experiments only (gemm_ring_kernel): 1 no C stores, 2 no epilogue, 4 no MFMA, 8 no loads in loop
     int out_f16; // C and `res` are f16_t rows (residual stream of the bf16 engine mode); bf16 inputs, p8 + generic kernel only
+    int shared;  // other contexts run beside this launch (serving schedule): tile choice by FLOP/byte, not by round fill
 };
 hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t s);
 // second-generation bf16 kernel (direct-to-LDS staging, swizzled LDS, LDS-staged epilogue)
@@ -100,6 +101,8 @@ struct AttnDecodeArgs {
     int out_frag;        // write `out` in the fragment-major operand layout of the decode chain (bf16)
     float scale;
     int dbg;             // timing experiments: 1 skip image K/V loads, 2 skip scores, 4 skip PV
+    int pairs_per_wg;    // MFMA kernel: (sentence, head) pairs per workgroup (1, 2, 4, 8); > 1 packs the launch onto fewer CUs
+    int n_pairs;         // set by the launcher
 };
 hipError_t launch_kv_repack(const void* qkv, void* kh, void* vh, int B, int N, int H, int d, bool is_f32, hipStream_t s);
 size_t attn_decode_lds_bytes(int beams, int N_img, int pos);

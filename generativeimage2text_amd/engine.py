@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after", "gitmi_op_sample_rows",
     "gitmi_generate_encode", "gitmi_generate_decode", "gitmi_search_done_count",
     "gitmi_debug_import_stage", "gitmi_debug_head_from", "gitmi_set_trie", "gitmi_operand_dtype",
+    "gitmi_clone_sized", "gitmi_set_decode_group", "gitmi_group_decode", "gitmi_set_shared_device",
 ]
 
 
@@ -104,6 +105,7 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     lib.gitmi_set_graph.argtypes = [vp, i32]
     lib.gitmi_set_temporal_embedding.argtypes = [vp, i32]
     lib.gitmi_set_encode_after.argtypes = [vp, vp]
+    lib.gitmi_set_shared_device.argtypes = [vp, i32]
     lib.gitmi_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_attention.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
@@ -114,6 +116,9 @@ def load_library(operands: str = "bf16") -> C.CDLL:
                                             i32, C.POINTER(GitmiSearch), vp, vp, vp, vp, vp]
     lib.gitmi_debug_set_gemm_impl.argtypes = [i32]
     lib.gitmi_clone.argtypes = [vp, C.POINTER(vp)]
+    lib.gitmi_clone_sized.argtypes = [vp, i32, C.POINTER(vp)]
+    lib.gitmi_set_decode_group.argtypes = [vp, vp, i32]
+    lib.gitmi_group_decode.argtypes = [vp, i32, i32, vp, i32, C.POINTER(GitmiSearch), vp, vp, vp, vp]
     lib.gitmi_preprocess_image.argtypes = [vp, i32, i32, i32, vp, C.c_size_t, vp, vp]
     lib.gitmi_preprocess_image_to.argtypes = [vp, i32, i32, i32, i32, vp, C.c_size_t, vp, vp]
     lib.gitmi_set_image_shape.argtypes = [vp, i32, i32, vp]
@@ -123,7 +128,7 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     for name in EXPORTED_SYMBOLS:
         if name not in ("gitmi_last_error", "gitmi_destroy"):
             getattr(lib, name).restype = C.c_int
-    if lib.gitmi_abi_version() != 5:
+    if lib.gitmi_abi_version() != 6:
         raise GitmiError("libgitmi.so ABI version mismatch")
     lib.gitmi_operand_dtype.restype = C.c_int
     if lib.gitmi_operand_dtype() != {"bf16": DTYPE_BF16, "f16": DTYPE_F16}[operands]:
@@ -190,15 +195,19 @@ class Engine:
         self._cur_F = 0
 
     # -- lifecycle ---------------------------------------------------------------------------
-    def clone(self) -> "Engine":
+    def clone(self, max_batch: Optional[int] = None) -> "Engine":
         """A second context sharing this engine's packed weights (own workspaces / KV caches / graph),
-        for keeping several batches in flight on different streams.  Keep `self` alive while it is used."""
+        for keeping several batches in flight on different streams.  Keep `self` alive while it is used.
+        max_batch: capacity of the clone when it differs (a decode-group context holds the rows of all its members)."""
         other = object.__new__(Engine)
-        other.lib, other.device, other.cfg, other.precision, other.c = self.lib, self.device, self.cfg, self.precision, self.c
+        other.lib, other.device, other.cfg, other.precision = self.lib, self.device, self.cfg, self.precision
+        other.c = GitmiConfig.from_buffer_copy(self.c)
+        if max_batch is not None:
+            other.c.max_batch = int(max_batch)
         other.n_tok = (self.c.image_size // self.c.patch) ** 2 + 1
         other._hw = (int(self.c.image_size), int(self.c.image_size))
         other._h = C.c_void_p()
-        _ck(self.lib.gitmi_clone(self._h, C.byref(other._h)))
+        _ck(self.lib.gitmi_clone_sized(self._h, int(other.c.max_batch), C.byref(other._h)))
         other._finalized, other._cur_B, other._cur_F = True, 0, 0
         other._parent = self
         return other
@@ -331,6 +340,32 @@ class Engine:
         _ck(self.lib.gitmi_generate_encode(self._h, arr, len(keep), B, _ptr(pfx), P, C.byref(search), _stream()))
         self._cur_B, self._half = B, (len(keep), B, pfx, P)
 
+    def set_decode_group(self, group: Optional["Engine"], image_offset: int = 0) -> None:
+        """Make this context a MEMBER of `group` (a clone(max_batch=...) context): generate_encode() writes the image K/V of
+        its request into the group's cache at `image_offset`, group.group_decode() searches over all members' images in
+        ONE decode chain.  group=None detaches."""
+        _ck(self.lib.gitmi_set_decode_group(self._h, group._h if group is not None else None, int(image_offset)))
+        self._group = group
+
+    def group_decode(self, n_frames: int, n_images: int, search: GitmiSearch, prefix: Optional[torch.Tensor] = None,
+                     sync: bool = True):
+        """On a group context: the search over the first n_images images its members published (their generate_encode
+        calls come first in host order).  -> (tokens [n_images, max_steps], logprobs [n_images], info) -- row i belongs to
+        the member whose image_offset covers i."""
+        dev = f"cuda:{self.device}"
+        P, pfx = 1, None
+        if prefix is not None:
+            pfx = prefix.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
+            P = int(pfx.numel())
+        tokens = torch.empty(n_images, search.max_steps, device=dev, dtype=torch.int64)
+        logprobs = torch.empty(n_images, device=dev, dtype=torch.float32)
+        info = torch.empty(4, device=dev, dtype=torch.int32)
+        _ck(self.lib.gitmi_group_decode(self._h, int(n_frames), int(n_images), _ptr(pfx), P, C.byref(search),
+                                        tokens.data_ptr(), logprobs.data_ptr(), info.data_ptr(), _stream()))
+        if sync:
+            torch.cuda.synchronize(self.device)
+        return tokens, logprobs, info
+
     def generate_decode(self, search: GitmiSearch, sync: bool = True):
         """Second half: the search over the text positions.  -> (tokens, logprobs, info) exactly as generate()."""
         F, B, pfx, P = self._half
@@ -445,6 +480,11 @@ class Engine:
         p = GitmiProfile()
         _ck(self.lib.gitmi_profile_read(self._h, C.byref(p)))
         return p.as_dict()
+
+    def set_shared_device(self, on: bool = True) -> None:
+        """Serving policy: other contexts run beside this one (kernel shapes by whole-device cost; bit-identical results).
+        Clones made afterwards inherit it."""
+        _ck(self.lib.gitmi_set_shared_device(self._h, 1 if on else 0))
 
     def set_encode_after(self, other: Optional["Engine"]) -> None:
         """Serving schedule: this context's image encoder starts only after `other`'s (most recently submitted) has

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GITMI_ABI_VERSION 5
+#define GITMI_ABI_VERSION 6
 
 /* compute precision of GEMM/attention operands (accumulation, LayerNorm statistics,
  * softmax, residual stream and logits are fp32 in both modes) */
@@ -149,6 +149,13 @@ int  gitmi_clone(gitmi_engine* src, gitmi_engine** out);
  * context waits for it either).  Destroying either context of a link removes the link. */
 int  gitmi_set_encode_after(gitmi_engine* e, gitmi_engine* after);
 
+/* serving policy (ABI 6): tell a context that other contexts keep the device busy beside it.  Kernel shapes are then chosen
+ * for what a launch costs the device as a whole, not for its own duration: the image-encoder GEMMs always take the
+ * 256x256 tile (a partial round's idle CUs are filled by the other contexts; measured +2.2 % captions/s in the mixed
+ * schedule, -3 % for a context alone), the decode attention packs two (sentence, head) pairs per workgroup (+0.7 %).
+ * Results are bit-identical either way.  Clones inherit the setting of their source at clone time. */
+int  gitmi_set_shared_device(gitmi_engine* e, int on);
+
 /* ---- input resolution of the following encode/generate calls (default: image_size x image_size).
  * Replaces the run-time branch of VisualTransformer.forward for inputs that are not the native
  * resolution (CLIP/model.py:243-251): the token grid becomes (H / patch) x (W / patch) -- the stride-patch
@@ -206,6 +213,25 @@ int  gitmi_generate_encode(gitmi_engine* e, const float* const* frames, int F, i
                            const int64_t* prefix, int P, const gitmi_search* search, void* stream);
 int  gitmi_generate_decode(gitmi_engine* e, int F, int B, const int64_t* prefix, int P, const gitmi_search* search,
                            int64_t* tokens_out, float* logprob_out, int32_t* info_out, void* stream);
+
+/* ---- decode groups (ABI 6): ONE decode chain for the requests of several contexts.
+ * The reference decodes every batch on its own (decoder.py:313-417); on the device the decode chain of a 64-image batch
+ * is 19 x 32 dependent, latency-bound launches that read every decoder weight once per step, whatever the row count.
+ * A GROUP context (gitmi_clone_sized with max_batch = the sum of its members') owns the image K/V cache; MEMBER contexts
+ * (gitmi_set_decode_group) run image encoder + prefill of their own requests as before -- each on its stream, as soon as
+ * its request arrives -- and write their K/V into the group's cache at `image_offset`; gitmi_group_decode then searches
+ * over the first B images of the cache in one chain: rows = the members' rows, weights streamed once per step, a quarter
+ * / half of the launches per caption.  Captions do not depend on their batch neighbours, so every request gets exactly
+ * what its own gitmi_generate call returns (same kernels, same per-row arithmetic).
+ *   ordering is the engine's: a member's K/V repack (a small graph of its own behind its prefill) waits for the group's
+ *   previous gitmi_group_decode, and gitmi_group_decode waits for the members covering images [0, B).  The caller only
+ *   keeps HOST order: the members' gitmi_generate_encode calls of a round, then the group's decode, then the next round.
+ *   A member accepts gitmi_generate_encode only (search / prefix arguments as for the group's decode).
+ * gitmi_set_decode_group(member, NULL, 0) detaches; destroying either context removes the link. */
+int  gitmi_clone_sized(gitmi_engine* src, int max_batch, gitmi_engine** out);
+int  gitmi_set_decode_group(gitmi_engine* member, gitmi_engine* group, int image_offset);
+int  gitmi_group_decode(gitmi_engine* group, int F, int B, const int64_t* prefix, int P, const gitmi_search* search,
+                        int64_t* tokens_out, float* logprob_out, int32_t* info_out, void* stream);
 
 /* ---- batched VQA: Q sentences with their OWN prefixes over B images.  The reference answers one question per
  * model call (decoder.py:984-989 asserts a single prefix; inference.py:172-199 loops); here the questions of one

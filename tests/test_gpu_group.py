@@ -1,0 +1,174 @@
+"""GPU: decode groups (gitmi_clone_sized / gitmi_set_decode_group / gitmi_group_decode, include/gitmi.h ABI 6).
+
+Several contexts encode + prefill their OWN requests and share ONE decode chain.  Captions do not depend on their batch
+neighbours (the reference decodes every batch on its own, decoder.py:313-417), so the bar is: every request gets bit for
+bit what its own gitmi_generate call returns -- in f32 mode and in the 16-bit modes alike (same kernels, same per-row
+arithmetic) -- over several rounds of hipGraph replays (the cross-context ordering is the engine's, by events)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(precision, sizes, beams=4, T=16, frames=1, cfg_name="TINY"):
+    from oracle import git_oracle as O
+    from generativeimage2text_amd.engine import Engine
+    cfg = O.CONFIGS[cfg_name]
+    w = O.make_weights(cfg, seed=81, tie_output=False, successor=2.0, eos_bias=1.0)
+    cap = max(sizes)
+    eng = Engine(cfg, precision=precision, max_batch=cap, max_beams=beams, max_frames=frames, max_text_len=T)
+    eng.load_state_dict(w)
+    members = [eng.clone() for _ in sizes]
+    group = eng.clone(max_batch=cap * len(sizes))
+    for i, m in enumerate(members):
+        m.set_decode_group(group, i * cap)
+    return O, cfg, eng, members, group, cap
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
+def test_group_decode_equals_each_requests_own_call(precision):
+    """Two / three members, greedy and beam-4 with a shared prefix, graph replays and eager launches, three rounds with
+    different images per round: rows of the group's decode == the rows of each request's own generate() call."""
+    from generativeimage2text_amd.engine import Engine
+    O, cfg, eng, members, group, cap = _setup(precision, [3, 3, 3])
+    streams = [torch.cuda.Stream() for _ in members] + [torch.cuda.Stream()]
+    prefix = torch.tensor([cfg.sos, 7, 9])
+    for graph in (True, False):
+        for c in members + [group, eng]:
+            c.set_graph(graph)
+        for search, pfx in ((Engine.make_search("greedy", 16, 1, 1), None),
+                            (Engine.make_search("beam", 16, 4, 2, 0.6), prefix)):
+            for rnd in range(3):
+                n_req = 3 if rnd != 1 else 2                 # round 1: only two of the three members have a request
+                reqs = [[f.cuda() for f in O.make_images(cfg, 3, 1, seed=100 * rnd + i)] for i in range(n_req)]
+                want = [eng.generate(r, search, prefix=pfx) for r in reqs]
+                for i, r in enumerate(reqs):
+                    with torch.cuda.stream(streams[i]):
+                        members[i].generate_encode(r, search, prefix=pfx)
+                with torch.cuda.stream(streams[-1]):
+                    tok, lp, info = group.group_decode(1, cap * n_req, search, prefix=pfx, sync=True)
+                for i, (t1, l1, i1) in enumerate(want):
+                    assert torch.equal(tok[i * cap:(i + 1) * cap], t1), (precision, graph, rnd, i)
+                    assert torch.equal(lp[i * cap:(i + 1) * cap], l1)
+                # info = (returned length, early flag, steps run, -): a property of the whole chain; with the same search
+                # budget the per-request values can only differ when a request ends early on its own
+                assert info.tolist()[2] >= max(w[2].tolist()[2] for w in want)
+    for c in members + [group, eng]:
+        c.close()
+
+
+def test_last_member_may_hold_fewer_images():
+    """The last request of a group may be smaller than its slot (rows stay contiguous); a smaller request in the MIDDLE
+    leaves a hole and is refused."""
+    from generativeimage2text_amd.engine import Engine, GitmiError
+    O, cfg, eng, members, group, cap = _setup("f32", [3, 3], beams=1)
+    search = Engine.make_search("greedy", 16, 1, 1)
+    a = [f.cuda() for f in O.make_images(cfg, 3, 1, seed=1)]
+    b = [f.cuda() for f in O.make_images(cfg, 2, 1, seed=2)]
+    wa, wb = eng.generate(a, search), eng.generate(b, search)
+    members[0].generate_encode(a, search)
+    members[1].generate_encode(b, search)
+    tok, lp, _ = group.group_decode(1, 5, search)
+    assert torch.equal(tok[:3], wa[0]) and torch.equal(tok[3:], wb[0]) and torch.equal(lp[3:], wb[1])
+    members[0].generate_encode(b, search)                    # 2 images in a 3-image slot, then member 1's images at 3..
+    members[1].generate_encode(a, search)
+    with pytest.raises(GitmiError, match="not published"):
+        group.group_decode(1, 6, search)
+    for c in members + [group, eng]:
+        c.close()
+
+
+def test_group_membership_rules_and_detach():
+    from generativeimage2text_amd.engine import Engine, GitmiError
+    O, cfg, eng, members, group, cap = _setup("f32", [2, 2], beams=1)
+    search = Engine.make_search("greedy", 16, 1, 1)
+    frames = [f.cuda() for f in O.make_images(cfg, 2, 1, seed=3)]
+    want = eng.generate(frames, search)
+    # a member only encodes; the whole call and the decode half belong to the group
+    with pytest.raises(GitmiError, match="member of a decode group"):
+        members[0].generate(frames, search)
+    # nothing published yet: the group refuses to decode
+    with pytest.raises(GitmiError, match="no published request|not published"):
+        group.group_decode(1, 2, search)
+    # a context without members is not a group
+    with pytest.raises(GitmiError, match="no member contexts"):
+        eng.group_decode(1, 2, search)
+    # slots must fit and must not overlap
+    extra = eng.clone()
+    with pytest.raises(GitmiError, match="do not fit"):
+        extra.set_decode_group(group, 3)
+    with pytest.raises(GitmiError, match="overlap"):
+        extra.set_decode_group(group, 1)
+    with pytest.raises(GitmiError, match="own group"):
+        group.set_decode_group(group, 0)
+    with pytest.raises(GitmiError, match="itself a member"):
+        extra.set_decode_group(members[0], 0)
+    # detaching gives the context its own cache (and whole calls) back
+    members[0].set_decode_group(None)
+    got = members[0].generate(frames, search)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # destroying the group detaches the remaining member
+    group.close()
+    got = members[1].generate(frames, search)
+    assert torch.equal(got[0], want[0])
+    for c in members + [extra, eng]:
+        c.close()
+
+
+def test_group_decode_on_the_benchmark_geometry_bf16():
+    """GIT_BASE, 2 x 16 images, greedy: the 32-row chain (two 16-row blocks padded to 64) returns each request's own ids;
+    the members' encoders run on two streams at once."""
+    from generativeimage2text_amd.configs import config_for_model
+    from generativeimage2text_amd.engine import Engine
+    from generativeimage2text_amd.synthetic import random_frames, random_state_dict
+    cfg = config_for_model("GIT_BASE")
+    eng = Engine(cfg, precision="bf16", max_batch=16, max_beams=1, max_frames=1, max_text_len=20)
+    eng.load_state_dict(random_state_dict(cfg, seed=1234))
+    members = [eng.clone(), eng.clone()]
+    group = eng.clone(max_batch=32)
+    for i, m in enumerate(members):
+        m.set_decode_group(group, 16 * i)
+    search = Engine.make_search("greedy", 20, 1, 1)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    for rnd in range(3):
+        reqs = [random_frames(cfg, 16, 1, seed=10 * rnd + i) for i in range(2)]
+        want = [eng.generate(r, search) for r in reqs]
+        for i, r in enumerate(reqs):
+            with torch.cuda.stream(streams[i]):
+                members[i].generate_encode(r, search)
+        with torch.cuda.stream(streams[2]):
+            tok, lp, _ = group.group_decode(1, 32, search)
+        for i in range(2):
+            assert torch.equal(tok[16 * i:16 * (i + 1)], want[i][0]), (rnd, i)
+            assert torch.equal(lp[16 * i:16 * (i + 1)], want[i][1])
+    for c in members + [group, eng]:
+        c.close()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f32"])
+def test_shared_device_policy_is_bitwise_neutral(precision):
+    """gitmi_set_shared_device changes kernel SHAPES (256-row GEMM tiles everywhere, two (sentence, head) pairs per
+    attention workgroup), never results: features, ids and log-probs of the benchmark geometry are bit-identical, for
+    a context and for a clone that inherits the setting."""
+    from generativeimage2text_amd.configs import config_for_model
+    from generativeimage2text_amd.engine import Engine
+    from generativeimage2text_amd.synthetic import random_frames, random_state_dict
+    cfg = config_for_model("GIT_BASE")
+    B = 64 if precision == "bf16" else 8
+    eng = Engine(cfg, precision=precision, max_batch=B, max_beams=4, max_frames=1, max_text_len=20)
+    eng.load_state_dict(random_state_dict(cfg, seed=1234))
+    frames = random_frames(cfg, B, 1, seed=0)
+    out = {}
+    for search in (Engine.make_search("greedy", 20, 1, 1), Engine.make_search("beam", 20, 4, 2, 0.6)):
+        for on in (False, True):
+            eng.set_shared_device(on)
+            feats = eng.encode(frames, return_features=True)
+            tok, lp, _ = eng.generate(frames, search)
+            out[on] = (feats.clone(), tok.clone(), lp.clone())
+        clone = eng.clone()                                  # inherits "on"
+        tok_c, lp_c, _ = clone.generate(frames, search)
+        clone.close()
+        assert torch.equal(out[False][0], out[True][0])
+        assert torch.equal(out[False][1], out[True][1]) and torch.equal(out[False][2], out[True][2])
+        assert torch.equal(tok_c, out[True][1]) and torch.equal(lp_c, out[True][2])
+    eng.close()

@@ -106,10 +106,24 @@ def _run_bench_with_fakes(monkeypatch, capsys, argv):
             self.c = types.SimpleNamespace(max_batch=max_batch, vocab=cfg.vocab)
             self.half = None
 
-        def clone(self):
+        def clone(self, max_batch=None):
             other = FakeEngine.__new__(FakeEngine)
-            other.c, other.half = self.c, None
+            other.c, other.half = types.SimpleNamespace(max_batch=max_batch or self.c.max_batch, vocab=self.c.vocab), None
+            other.group, other.members, other.shared = None, [], getattr(self, "shared", False)
             return other
+
+        def set_shared_device(self, on=True):
+            self.shared = on
+
+        def set_decode_group(self, group, image_offset=0):
+            self.group, self.offset = group, image_offset
+            group.members.append(self)
+
+        def group_decode(self, n_frames, n_images, search, prefix=None, sync=True):
+            sizes = [m.half for m in self.members]
+            assert all(b is not None for b in sizes) and sum(sizes) == n_images <= self.c.max_batch
+            log.append(("group_decode", n_images, self.shared))       # (the cache stays valid: a group may decode it again)
+            return self._out(n_images, search)
 
         def load_state_dict(self, sd): pass
         def set_graph(self, on): pass
@@ -130,7 +144,7 @@ def _run_bench_with_fakes(monkeypatch, capsys, argv):
             return self._out(int(frames[0].shape[0]), search)
 
         def generate_encode(self, frames, search, prefix=None):
-            assert self.half is None
+            assert self.half is None or getattr(self, "group", None) is not None
             self.half = int(frames[0].shape[0])
             log.append(("encode", self.half))
 
@@ -185,6 +199,16 @@ def test_bench_control_flow_all_schedules(monkeypatch, capsys):
     assert "2 requests of 64 images coalesced" in d["config"]["schedule"] and d["warmup"] == 4
     passes = [e for e in log if e == ("generate", 128)]
     assert len(passes) == 4 + 2 + 4                     # priming (one pass per context), warm-up 4 steps, 8 timed steps
+    # decode groups: every request encoded by its own member context, one decode per pair of requests; the serving
+    # policy (gitmi_set_shared_device) is on for every context of a multi-context run
+    d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--warmup", "3", "--decode-group", "2"])
+    assert "2 requests per decode chain (128 rows)" in d["config"]["schedule"] and d["warmup"] == 4 and d["config"]["shared_device_policy"]
+    assert d["roofline_decode"]["rows_per_step"] == 128
+    ev = [e for e in log if e[0] in ("encode", "group_decode")]
+    assert ev[:3] == [("encode", 64), ("encode", 64), ("group_decode", 128, True)]
+    assert len([e for e in ev if e[0] == "encode"]) == 4 + 4 + 4 + 8 + 2      # two priming rounds, warm-up, timed, the probe's publish
     import pytest
     with pytest.raises(SystemExit):
         _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "7", "--coalesce", "2"])
+    with pytest.raises(SystemExit):
+        _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--decode-group", "3"])
