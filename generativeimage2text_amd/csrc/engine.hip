@@ -141,6 +141,7 @@ struct gitmi_engine {
     int attn_dbg = 0, dgemm_dbg = 0;    // timing experiments (GITMI_ATTN_DBG, GITMI_DGEMM_DBG)
     int attn_pw = 0;                    // (sentence, head) pairs per workgroup of the decode attention (GITMI_ATTN_PW; 0 = by policy)
     bool shared_device = false;         // gitmi_set_shared_device: other contexts run beside this one
+    int dgemm_rows = 0;                 // rows per workgroup of the N = 768 chain GEMMs (GITMI_DGEMM_ROWS: 16 / 32 / 64; 0 = by policy)
     int decode_skip = 0;                // timing experiment (GITMI_DECODE_SKIP): launches of the decode chain left out --
                                         // 1 attention, 2 QKV / FFN1 GEMMs, 4 out-proj / FFN2 GEMMs, 8 vocabulary head (ids are garbage)
     bool use_temb = true;               // add img_temperal_embedding[i] to frame i (the reference does so only for a LIST of frames)
@@ -331,6 +332,7 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     if (const char* env = getenv("GITMI_ATTN_DBG")) e->attn_dbg = atoi(env);
     if (const char* env = getenv("GITMI_ATTN_PW")) e->attn_pw = atoi(env);
     if (const char* env = getenv("GITMI_DECODE_SKIP")) e->decode_skip = atoi(env);
+    if (const char* env = getenv("GITMI_DGEMM_ROWS")) e->dgemm_rows = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_DBG")) e->dgemm_dbg = atoi(env);
     if (const char* env = getenv("GITMI_SKINNY")) e->skinny = atoi(env) != 0;
     e->stream_f16 = !e->f32;
@@ -785,7 +787,7 @@ static int clone_impl(gitmi_engine* src, int max_batch, gitmi_engine** out) {
     e->Nmax = src->Nmax; e->max_pixels = src->max_pixels;
     e->use_graph = src->use_graph; e->skinny = src->skinny; e->use_temb = src->use_temb;
     e->attn_dbg = src->attn_dbg; e->dgemm_dbg = src->dgemm_dbg; e->attn_pw = src->attn_pw; e->decode_skip = src->decode_skip;
-    e->shared_device = src->shared_device;
+    e->shared_device = src->shared_device; e->dgemm_rows = src->dgemm_rows;
     e->parent = src->parent ? src->parent : src;
     e->conv_w = src->conv_w; e->cls = src->cls; e->pos = src->pos; e->pos_cur = src->pos;
     e->lnpre_g = src->lnpre_g; e->lnpre_b = src->lnpre_b; e->lnpost_g = src->lnpost_g; e->lnpost_b = src->lnpost_b;
@@ -961,6 +963,11 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
 static int dgemm(gitmi_engine* e, hipStream_t s, const DGemmArgs& g_in) {
     DGemmArgs g = g_in;
     g.dbg = e->dgemm_dbg;
+    // N = 768 GEMMs of the chain: 64 rows per workgroup (one pass over the weight strip, a quarter of the workgroups) for
+    // beam batches -- faster even alone (R = 256: 0.466 -> 0.461 ms per step) -- and whenever other contexts share the
+    // device: the launch is 2.8 us longer on its own but closes far fewer CUs to the encoder's GEMM workgroups
+    // (profiles/r03_t_bench_lines.txt: greedy 10.34k -> 10.49k, beam-4 6.70k -> 7.00k captions/s in the mixed schedule)
+    g.rows_per_wg = e->dgemm_rows > 0 ? e->dgemm_rows : (e->shared_device || g.M > 64) ? 64 : 16;
     SpanGuard sp(e, s, TAG_GEMM_OTHER, 2.0 * (double)g.M * (double)g.N * (double)g.K);
     HIPCK(launch_dgemm(g, s));
     return 0;

@@ -73,10 +73,10 @@ __device__ __forceinline__ void ld8bf(const bf16_t* p, float (&v)[8]) {
 // halves meet once in LDS.  KB >= beams (1, 2, 4 or 8); TI: text items per 8-lane group loaded up front.
 constexpr int ACS = 4;          // key steps per chunk and wave
 
-// PW: (sentence, head) pairs per workgroup.  1 spreads a launch over every CU (fastest on an idle device); 8 packs it onto
-// 96 CUs -- next to the image encoder of another context every CU that holds even one of these waves (120 registers) is
-// closed to a GEMM workgroup (8 waves x 232 registers, 128 KiB LDS) until the wave retires, so fewer, full CUs cost the
-// encoder less than all of them lightly loaded ("Round 3: what the mix costs").
+// PW: (sentence, head) pairs per workgroup (1, 2 or 4; a wave needs 214 registers, so 8 waves fill a CU).  1 spreads a
+// launch over every CU (fastest on an idle device); next to the image encoder of another context every CU that holds even
+// one of these waves is closed to a GEMM workgroup (8 waves x 232 registers, 128 KiB LDS) until the wave retires: 2 pairs
+// per workgroup measured +0.7 % captions/s in the mixed schedule, 4 no further gain (profiles/r03_p_bench_lines.txt).
 template <int KB, int TI = 3, int PW = 1>
 __global__ __launch_bounds__(128 * PW) void attn_decode_mfma_kernel(AttnDecodeArgs a) {
     __shared__ float part[PW][2][KB][HD + 2];     // [pair][half][beam]: o[64], m, l
@@ -381,12 +381,10 @@ hipError_t launch_attn_decode_mfma(const AttnDecodeArgs& a, int B, int H, hipStr
     const int pw = a.pairs_per_wg;
     if (pw > 1 && (a.beams <= 1 || (a.beams > 2 && a.beams <= 4))) {
         if (a.beams <= 1) {
-            if (pw >= 8) hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 8>), dim3((p.n_pairs + 7) / 8), dim3(1024), 0, s, p);
-            else if (pw >= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 4>), dim3((p.n_pairs + 3) / 4), dim3(512), 0, s, p);
+            if (pw >= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 4>), dim3((p.n_pairs + 3) / 4), dim3(512), 0, s, p);
             else hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 2>), dim3((p.n_pairs + 1) / 2), dim3(256), 0, s, p);
         } else {
-            if (pw >= 8) hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 8>), dim3((p.n_pairs + 7) / 8), dim3(1024), 0, s, p);
-            else if (pw >= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 4>), dim3((p.n_pairs + 3) / 4), dim3(512), 0, s, p);
+            if (pw >= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 4>), dim3((p.n_pairs + 3) / 4), dim3(512), 0, s, p);
             else hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 2>), dim3((p.n_pairs + 1) / 2), dim3(256), 0, s, p);
         }
         return hipGetLastError();

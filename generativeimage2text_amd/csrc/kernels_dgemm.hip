@@ -439,8 +439,17 @@ static hipError_t launch_dgemm_t(const DGemmArgs& g, hipStream_t s) {
     const bool wide = g.N >= 1536;
     const int big_k = g.K >= 2048;
     if (EPI == DEPI_RES || !wide) {
-        dim3 grid((g.N + 15) / 16, (g.M + 15) / 16);
-        if (big_k) hipLaunchKernelGGL((dgemm_kernel<1, 8, EPI>), grid, dim3(512), 0, s, g);
+        // g.rows_per_wg: 16 (default: 48 strips x R/16 workgroups, each re-reading its weight strip from the L2) / 32 / 64
+        // (one pass over the strip for 64 rows: a quarter of the workgroups and 40 % less L2 traffic, a longer launch)
+        const int mt = g.rows_per_wg >= 64 && g.M > 32 ? 4 : g.rows_per_wg >= 32 && g.M > 16 ? 2 : 1;
+        dim3 grid((g.N + 15) / 16, (g.M + 16 * mt - 1) / (16 * mt));
+        if (mt == 4) {
+            if (big_k) hipLaunchKernelGGL((dgemm_kernel<4, 8, EPI>), grid, dim3(512), 0, s, g);
+            else hipLaunchKernelGGL((dgemm_kernel<4, 4, EPI>), grid, dim3(256), 0, s, g);
+        } else if (mt == 2) {
+            if (big_k) hipLaunchKernelGGL((dgemm_kernel<2, 8, EPI>), grid, dim3(512), 0, s, g);
+            else hipLaunchKernelGGL((dgemm_kernel<2, 4, EPI>), grid, dim3(256), 0, s, g);
+        } else if (big_k) hipLaunchKernelGGL((dgemm_kernel<1, 8, EPI>), grid, dim3(512), 0, s, g);
         else hipLaunchKernelGGL((dgemm_kernel<1, 4, EPI>), grid, dim3(256), 0, s, g);
     } else if (g.M <= 16) {
         hipLaunchKernelGGL((dgemm_kernel<1, 4, EPI>), dim3((g.N + 15) / 16, 1), dim3(256), 0, s, g);

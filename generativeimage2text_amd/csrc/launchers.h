@@ -42,6 +42,7 @@ struct DGemmArgs {
     float* x_out; unsigned short* xb_out; float2* stats_out;
     int M, N, K, lda, ldc, act;
     int dbg;                    // timing experiments only: 1 no activation loads, 2 no weight loads, 4 no MFMA, 8 no epilogue loads
+    int rows_per_wg;            // N = 768 form: rows per workgroup (0 / 16 default, 32, 64)
 };
 hipError_t launch_dgemm(const DGemmArgs& g, hipStream_t s);
 
