@@ -140,6 +140,7 @@ struct gitmi_engine {
     gitmi_search sample{};              // sampling parameters of the current search (do_sample, top_k, top_p, temperature, seed)
     int attn_dbg = 0, dgemm_dbg = 0;    // timing experiments (GITMI_ATTN_DBG, GITMI_DGEMM_DBG)
     int attn_pw = 0;                    // (sentence, head) pairs per workgroup of the decode attention (GITMI_ATTN_PW; 0 = by policy)
+    int attn_nh = 0;                    // waves per (sentence, head) pair of the decode attention (GITMI_ATTN_NH: 1 / 2)
     bool shared_device = false;         // gitmi_set_shared_device: other contexts run beside this one
     int dgemm_rows = 0;                 // rows per workgroup of the N = 768 chain GEMMs (GITMI_DGEMM_ROWS: 16 / 32 / 64; 0 = by policy)
     int decode_skip = 0;                // timing experiment (GITMI_DECODE_SKIP): launches of the decode chain left out --
@@ -331,6 +332,7 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     if (const char* env = getenv("GITMI_GRAPH")) e->use_graph = atoi(env) != 0;
     if (const char* env = getenv("GITMI_ATTN_DBG")) e->attn_dbg = atoi(env);
     if (const char* env = getenv("GITMI_ATTN_PW")) e->attn_pw = atoi(env);
+    if (const char* env = getenv("GITMI_ATTN_NH")) e->attn_nh = atoi(env);
     if (const char* env = getenv("GITMI_DECODE_SKIP")) e->decode_skip = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_ROWS")) e->dgemm_rows = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_DBG")) e->dgemm_dbg = atoi(env);
@@ -786,7 +788,7 @@ static int clone_impl(gitmi_engine* src, int max_batch, gitmi_engine** out) {
     e->N_nat = e->N = src->N_nat; e->g_nat = e->gh = e->gw = src->g_nat; e->H = e->W = src->cfg.image_size;
     e->Nmax = src->Nmax; e->max_pixels = src->max_pixels;
     e->use_graph = src->use_graph; e->skinny = src->skinny; e->use_temb = src->use_temb;
-    e->attn_dbg = src->attn_dbg; e->dgemm_dbg = src->dgemm_dbg; e->attn_pw = src->attn_pw; e->decode_skip = src->decode_skip;
+    e->attn_dbg = src->attn_dbg; e->dgemm_dbg = src->dgemm_dbg; e->attn_pw = src->attn_pw; e->attn_nh = src->attn_nh; e->decode_skip = src->decode_skip;
     e->shared_device = src->shared_device; e->dgemm_rows = src->dgemm_rows;
     e->parent = src->parent ? src->parent : src;
     e->conv_w = src->conv_w; e->cls = src->cls; e->pos = src->pos; e->pos_cur = src->pos;
@@ -1002,7 +1004,8 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
         a.out_frag = chain ? 1 : 0;
         a.N_pad = round_up(e->cur_Nimg, 32);
         a.dbg = e->attn_dbg;
-        a.pairs_per_wg = e->attn_pw > 0 ? e->attn_pw : e->shared_device ? 2 : 1;
+        a.waves_per_pair = e->attn_nh;
+        a.pairs_per_wg = e->attn_pw > 0 ? e->attn_pw : 1;      // (two-wave kernel only)
         if (e->f32) HIPCK(launch_attn_decode(a, B, c.dec_heads, true, s));
         else if (!(e->decode_skip & 1)) HIPCK(launch_attn_decode_mfma(a, B, c.dec_heads, s));
         if (chain) {
@@ -1737,8 +1740,8 @@ extern "C" int gitmi_set_temporal_embedding(gitmi_engine* e, int on) {
 }
 // Serving policy: other contexts keep the device busy beside this one.  Kernel shapes are then chosen for what they cost
 // the device as a whole rather than for their own duration: the encoder GEMMs take the 256-row tile even where it leaves
-// a partial round (the idle CUs are filled by the other contexts), the decode attention packs two (sentence, head) pairs
-// per workgroup.  Results are bit-identical either way.
+// a partial round (the idle CUs are filled by the other contexts), the N = 768 GEMMs of the decode chain take 64 rows per
+// workgroup.  Results are bit-identical either way.
 extern "C" int gitmi_set_shared_device(gitmi_engine* e, int on) {
     if (!e) return fail("null engine");
     if ((on != 0) != e->shared_device) {

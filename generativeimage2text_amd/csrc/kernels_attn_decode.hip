@@ -77,13 +77,16 @@ constexpr int ACS = 4;          // key steps per chunk and wave
 // launch over every CU (fastest on an idle device); next to the image encoder of another context every CU that holds even
 // one of these waves is closed to a GEMM workgroup (8 waves x 232 registers, 128 KiB LDS) until the wave retires: 2 pairs
 // per workgroup measured +0.7 % captions/s in the mixed schedule, 4 no further gain (profiles/r03_p_bench_lines.txt).
-template <int KB, int TI = 3, int PW = 1>
-__global__ __launch_bounds__(128 * PW) void attn_decode_mfma_kernel(AttnDecodeArgs a) {
-    __shared__ float part[PW][2][KB][HD + 2];     // [pair][half][beam]: o[64], m, l
+// NH: waves per pair.  2 = the two waves of a head split its key steps (one memory round trip each); 1 = ONE wave walks
+// all key steps in chunks of ACS (two round trips at 197 image keys): half the resident waves for ~1.3x the time.
+template <int KB, int TI = 3, int PW = 1, int NH = 2>
+__global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDecodeArgs a) {
+    __shared__ float part[PW][NH][KB][HD + 2];    // [pair][half][beam]: o[64], m, l
+    constexpr int PT = 64 * NH;                   // threads of a pair
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int hp = wave >> 1, half = wave & 1;     // pair of the workgroup, half of the head's keys
+    const int hp = wave / NH, half = wave % NH;    // pair of the workgroup, half of the head's keys
     const int H = a.d / HD;
     const int pair = PW == 1 ? (int)(blockIdx.y * H + blockIdx.x) : (int)blockIdx.x * PW + hp;
     const bool head_on = PW == 1 || pair < a.n_pairs;
@@ -104,10 +107,10 @@ __global__ __launch_bounds__(128 * PW) void attn_decode_mfma_kernel(AttnDecodeAr
     // ---- image K/V of this wave's first chunk: requested before anything else (the longest latency) ---------------
     const int nimg_steps = (!head_on || (a.dbg & 1)) ? 0 : nsteps;
     bf16x8_t kq[ACS][2][2], vq[ACS][4];
-    auto load_chunk = [&](int s0) {              // steps s0, s0 + 2, ... (this half's parity)
+    auto load_chunk = [&](int s0) {              // steps s0, s0 + NH, ... (this half's parity)
 #pragma unroll
         for (int c = 0; c < ACS; ++c) {
-            const int s = s0 + 2 * c;
+            const int s = s0 + NH * c;
             const bool on = s < nimg_steps && !(a.dbg & 8);
             const bf16_t* kp = Kf + frag_tile(2 * s, 0, 2, lane);            // the step's 4 KiB of K, then of V^T: contiguous
             const bf16_t* vp = Vt + ((size_t)s * 4 * 64 + lane) * 8;
@@ -128,13 +131,13 @@ __global__ __launch_bounds__(128 * PW) void attn_decode_mfma_kernel(AttnDecodeAr
     load_chunk(half);
 
     // ---- text items: the 16 eight-lane groups of the head's two waves share them ----------------------------------
-    const int grp = (tid & 127) >> 3, sub = tid & 7;
+    const int grp = (tid % PT) >> 3, sub = tid & 7;      // 8 * NH eight-lane groups per pair
     const int nt = a.pos + 1;
     int t_j[TI], t_s[TI];
     u32x4_t tkr[TI], tvr[TI];
 #pragma unroll
     for (int u = 0; u < TI; ++u) {
-        const int it = grp + 16 * u;
+        const int it = grp + 8 * NH * u;
         t_j[u] = (head_on && it < k * nt) ? it / nt : -1;
         t_s[u] = it < k * nt ? it % nt : 0;
         tkr[u] = u32x4_t{0u, 0u, 0u, 0u};
@@ -154,8 +157,8 @@ __global__ __launch_bounds__(128 * PW) void attn_decode_mfma_kernel(AttnDecodeAr
         }
     }
     // append this position's K/V of every beam to the text cache (16-byte copies by the first k*8 threads of the head)
-    if (head_on && (tid & 127) < k * 8) {
-        const int j = (tid & 127) >> 3;
+    if (head_on && (tid % PT) < k * 8) {
+        const int j = (tid % PT) >> 3;
         const bf16_t* src = QKV + (size_t)(row0 + j) * ld3 + a.d + h * HD + sub * 8;
         const size_t dst = ((size_t)(row0 + j) * a.T_max + a.pos) * a.d + h * HD + sub * 8;
         *reinterpret_cast<u32x4_t*>(TK + dst) = *reinterpret_cast<const u32x4_t*>(src);
@@ -179,14 +182,14 @@ __global__ __launch_bounds__(128 * PW) void attn_decode_mfma_kernel(AttnDecodeAr
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    for (int s0 = half; s0 < nimg_steps; s0 += 2 * ACS) {
+    for (int s0 = half; s0 < nimg_steps; s0 += NH * ACS) {
         if (s0 != half) load_chunk(s0);                    // later chunks (long image sequences: video, VQA resolutions)
         // every score tile of the chunk: lane (row l15, lg) holds keys 32s + t*16 + lg*4 + r
         f32x4_t sc[ACS][2];
         float cm = -INFINITY;
 #pragma unroll
         for (int c = 0; c < ACS; ++c) {
-            const int s = s0 + 2 * c;
+            const int s = s0 + NH * c;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 sc[c][t] = mfma16(kq[c][t][0], qf[0], f32x4_t{0.f, 0.f, 0.f, 0.f});
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(128 * PW) void attn_decode_mfma_kernel(AttnDecodeAr
         }
     }
     if (head_on) {
-        for (int it = grp + 16 * TI; it < k * nt; it += 16) {   // long texts: dependent-load path
+        for (int it = grp + 8 * NH * TI; it < k * nt; it += 8 * NH) {   // long texts: dependent-load path
             const int j = it / nt, sidx = it % nt;
             float kv[8], vv[8];
             if (sidx == a.pos) {
@@ -349,14 +352,21 @@ __global__ __launch_bounds__(128 * PW) void attn_decode_mfma_kernel(AttnDecodeAr
     }
     __syncthreads();
     if (!head_on) return;
-    for (int i = tid & 127; i < k * HD; i += 128) {
+    for (int i = tid % PT; i < k * HD; i += PT) {
         const int j = i / HD, dd = i % HD;
-        const float m0 = part[hp][0][j][HD], m1 = part[hp][1][j][HD];
+        if constexpr (NH == 1) {
+            const float r1 = part[hp][0][j][dd] / part[hp][0][j][HD + 1];
+            if (a.out_frag) O[frag_offset(row0 + j, h * HD + dd, a.d >> 5)] = f2bf(r1);
+            else O[(size_t)(row0 + j) * a.d + h * HD + dd] = f2bf(r1);
+            continue;
+        }
+        constexpr int H1 = NH - 1;
+        const float m0 = part[hp][0][j][HD], m1 = part[hp][H1][j][HD];
         const float mm = fmaxf(m0, m1);
         const float a0 = m0 == -INFINITY ? 0.f : fast_exp(m0 - mm);
         const float a1 = m1 == -INFINITY ? 0.f : fast_exp(m1 - mm);
-        const float num = a0 * part[hp][0][j][dd] + a1 * part[hp][1][j][dd];
-        const float den = a0 * part[hp][0][j][HD + 1] + a1 * part[hp][1][j][HD + 1];
+        const float num = a0 * part[hp][0][j][dd] + a1 * part[hp][H1][j][dd];
+        const float den = a0 * part[hp][0][j][HD + 1] + a1 * part[hp][H1][j][HD + 1];
         const float r = num / den;
         if (a.out_frag) O[frag_offset(row0 + j, h * HD + dd, a.d >> 5)] = f2bf(r);
         else O[(size_t)(row0 + j) * a.d + h * HD + dd] = f2bf(r);
@@ -379,6 +389,20 @@ hipError_t launch_attn_decode_mfma(const AttnDecodeArgs& a, int B, int H, hipStr
     AttnDecodeArgs p = a;
     p.n_pairs = B * H;
     const int pw = a.pairs_per_wg;
+    if (a.waves_per_pair != 2) {
+        // default: ONE wave per (sentence, head) pair, 4 pairs per 256-thread workgroup.  Against two waves per pair it is
+        // 1.9 us slower per launch on an idle device (two memory round trips instead of one) and keeps half as many
+        // 214-register waves resident: +1.3 % captions/s in the mixed schedule, where every CU that holds one of these
+        // waves is closed to the image encoder's GEMM workgroups (profiles/r03_v_bench_lines.txt).  waves_per_pair = 2
+        // (GITMI_ATTN_NH=2) keeps the two-wave kernel for A/B; the two differ in the last bits (one partial instead of
+        // two per row), so ONE of them is the engine's arithmetic: this one.
+        const dim3 g4((p.n_pairs + 3) / 4);
+        if (a.beams <= 1) hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 4, 1>), g4, dim3(256), 0, s, p);
+        else if (a.beams <= 2) hipLaunchKernelGGL((attn_decode_mfma_kernel<2, 3, 4, 1>), g4, dim3(256), 0, s, p);
+        else if (a.beams <= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 4, 1>), g4, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((attn_decode_mfma_kernel<8, 3, 4, 1>), g4, dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
     if (pw > 1 && (a.beams <= 1 || (a.beams > 2 && a.beams <= 4))) {
         if (a.beams <= 1) {
             if (pw >= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 4>), dim3((p.n_pairs + 3) / 4), dim3(512), 0, s, p);

@@ -68,6 +68,7 @@ enum { DEPI_BF16 = 0, DEPI_RES = 1 };
 // grid = (ceil(N/16), ceil(M/(16*MT))); block = 64*NW
 template <int MT, int NW, int EPI>
 __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs g) {
+    static_assert(NW >= MT, "wave i finishes row tile i: a workgroup needs at least MT waves");
     __shared__ __attribute__((aligned(16))) f32x4_t red[NW][MT][64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

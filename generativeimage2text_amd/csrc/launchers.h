@@ -104,6 +104,7 @@ struct AttnDecodeArgs {
     int dbg;             // timing experiments: 1 skip image K/V loads, 2 skip scores, 4 skip PV
     int pairs_per_wg;    // MFMA kernel: (sentence, head) pairs per workgroup (1, 2, 4, 8); > 1 packs the launch onto fewer CUs
     int n_pairs;         // set by the launcher
+    int waves_per_pair;  // MFMA kernel: 0 / 1 = one wave walks all key steps of a pair (default); 2 = two waves split them (A/B)
 };
 hipError_t launch_kv_repack(const void* qkv, void* kh, void* vh, int B, int N, int H, int d, bool is_f32, hipStream_t s);
 size_t attn_decode_lds_bytes(int beams, int N_img, int pos);

@@ -152,8 +152,8 @@ int  gitmi_set_encode_after(gitmi_engine* e, gitmi_engine* after);
 /* serving policy (ABI 6): tell a context that other contexts keep the device busy beside it.  Kernel shapes are then chosen
  * for what a launch costs the device as a whole, not for its own duration: the image-encoder GEMMs always take the
  * 256x256 tile (a partial round's idle CUs are filled by the other contexts; measured +2.2 % captions/s in the mixed
- * schedule, -3 % for a context alone), the decode attention packs two (sentence, head) pairs per workgroup (+0.7 %), the
- * N = 768 GEMMs of the decode chain take 64 rows per workgroup (a quarter of the workgroups; +1.5 %, beam-4 +4.5 %).
+ * schedule, -3 % for a context alone), the N = 768 GEMMs of the decode chain take 64 rows per workgroup (a quarter of the
+ * workgroups; +1.5 %, beam-4 +4.5 %).
  * Results are bit-identical either way.  Clones inherit the setting of their source at clone time. */
 int  gitmi_set_shared_device(gitmi_engine* e, int on);
 
