@@ -621,6 +621,31 @@ def main(argv=None, engine_factory=None):
             "method": "HIP events around the decode hipGraph of one context (production launch path), averaged over "
                       "5 replays; eager_step_ms = the same step with one host launch per kernel",
         }
+        if result["config"].get("shared_device_policy"):
+            # the same two measurements with the kernel shapes a context picks when it has the device to itself
+            # (gitmi_set_shared_device off): what the serving policy trades away per launch for the whole-device rate
+            solo = eng.clone()
+            solo.set_shared_device(False)
+            solo.profile_enable(1)
+            for _ in range(2):
+                solo.generate(frames, search, sync=True)
+                sprof = solo.profile_read()
+            solo.profile_enable(2)
+            for it in range(6):
+                solo.generate(frames, search, sync=True)
+                if it == 0:
+                    solo.profile_read()
+            sgprof = solo.profile_read()
+            solo.profile_enable(0)
+            solo.close()
+            s_ms = sprof["vit_gemm_ms"] / max(1, sprof["vit_gemm_launches"])
+            s_tf = flops_per_launch / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
+            result["roofline"]["solo_policy"] = {"avg_launch_ms": round(s_ms, 4), "achieved": round(s_tf, 2),
+                                                 "frac": round(s_tf / PEAK_BF16_TFLOPS, 4)}
+            ss_ms = sgprof["decode_step_ms"]
+            ss_gbs = sgprof["decode_step_bytes"] / (ss_ms * 1e-3) / 1e9 if ss_ms > 0 else 0.0
+            result["roofline_decode"]["solo_policy"] = {"avg_step_ms": round(ss_ms, 4), "achieved": round(ss_gbs, 1),
+                                                        "frac": round(ss_gbs / PEAK_HBM_GBS, 4)}
         if dgroup > 1:
             # the production decode chain of this schedule runs over the rows of a whole group: time THAT chain (graph
             # replays of one group context alone; its members publish once, the cache stays valid between replays)

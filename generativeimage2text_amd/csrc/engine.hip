@@ -1005,7 +1005,7 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
         a.N_pad = round_up(e->cur_Nimg, 32);
         a.dbg = e->attn_dbg;
         a.waves_per_pair = e->attn_nh;
-        a.pairs_per_wg = e->attn_pw > 0 ? e->attn_pw : 1;      // (two-wave kernel only)
+        a.pairs_per_wg = e->attn_pw > 0 ? e->attn_pw : e->shared_device ? 8 : 4;
         if (e->f32) HIPCK(launch_attn_decode(a, B, c.dec_heads, true, s));
         else if (!(e->decode_skip & 1)) HIPCK(launch_attn_decode_mfma(a, B, c.dec_heads, s));
         if (chain) {
@@ -1741,7 +1741,7 @@ extern "C" int gitmi_set_temporal_embedding(gitmi_engine* e, int on) {
 // Serving policy: other contexts keep the device busy beside this one.  Kernel shapes are then chosen for what they cost
 // the device as a whole rather than for their own duration: the encoder GEMMs take the 256-row tile even where it leaves
 // a partial round (the idle CUs are filled by the other contexts), the N = 768 GEMMs of the decode chain take 64 rows per
-// workgroup.  Results are bit-identical either way.
+// workgroup, the decode attention packs 8 (sentence, head) pairs per workgroup.  Results are bit-identical either way.
 extern "C" int gitmi_set_shared_device(gitmi_engine* e, int on) {
     if (!e) return fail("null engine");
     if ((on != 0) != e->shared_device) {

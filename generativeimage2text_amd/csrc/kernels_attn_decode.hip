@@ -390,13 +390,17 @@ hipError_t launch_attn_decode_mfma(const AttnDecodeArgs& a, int B, int H, hipStr
     p.n_pairs = B * H;
     const int pw = a.pairs_per_wg;
     if (a.waves_per_pair != 2) {
-        // default: ONE wave per (sentence, head) pair, 4 pairs per 256-thread workgroup.  Against two waves per pair it is
+        // default: ONE wave per (sentence, head) pair, 4 pairs per 256-thread workgroup (8 pairs / 512 threads = a full CU
+        // under the serving policy, beams 1 and 4: same per-wave arithmetic, 10.58k -> 10.67k captions/s in the mixed
+        // schedule, +11 us per decode step alone; profiles/r03_y_bench_lines.txt).  Against two waves per pair it is
         // 1.9 us slower per launch on an idle device (two memory round trips instead of one) and keeps half as many
         // 214-register waves resident: +1.3 % captions/s in the mixed schedule, where every CU that holds one of these
         // waves is closed to the image encoder's GEMM workgroups (profiles/r03_v_bench_lines.txt).  waves_per_pair = 2
         // (GITMI_ATTN_NH=2) keeps the two-wave kernel for A/B; the two differ in the last bits (one partial instead of
         // two per row), so ONE of them is the engine's arithmetic: this one.
         const dim3 g4((p.n_pairs + 3) / 4);
+        if (pw == 8 && a.beams <= 1) { hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 8, 1>), dim3((p.n_pairs + 7) / 8), dim3(512), 0, s, p); return hipGetLastError(); }
+        if (pw == 8 && a.beams > 2 && a.beams <= 4) { hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 8, 1>), dim3((p.n_pairs + 7) / 8), dim3(512), 0, s, p); return hipGetLastError(); }
         if (a.beams <= 1) hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 4, 1>), g4, dim3(256), 0, s, p);
         else if (a.beams <= 2) hipLaunchKernelGGL((attn_decode_mfma_kernel<2, 3, 4, 1>), g4, dim3(256), 0, s, p);
         else if (a.beams <= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 4, 1>), g4, dim3(256), 0, s, p);

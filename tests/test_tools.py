@@ -126,6 +126,7 @@ def _run_bench_with_fakes(monkeypatch, capsys, argv):
             return self._out(n_images, search)
 
         def load_state_dict(self, sd): pass
+        def close(self): pass
         def set_graph(self, on): pass
         def set_encode_after(self, other): pass
         def profile_enable(self, on): pass

@@ -2,9 +2,9 @@
 # Round 3 collection in one call: full GPU suite, smoke, PMC passes for the current csrc (copied to profiles/ so that the
 # bench line of this very run carries fresh `traffic`), the default bench line (with the CPU baseline), rocprofv3 kernel
 # statistics of the solo graph replay and of the default mixed schedule, bench lines of the other BASELINE configs in
-# both 16-bit operand builds.
+# both 16-bit operand builds, the default line without the serving policy and with decode groups of 2.
 set -u; mkdir -p gpurun_out; export PYTHONUNBUFFERED=1 HSA_ENABLE_IPC_MODE_LEGACY=0
-R=$PWD; TAG=${1:-r03_j}; T0=$(date +%s); t() { echo "[t+$(( $(date +%s) - T0 ))s] $*"; }
+R=$PWD; TAG=${1:-r03_z}; T0=$(date +%s); t() { echo "[t+$(( $(date +%s) - T0 ))s] $*"; }
 rm -f gpurun_out/parity_measured.jsonl
 t "pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.txt 2>&1; echo "rc=$?"; tail -n 6 gpurun_out/${TAG}_pytest_gpu.txt | cut -c1-250
 cp gpurun_out/parity_measured.jsonl gpurun_out/${TAG}_parity_measured.jsonl 2>/dev/null
@@ -25,6 +25,8 @@ t "rocprof beam solo"; prof beam4_solo --search beam --contexts 1 --steps 6 --wa
 t "rocprof large solo"; prof large_solo --model GIT_LARGE_COCO --batch 32 --contexts 1 --steps 6 --warmup 2
 cd $R
 run() { local name=$1; shift; timeout 500 python bench.py --no-cpu-baseline --steps 20 --warmup 4 "$@" 2> gpurun_out/${TAG}_${name}.err | tail -n 1 > gpurun_out/${TAG}_${name}_bench.json; python -c "import json; d=json.load(open('gpurun_out/${TAG}_${name}_bench.json')); p=d.get('parity') or {}; print('$name', d['dtype'], d['value'], d['ms_per_step'], 'ms | gemm', d['roofline']['frac'], 'decode frac', d['roofline_decode']['frac'], 'step', d['roofline_decode']['avg_step_ms'], '| parity', p.get('identical'), '/', p.get('rows'), p.get('ok'))"; }
+run base_solo_policy --solo-policy
+run base_decode_group2 --decode-group 2
 for pr in bf16 f16; do
   run base_${pr} --precision $pr
   run beam4_${pr} --search beam --precision $pr

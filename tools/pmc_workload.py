@@ -23,6 +23,7 @@ cfg = config_for_model("GIT_BASE")
 eng = E.Engine(cfg, precision="bf16", max_batch=64, max_beams=1, max_frames=1, max_text_len=20)
 eng.load_state_dict(random_state_dict(cfg, seed=1234))
 eng.set_graph(False)
+eng.set_shared_device(True)          # the kernel shapes of the benchmarked (multi-context) schedule
 frames = random_frames(cfg, 64, 1, seed=0)
 s = E.Engine.make_search("greedy", 20, 1, 1)
 for _ in range(2):
