@@ -73,10 +73,10 @@ __device__ __forceinline__ void ld8bf(const bf16_t* p, float (&v)[8]) {
 // halves meet once in LDS.  KB >= beams (1, 2, 4 or 8); TI: text items per 8-lane group loaded up front.
 constexpr int ACS = 4;          // key steps per chunk and wave
 
-// PW: (sentence, head) pairs per workgroup (1, 2 or 4; a wave needs 214 registers, so 8 waves fill a CU).  1 spreads a
-// launch over every CU (fastest on an idle device); next to the image encoder of another context every CU that holds even
-// one of these waves is closed to a GEMM workgroup (8 waves x 232 registers, 128 KiB LDS) until the wave retires: 2 pairs
-// per workgroup measured +0.7 % captions/s in the mixed schedule, 4 no further gain (profiles/r03_p_bench_lines.txt).
+// PW: (sentence, head) pairs per workgroup (a wave needs 214 registers, so 8 waves fill a CU).  1 spreads a launch over
+// every CU (fastest on an idle device); next to the image encoder of another context every CU that holds even one of
+// these waves is closed to a GEMM workgroup (8 waves x 232 registers, 128 KiB LDS) until the wave retires, so the launcher
+// packs the one-wave kernel (launch_attn_decode_mfma).
 // NH: waves per pair.  2 = the two waves of a head split its key steps (one memory round trip each); 1 = ONE wave walks
 // all key steps in chunks of ACS (two round trips at 197 image keys): half the resident waves for ~1.3x the time.
 template <int KB, int TI = 3, int PW = 1, int NH = 2>
@@ -385,42 +385,43 @@ hipError_t launch_kv_repack_frag(const void* qkv, void* kf, void* vt, int B, int
 hipError_t launch_attn_decode_mfma(const AttnDecodeArgs& a, int B, int H, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (a.beams > 8 || a.N_pad % 32 || a.N_pad < a.N_img || a.N_img < 1) return hipErrorInvalidValue;
-    const dim3 grid(H, B);
     AttnDecodeArgs p = a;
     p.n_pairs = B * H;
-    const int pw = a.pairs_per_wg;
-    if (a.waves_per_pair != 2) {
-        // default: ONE wave per (sentence, head) pair, 4 pairs per 256-thread workgroup (8 pairs / 512 threads = a full CU
-        // under the serving policy, beams 1 and 4: same per-wave arithmetic, 10.58k -> 10.67k captions/s in the mixed
-        // schedule, +11 us per decode step alone; profiles/r03_y_bench_lines.txt).  Against two waves per pair it is
-        // 1.9 us slower per launch on an idle device (two memory round trips instead of one) and keeps half as many
-        // 214-register waves resident: +1.3 % captions/s in the mixed schedule, where every CU that holds one of these
-        // waves is closed to the image encoder's GEMM workgroups (profiles/r03_v_bench_lines.txt).  waves_per_pair = 2
-        // (GITMI_ATTN_NH=2) keeps the two-wave kernel for A/B; the two differ in the last bits (one partial instead of
-        // two per row), so ONE of them is the engine's arithmetic: this one.
-        const dim3 g4((p.n_pairs + 3) / 4);
-        if (pw == 8 && a.beams <= 1) { hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 8, 1>), dim3((p.n_pairs + 7) / 8), dim3(512), 0, s, p); return hipGetLastError(); }
-        if (pw == 8 && a.beams > 2 && a.beams <= 4) { hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 8, 1>), dim3((p.n_pairs + 7) / 8), dim3(512), 0, s, p); return hipGetLastError(); }
-        if (a.beams <= 1) hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 4, 1>), g4, dim3(256), 0, s, p);
-        else if (a.beams <= 2) hipLaunchKernelGGL((attn_decode_mfma_kernel<2, 3, 4, 1>), g4, dim3(256), 0, s, p);
-        else if (a.beams <= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 4, 1>), g4, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((attn_decode_mfma_kernel<8, 3, 4, 1>), g4, dim3(256), 0, s, p);
+    // Which kernel: the GEOMETRY decides, so a model has ONE attention arithmetic (the two kernels differ in the last bits:
+    // one partial per row instead of two).
+    //  * ONE wave per (sentence, head) pair when the image keys fit two chunks (<= 8 key steps: one 224-pixel image).  Against
+    //    two waves per pair it is 1.9 us slower per launch on an idle device (two memory round trips instead of one) and
+    //    keeps half as many 214-register waves resident: +1.3 % captions/s in the mixed schedule, where every CU that holds
+    //    one of these waves is closed to the image encoder's GEMM workgroups (profiles/r03_v_bench_lines.txt).
+    //  * TWO waves per pair for long key sequences (6 video frames, a 480 x 640 VQA image: 37 steps would be 10 round trips
+    //    in one wave, 5 in two; GIT_BASE_VATEX bs = 16: 1.78k captions/s with one wave, 1.90k with two).
+    // waves_per_pair 1 / 2 (GITMI_ATTN_NH) force one of them for A/B.
+    const bool one_wave = a.waves_per_pair == 1 || (a.waves_per_pair != 2 && a.N_pad <= 8 * 32);
+    if (!one_wave) {
+        const dim3 grid(H, B);
+        if (a.beams <= 1) hipLaunchKernelGGL((attn_decode_mfma_kernel<1>), grid, dim3(128), 0, s, p);
+        else if (a.beams <= 2) hipLaunchKernelGGL((attn_decode_mfma_kernel<2>), grid, dim3(128), 0, s, p);
+        else if (a.beams <= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<4>), grid, dim3(128), 0, s, p);
+        else hipLaunchKernelGGL((attn_decode_mfma_kernel<8>), grid, dim3(128), 0, s, p);
         return hipGetLastError();
     }
-    if (pw > 1 && (a.beams <= 1 || (a.beams > 2 && a.beams <= 4))) {
-        if (a.beams <= 1) {
-            if (pw >= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 4>), dim3((p.n_pairs + 3) / 4), dim3(512), 0, s, p);
-            else hipLaunchKernelGGL((attn_decode_mfma_kernel<1, 3, 2>), dim3((p.n_pairs + 1) / 2), dim3(256), 0, s, p);
-        } else {
-            if (pw >= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 4>), dim3((p.n_pairs + 3) / 4), dim3(512), 0, s, p);
-            else hipLaunchKernelGGL((attn_decode_mfma_kernel<4, 3, 2>), dim3((p.n_pairs + 1) / 2), dim3(256), 0, s, p);
-        }
-        return hipGetLastError();
-    }
-    if (a.beams <= 1) hipLaunchKernelGGL((attn_decode_mfma_kernel<1>), grid, dim3(128), 0, s, a);
-    else if (a.beams <= 2) hipLaunchKernelGGL((attn_decode_mfma_kernel<2>), grid, dim3(128), 0, s, a);
-    else if (a.beams <= 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<4>), grid, dim3(128), 0, s, a);
-    else hipLaunchKernelGGL((attn_decode_mfma_kernel<8>), grid, dim3(128), 0, s, a);
+    // pairs per workgroup (same per-wave arithmetic whatever the packing): 4 by default, 8 = a full CU under the serving
+    // policy (10.58k -> 10.67k captions/s in the mixed schedule, +11 us per decode step alone; profiles/r03_y_*) -- but
+    // never fewer than 96 workgroups: a small batch packed onto a handful of CUs streams its K/V through too few of them
+    int pw = a.pairs_per_wg >= 8 ? 8 : a.pairs_per_wg >= 4 || a.pairs_per_wg <= 0 ? 4 : a.pairs_per_wg >= 2 ? 2 : 1;
+    while (pw > 1 && p.n_pairs / pw < 96) pw >>= 1;
+#define GITMI_ATTN1(KBV)                                                                                                   \
+    do {                                                                                                                   \
+        if (pw == 8) hipLaunchKernelGGL((attn_decode_mfma_kernel<KBV, 3, 8, 1>), dim3((p.n_pairs + 7) / 8), dim3(512), 0, s, p);      \
+        else if (pw == 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<KBV, 3, 4, 1>), dim3((p.n_pairs + 3) / 4), dim3(256), 0, s, p); \
+        else if (pw == 2) hipLaunchKernelGGL((attn_decode_mfma_kernel<KBV, 3, 2, 1>), dim3((p.n_pairs + 1) / 2), dim3(128), 0, s, p); \
+        else hipLaunchKernelGGL((attn_decode_mfma_kernel<KBV, 3, 1, 1>), dim3(p.n_pairs), dim3(64), 0, s, p);                         \
+    } while (0)
+    if (a.beams <= 1) GITMI_ATTN1(1);
+    else if (a.beams <= 2) GITMI_ATTN1(2);
+    else if (a.beams <= 4) GITMI_ATTN1(4);
+    else { if (pw == 8) pw = 4; GITMI_ATTN1(8); }       // 8 beams: 269 registers, one wave per SIMD: 4 pairs fill a CU
+#undef GITMI_ATTN1
     return hipGetLastError();
 }
 
