@@ -124,6 +124,13 @@ def pmc_profile(kernel_substrs):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.tsv")))
     if not files:
         return None
+
+    def sha_of(f):
+        with open(f) as fh:
+            return next((l.split("=", 1)[1].strip() for l in fh if l.startswith("# csrc_sha=")), None)
+    # the summary taken for THIS csrc/ if there is one, else the last by name (reported as stale)
+    cur = csrc_sha()
+    files = [f for f in files if sha_of(f) == cur][-1:] or files
     lines = open(files[-1]).read().splitlines()
     sha = next((l.split("=", 1)[1].strip() for l in lines if l.startswith("# csrc_sha=")), None)
     rows = [l.split("\t") for l in lines if not l.startswith("#")]

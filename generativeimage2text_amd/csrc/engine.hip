@@ -142,6 +142,7 @@ struct gitmi_engine {
     int attn_pw = 0;                    // (sentence, head) pairs per workgroup of the decode attention (GITMI_ATTN_PW; 0 = by policy)
     int attn_nh = 0;                    // waves per (sentence, head) pair of the decode attention (GITMI_ATTN_NH: 1 / 2)
     bool shared_device = false;         // gitmi_set_shared_device: other contexts run beside this one
+    int dgemm_no_row_walk = -1;         // A/B (GITMI_DGEMM_NO_ROW_WALK=0|1; -1 = by policy)
     int dgemm_rows = 0;                 // rows per workgroup of the N = 768 chain GEMMs (GITMI_DGEMM_ROWS: 16 / 32 / 64; 0 = by policy)
     int decode_skip = 0;                // timing experiment (GITMI_DECODE_SKIP): launches of the decode chain left out --
                                         // 1 attention, 2 QKV / FFN1 GEMMs, 4 out-proj / FFN2 GEMMs, 8 vocabulary head (ids are garbage)
@@ -181,6 +182,7 @@ struct gitmi_engine {
     int kv_image_off = 0;
     std::vector<gitmi_engine*> kv_members;      // on the group context
     hipEvent_t kv_published = nullptr;          // member: the K/V of its latest request are in the group's cache
+    bool kv_pending = false;                    // member: a request was published that no gitmi_group_decode has been submitted for
     hipEvent_t group_dec_done = nullptr;        // group: the latest decode chain over the cache has finished
     bool graph_is_group = false;
     double split_encode_ms = 0, split_decode_ms = 0;
@@ -335,6 +337,7 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     if (const char* env = getenv("GITMI_ATTN_NH")) e->attn_nh = atoi(env);
     if (const char* env = getenv("GITMI_DECODE_SKIP")) e->decode_skip = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_ROWS")) e->dgemm_rows = atoi(env);
+    if (const char* env = getenv("GITMI_DGEMM_NO_ROW_WALK")) e->dgemm_no_row_walk = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_DBG")) e->dgemm_dbg = atoi(env);
     if (const char* env = getenv("GITMI_SKINNY")) e->skinny = atoi(env) != 0;
     e->stream_f16 = !e->f32;
@@ -370,7 +373,7 @@ extern "C" void gitmi_destroy(gitmi_engine* e) {
         v.erase(std::remove(v.begin(), v.end(), e), v.end());
     }
     for (gitmi_engine* m : e->kv_members) {       // members of a destroyed group go back to their own caches
-        m->kv_group = nullptr; m->kv_image_off = 0;
+        m->kv_group = nullptr; m->kv_image_off = 0; m->kv_pending = false;
         destroy_graph(m);
     }
     if (e->kv_published) hipEventDestroy(e->kv_published);
@@ -789,7 +792,7 @@ static int clone_impl(gitmi_engine* src, int max_batch, gitmi_engine** out) {
     e->Nmax = src->Nmax; e->max_pixels = src->max_pixels;
     e->use_graph = src->use_graph; e->skinny = src->skinny; e->use_temb = src->use_temb;
     e->attn_dbg = src->attn_dbg; e->dgemm_dbg = src->dgemm_dbg; e->attn_pw = src->attn_pw; e->attn_nh = src->attn_nh; e->decode_skip = src->decode_skip;
-    e->shared_device = src->shared_device; e->dgemm_rows = src->dgemm_rows;
+    e->shared_device = src->shared_device; e->dgemm_rows = src->dgemm_rows; e->dgemm_no_row_walk = src->dgemm_no_row_walk;
     e->parent = src->parent ? src->parent : src;
     e->conv_w = src->conv_w; e->cls = src->cls; e->pos = src->pos; e->pos_cur = src->pos;
     e->lnpre_g = src->lnpre_g; e->lnpre_b = src->lnpre_b; e->lnpost_g = src->lnpost_g; e->lnpost_b = src->lnpost_b;
@@ -969,6 +972,10 @@ static int dgemm(gitmi_engine* e, hipStream_t s, const DGemmArgs& g_in) {
     // beam batches -- faster even alone (R = 256: 0.466 -> 0.461 ms per step) -- and whenever other contexts share the
     // device: the launch is 2.8 us longer on its own but closes far fewer CUs to the encoder's GEMM workgroups
     // (profiles/r03_t_bench_lines.txt: greedy 10.34k -> 10.49k, beam-4 6.70k -> 7.00k captions/s in the mixed schedule)
+    // wide GEMMs over > 64 rows (beam batches, decode groups): one workgroup per strip walks the row blocks with its weight
+    // fragments in registers when other contexts share the device (beam-4: 7.18k -> 7.30k captions/s in the mixed schedule,
+    // profiles/r03_zzz_ab_bench_lines.txt); alone, one workgroup per (strip, row block) is 3.5 us faster per launch
+    g.no_row_walk = e->dgemm_no_row_walk >= 0 ? e->dgemm_no_row_walk : e->shared_device ? 0 : 1;
     g.rows_per_wg = e->dgemm_rows > 0 ? e->dgemm_rows : (e->shared_device || g.M > 64) ? 64 : 16;
     SpanGuard sp(e, s, TAG_GEMM_OTHER, 2.0 * (double)g.M * (double)g.N * (double)g.K);
     HIPCK(launch_dgemm(g, s));
@@ -1408,6 +1415,11 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     const bool graph = e->use_graph && !e->profiling && !long_budget;
     const bool group = phase == 3, member = e->kv_group != nullptr;
     if (member && phase != 1) return fail("this context is a member of a decode group: gitmi_generate_encode + gitmi_group_decode");
+    // host order is the contract (include/gitmi.h): a member's next request would overwrite K/V its group has not been
+    // ASKED to decode yet -- no event can order that, so it is refused
+    if (member && e->kv_pending)
+        return fail("generate_encode: the previous request of this member (images from %d) has not been submitted to "
+                    "gitmi_group_decode yet", e->kv_image_off);
     const int F_in = c.num_frames > 0 ? std::min(F, c.num_frames) : F;
     if (group) {        // host-side state a prefill on this context would have left behind
         e->cur_B = B; e->cur_F = F_in; e->cur_Nimg = F_in * e->N;
@@ -1421,6 +1433,7 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
             if (e->kv_group->group_dec_done) HIPCK(hipStreamWaitEvent(s, e->kv_group->group_dec_done, 0));
             RCK(publish_kv(e, s));
             HIPCK(hipEventRecord(e->kv_published, s));
+            e->kv_pending = true;
             return 0;
         }
         if (phase == 1) return generate_encode(e, frames, F, B, s);
@@ -1505,6 +1518,7 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
         if (e->kv_group->group_dec_done) HIPCK(hipStreamWaitEvent(x, e->kv_group->group_dec_done, 0));
         HIPCK(hipGraphLaunch(e->graph_exec_b, x));
         HIPCK(hipEventRecord(e->kv_published, x));
+        e->kv_pending = true;
         e->half_submitted = false;
     } else if (!split) {
         HIPCK(hipGraphLaunch(e->graph_exec, x));
@@ -1600,6 +1614,7 @@ static void unlink_decode_group(gitmi_engine* m) {
     v.erase(std::remove(v.begin(), v.end(), m), v.end());
     m->kv_group = nullptr;
     m->kv_image_off = 0;
+    m->kv_pending = false;
     destroy_graph(m);                   // its graphs write into the group's cache
 }
 
@@ -1649,10 +1664,14 @@ extern "C" int gitmi_group_decode(gitmi_engine* e, int F, int B, const int64_t* 
         if (m->cur_F != F_in || m->N != e->N || m->cur_B < 1)
             return fail("group_decode: the member at image %d has no published request of this geometry", m->kv_image_off);
         for (int i = m->kv_image_off; i < std::min(B, m->kv_image_off + m->cur_B); ++i) have[(size_t)i] = 1;
-        HIPCK(hipStreamWaitEvent(s, m->kv_published, 0));
     }
     for (int i = 0; i < B; ++i)
         if (!have[(size_t)i]) return fail("group_decode: image %d of %d was not published by any member", i, B);
+    for (gitmi_engine* m : e->kv_members) {
+        if (m->kv_image_off >= B) continue;
+        HIPCK(hipStreamWaitEvent(s, m->kv_published, 0));
+        m->kv_pending = false;
+    }
     RCK(fill_uniform_sentences(e, B, (const long long*)prefix, P, s));
     e->img_identity = true;
     RCK(generate_run(e, nullptr, F, B, B, P, P, false, sp, tokens_out, logprob_out, info_out, nullptr, s, 3));

@@ -243,6 +243,113 @@ __global__ __launch_bounds__(64 * NW) void dgemm_kernel(DGemmArgs g) {
     }
 }
 
+// ---- wide form over MORE than 64 rows (beam batches, decode groups): the workgroup walks the row blocks ------------
+// grid = (ceil(N/16), 1); block = 256.  Same arithmetic per row as dgemm_kernel<4, 4, DEPI_BF16> (K split over 4 waves,
+// partials summed in wave order), so results are bit-identical; the wave's slice of the weight strip (K/4 <= 6 k-steps)
+// is loaded ONCE and stays in registers while the workgroup walks the 64-row blocks -- with one workgroup per (strip,
+// row block) a 256-row beam batch streamed every weight four times (9.1 us against 5.7 us for 64 rows).
+constexpr int DW_KS = 6;        // k-steps per wave held in registers: K <= 4 * 6 * 32 = 768
+
+__global__ __launch_bounds__(256) void dgemm_wide_rows_kernel(DGemmArgs g) {
+    __shared__ __attribute__((aligned(16))) f32x4_t red[2][4][4][64];      // double-buffered: one barrier per row block
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.x * 16, fn = n0 + lg * 4;
+    const bf16_t* __restrict__ X = g.A;
+    const int ksteps = g.K >> 5;
+    const int per = (ksteps + 3) / 4;
+    const int kb = wave * per, ke = min(kb + per, ksteps);
+
+    auto ld4 = [&](const float* p, int n) {
+        float4 r;
+        r.x = p[n < g.N ? n : g.N - 1];
+        r.y = p[n + 1 < g.N ? n + 1 : g.N - 1];
+        r.z = p[n + 2 < g.N ? n + 2 : g.N - 1];
+        r.w = p[n + 3 < g.N ? n + 3 : g.N - 1];
+        return r;
+    };
+    // per-column constants and this wave's weight fragments: once per workgroup
+    const float4 bias4 = ld4(g.bias, fn);
+    const float4 cs4 = g.stats_in ? ld4(g.colsum, fn) : float4{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* wp = g.W + frag_tile(blockIdx.x, 0, ksteps, lane);
+    bf16x8_t wf[DW_KS];
+#pragma unroll
+    for (int u = 0; u < DW_KS; ++u)
+        wf[u] = kb + u < ke ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)(kb + u) * 512))
+                            : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+
+    const int nrb = (g.M + 63) >> 6;
+    for (int rb = 0; rb < nrb; ++rb) {
+        const int m0 = rb * 64;
+        const int fm_raw = m0 + wave * 16 + l15;                 // wave i finishes row tile i of the block
+        const int fm = fm_raw < g.M ? fm_raw : g.M - 1;
+        RowStatLoads sl;
+        if (g.stats_in) stats_issue(sl, g.stats_in, g.strips_in, g.M, fm, lg);
+        bf16x8_t xf[DW_KS][4];
+#pragma unroll
+        for (int u = 0; u < DW_KS; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xf[u][i] = kb + u < ke ? *reinterpret_cast<const bf16x8_t*>(X + frag_tile(rb * 4 + i, kb + u, ksteps, lane))
+                                       : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        f32x4_t acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < DW_KS; ++u) {
+            if (kb + u < ke) {                                   // uniform per wave; keeps the MFMA sequence of dgemm_kernel
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = mfma16(wf[u], xf[u][i], acc[i]);
+            }
+        }
+        f32x4_t(*rd)[4][64] = red[rb & 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rd[wave][i][lane] = acc[i];
+        __syncthreads();
+        f32x4_t tot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const f32x4_t t = rd[w][wave][lane];
+            tot[0] += t[0]; tot[1] += t[1]; tot[2] += t[2]; tot[3] += t[3];
+        }
+        float v[4] = {tot[0], tot[1], tot[2], tot[3]};
+        const float biasv[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+        if (g.stats_in) {
+            float mean, rstd;
+            stats_finish(sl, g.inv_d, g.eps_in, mean, rstd);
+            const float cs[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * cs[r]) + biasv[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += biasv[r];
+        }
+        if (g.act != GITMI_ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], g.act);
+        }
+        if (fm_raw >= g.M || fn >= g.N) continue;
+        if (g.c_frag) {
+            uint2 t;
+            t.x = pack2bf(v[0], v[1]);
+            t.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + frag_offset(fm, fn, g.N >> 5)) = t;
+            continue;
+        }
+        bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (size_t)fm * g.ldc + fn;
+        if (fn + 3 < g.N && (g.ldc & 3) == 0) {
+            uint2 t;
+            t.x = pack2bf(v[0], v[1]);
+            t.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(cp) = t;
+        } else {
+            for (int r = 0; r < 4; ++r)
+                if (fn + r < g.N) cp[r] = f2bf(v[r]);
+        }
+    }
+}
+
 // ---- vocabulary head + running top-M / log-sum-exp ---------------------------------------------------------
 // grid = (ceil(V / (16*NS)), ceil(M/(16*MT))); block = 256 (K split over 4 waves, K <= 768).
 // A workgroup owns NS 16-column strips.  EVERY weight fragment of its strips is requested before the first MFMA
@@ -456,6 +563,8 @@ static hipError_t launch_dgemm_t(const DGemmArgs& g, hipStream_t s) {
         hipLaunchKernelGGL((dgemm_kernel<1, 4, EPI>), dim3((g.N + 15) / 16, 1), dim3(256), 0, s, g);
     } else if (g.M <= 32) {
         hipLaunchKernelGGL((dgemm_kernel<2, 4, EPI>), dim3((g.N + 15) / 16, 1), dim3(256), 0, s, g);
+    } else if (EPI == DEPI_BF16 && g.M > 64 && (g.K >> 5) <= 4 * DW_KS && !g.dbg && !g.no_row_walk) {
+        hipLaunchKernelGGL(dgemm_wide_rows_kernel, dim3((g.N + 15) / 16, 1), dim3(256), 0, s, g);       // weights once for all row blocks
     } else {
         hipLaunchKernelGGL((dgemm_kernel<4, 4, EPI>), dim3((g.N + 15) / 16, (g.M + 63) / 64), dim3(256), 0, s, g);
     }

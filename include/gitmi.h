@@ -153,7 +153,8 @@ int  gitmi_set_encode_after(gitmi_engine* e, gitmi_engine* after);
  * for what a launch costs the device as a whole, not for its own duration: the image-encoder GEMMs always take the
  * 256x256 tile (a partial round's idle CUs are filled by the other contexts; measured +2.2 % captions/s in the mixed
  * schedule, -3 % for a context alone), the N = 768 GEMMs of the decode chain take 64 rows per workgroup (a quarter of the
- * workgroups; +1.5 %, beam-4 +4.5 %), the decode attention packs 8 instead of 4 (sentence, head) pairs per workgroup (+0.8 %).
+ * workgroups; +1.5 %, beam-4 +4.5 %), the decode attention packs 8 instead of 4 (sentence, head) pairs per workgroup (+0.8 %), the wide
+ * chain GEMMs of beam batches walk their row blocks in one workgroup per weight strip (beam-4 +1.7 %).
  * Results are bit-identical either way.  Clones inherit the setting of their source at clone time. */
 int  gitmi_set_shared_device(gitmi_engine* e, int on);
 
@@ -226,7 +227,9 @@ int  gitmi_generate_decode(gitmi_engine* e, int F, int B, const int64_t* prefix,
  * what its own gitmi_generate call returns (same kernels, same per-row arithmetic).
  *   ordering is the engine's: a member's K/V repack (a small graph of its own behind its prefill) waits for the group's
  *   previous gitmi_group_decode, and gitmi_group_decode waits for the members covering images [0, B).  The caller only
- *   keeps HOST order: the members' gitmi_generate_encode calls of a round, then the group's decode, then the next round.
+ *   keeps HOST order: the members' gitmi_generate_encode calls of a round, then the group's decode, then the next round
+ *   (a member's next gitmi_generate_encode before a gitmi_group_decode covering its previous request was submitted is
+ *   refused: no event could order it).
  *   A member accepts gitmi_generate_encode only (search / prefix arguments as for the group's decode).
  * gitmi_set_decode_group(member, NULL, 0) detaches; destroying either context removes the link. */
 int  gitmi_clone_sized(gitmi_engine* src, int max_batch, gitmi_engine** out);

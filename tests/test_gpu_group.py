@@ -103,6 +103,14 @@ def test_group_membership_rules_and_detach():
         group.set_decode_group(group, 0)
     with pytest.raises(GitmiError, match="itself a member"):
         extra.set_decode_group(members[0], 0)
+    # host order is the contract: a member's next request before its group was asked to decode the previous one is refused
+    members[0].generate_encode(frames, search)
+    with pytest.raises(GitmiError, match="has not been submitted to gitmi_group_decode"):
+        members[0].generate_encode(frames, search)
+    members[1].generate_encode(frames, search)
+    tok, _, _ = group.group_decode(1, 4, search)
+    assert torch.equal(tok[:2], want[0]) and torch.equal(tok[2:], want[0])
+    members[0].generate_encode(frames, search)               # ... and accepted again afterwards
     # detaching gives the context its own cache (and whole calls) back
     members[0].set_decode_group(None)
     got = members[0].generate(frames, search)

@@ -169,6 +169,10 @@ def test_dgemm_qkv_ffn1_form(M, N, K, act, fold):
         assert (out.cpu().double() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
         if N % 32 == 0:      # fragment-major output (operand of the next chain GEMM) holds the same values
             assert torch.equal(E.op_dgemm(A.cuda(), W.bfloat16().cuda(), bias.cuda(), act=act, frag_out=True), out)
+        if M > 64:           # the row-walking kernel (> 64 rows) == the one-block kernel on the same rows, bit for bit
+            hi = min(M, 128)
+            sub = E.op_dgemm(A[64:hi].contiguous().cuda(), W.bfloat16().cuda(), bias.cuda(), act=act)
+            assert torch.equal(sub, out[64:hi])
         return
     if K % 16:
         pytest.skip("strip partials need K % 16 == 0")
@@ -178,7 +182,13 @@ def test_dgemm_qkv_ffn1_form(M, N, K, act, fold):
                + bias.double(), act)
     Wf, bf, cs = _fold(W, bias, gamma, beta)
     stats = E.strip_stats(x.cuda())
-    out = E.op_dgemm(x.bfloat16().cuda(), Wf.cuda(), bf.cuda(), cs.cuda(), stats, 1e-12, act).cpu().double()
+    out_dev = E.op_dgemm(x.bfloat16().cuda(), Wf.cuda(), bf.cuda(), cs.cuda(), stats, 1e-12, act)
+    if M > 64:               # row-walking kernel vs one-block kernel, folded LayerNorm included
+        hi = min(M, 128)
+        sub = E.op_dgemm(x[64:hi].bfloat16().contiguous().cuda(), Wf.cuda(), bf.cuda(), cs.cuda(),
+                         stats[:, 64:hi].contiguous(), 1e-12, act)
+        assert torch.equal(sub, out_dev[64:hi])
+    out = out_dev.cpu().double()
     # bf16 operands on both sides: error ~ 2^-8 relative to the output scale
     assert (out - ref).abs().max().item() < 2.5e-2 * max(1.0, ref.abs().max().item())
     # against the same arithmetic in fp64 (bf16 operands as the kernel sees them): only fp32 summation-order error + bf16 output rounding
