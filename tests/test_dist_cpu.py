@@ -179,6 +179,40 @@ def _bench_main_worker(rank, world, port, tmpdir):
         assert res is None and gathered[-1] == (None, None)
 
 
+def _bench_group_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import bench
+    gathered = []
+    real_gather = bench.gather_results
+
+    def spy(tokens, logprobs):
+        out = real_gather(tokens, logprobs)
+        gathered.append(out)
+        return out
+    bench.gather_results = spy
+    res = bench.main(["--gpus", str(world), "--steps", "4", "--warmup", "2", "--batch", "3", "--contexts", "2",
+                      "--decode-group", "2", "--no-cpu-baseline"],
+                     engine_factory=lambda args, r: (_StandInEngine(r, args.batch, args.max_steps), [torch.zeros(1)]))
+    if rank == 0:
+        # every request of a group is gathered on its own: [world x batch, T] rows in rank order, twice per group decode
+        assert res["n_gpus"] == world and res["config"]["global_batch"] == world * 3
+        t, l = gathered[-1]
+        assert t.shape == (world * 3, 20) and t[:3].eq(1000).all() and t[3:].eq(1001).all()
+        assert len(gathered) % 2 == 0
+        open(os.path.join(tmpdir, "ok"), "w").write(json.dumps(res))
+    else:
+        assert res is None and gathered[-1] == (None, None)
+
+
+def test_two_rank_bench_decode_groups_with_standin_engine(tmp_path):
+    """bench.main --decode-group 2 under a 2-rank launcher environment (gloo, stand-in engine): each rank runs its own
+    groups; the rows of every request reach rank 0 in rank order."""
+    mp.spawn(_bench_group_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert json.loads((tmp_path / "ok").read_text())["n_gpus"] == 2
+
+
 def test_two_rank_bench_main_with_standin_engine(tmp_path):
     """bench.main under a 2-rank launcher environment (gloo, stand-in engine): every rank runs, rank 0 prints ONE line
     with n_gpus == --gpus == WORLD_SIZE, the gather delivers every rank's rows to rank 0."""
