@@ -143,6 +143,7 @@ struct gitmi_engine {
     int attn_nh = 0;                    // waves per (sentence, head) pair of the decode attention (GITMI_ATTN_NH: 1 / 2)
     bool shared_device = false;         // gitmi_set_shared_device: other contexts run beside this one
     int dgemm_no_row_walk = -1;         // A/B (GITMI_DGEMM_NO_ROW_WALK=0|1; -1 = by policy)
+    int dgemm_two_strips = -1;          // A/B (GITMI_DGEMM_WIDE2=0|1; -1 = by policy)
     int dgemm_rows = 0;                 // rows per workgroup of the N = 768 chain GEMMs (GITMI_DGEMM_ROWS: 16 / 32 / 64; 0 = by policy)
     int decode_skip = 0;                // timing experiment (GITMI_DECODE_SKIP): launches of the decode chain left out --
                                         // 1 attention, 2 QKV / FFN1 GEMMs, 4 out-proj / FFN2 GEMMs, 8 vocabulary head (ids are garbage)
@@ -337,6 +338,7 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     if (const char* env = getenv("GITMI_ATTN_NH")) e->attn_nh = atoi(env);
     if (const char* env = getenv("GITMI_DECODE_SKIP")) e->decode_skip = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_ROWS")) e->dgemm_rows = atoi(env);
+    if (const char* env = getenv("GITMI_DGEMM_WIDE2")) e->dgemm_two_strips = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_NO_ROW_WALK")) e->dgemm_no_row_walk = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_DBG")) e->dgemm_dbg = atoi(env);
     if (const char* env = getenv("GITMI_SKINNY")) e->skinny = atoi(env) != 0;
@@ -792,7 +794,7 @@ static int clone_impl(gitmi_engine* src, int max_batch, gitmi_engine** out) {
     e->Nmax = src->Nmax; e->max_pixels = src->max_pixels;
     e->use_graph = src->use_graph; e->skinny = src->skinny; e->use_temb = src->use_temb;
     e->attn_dbg = src->attn_dbg; e->dgemm_dbg = src->dgemm_dbg; e->attn_pw = src->attn_pw; e->attn_nh = src->attn_nh; e->decode_skip = src->decode_skip;
-    e->shared_device = src->shared_device; e->dgemm_rows = src->dgemm_rows; e->dgemm_no_row_walk = src->dgemm_no_row_walk;
+    e->shared_device = src->shared_device; e->dgemm_rows = src->dgemm_rows; e->dgemm_two_strips = src->dgemm_two_strips; e->dgemm_no_row_walk = src->dgemm_no_row_walk;
     e->parent = src->parent ? src->parent : src;
     e->conv_w = src->conv_w; e->cls = src->cls; e->pos = src->pos; e->pos_cur = src->pos;
     e->lnpre_g = src->lnpre_g; e->lnpre_b = src->lnpre_b; e->lnpost_g = src->lnpost_g; e->lnpost_b = src->lnpost_b;
@@ -976,6 +978,7 @@ static int dgemm(gitmi_engine* e, hipStream_t s, const DGemmArgs& g_in) {
     // fragments in registers when other contexts share the device (beam-4: 7.18k -> 7.30k captions/s in the mixed schedule,
     // profiles/r03_zzz_ab_bench_lines.txt); alone, one workgroup per (strip, row block) is 3.5 us faster per launch
     g.no_row_walk = e->dgemm_no_row_walk >= 0 ? e->dgemm_no_row_walk : e->shared_device ? 0 : 1;
+    g.two_strips = e->dgemm_two_strips >= 0 ? e->dgemm_two_strips : e->shared_device ? 1 : 0;
     g.rows_per_wg = e->dgemm_rows > 0 ? e->dgemm_rows : (e->shared_device || g.M > 64) ? 64 : 16;
     SpanGuard sp(e, s, TAG_GEMM_OTHER, 2.0 * (double)g.M * (double)g.N * (double)g.K);
     HIPCK(launch_dgemm(g, s));

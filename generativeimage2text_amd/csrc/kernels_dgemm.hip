@@ -350,6 +350,120 @@ __global__ __launch_bounds__(256) void dgemm_wide_rows_kernel(DGemmArgs g) {
     }
 }
 
+// ---- wide form, <= 64 rows, TWO adjacent 16-column strips per workgroup ---------------------------------------------
+// grid = (ceil(N/32), 1); block = 256.  Per element the arithmetic of dgemm_kernel<4, 4, DEPI_BF16> (K split over 4 waves,
+// partials summed in wave order): bit-identical results.  The four waves load the activation fragments of their K slice
+// ONCE and the weight fragments of both strips up front (one memory round trip, as before), then run the two strips
+// back to back: half the workgroups / resident waves and half the activation traffic for ~1 us more per launch -- what
+// a decode launch costs the image encoders running beside it is its resident waves x time.
+__global__ __launch_bounds__(256) void dgemm_wide2_kernel(DGemmArgs g) {
+    __shared__ __attribute__((aligned(16))) f32x4_t red[2][4][4][64];      // [strip][wave][row tile][lane]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int nstrips = (g.N + 15) >> 4;
+    const bf16_t* __restrict__ X = g.A;
+    const int ksteps = g.K >> 5;
+    const int per = (ksteps + 3) / 4;
+    const int kb = wave * per, ke = min(kb + per, ksteps);
+    const int fm_raw = wave * 16 + l15;                       // wave i finishes row tile i
+    const int fm = fm_raw < g.M ? fm_raw : g.M - 1;
+
+    auto ld4 = [&](const float* p, int n) {
+        float4 r;
+        r.x = p[n < g.N ? n : g.N - 1];
+        r.y = p[n + 1 < g.N ? n + 1 : g.N - 1];
+        r.z = p[n + 2 < g.N ? n + 2 : g.N - 1];
+        r.w = p[n + 3 < g.N ? n + 3 : g.N - 1];
+        return r;
+    };
+    RowStatLoads sl;
+    if (g.stats_in) stats_issue(sl, g.stats_in, g.strips_in, g.M, fm, lg);
+    float4 bias4[2], cs4[2];
+    bf16x8_t wf[2][DW_KS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int strip = min((int)blockIdx.x * 2 + t, nstrips - 1);
+        const int fn = strip * 16 + lg * 4;
+        bias4[t] = ld4(g.bias, fn);
+        cs4[t] = g.stats_in ? ld4(g.colsum, fn) : float4{0.f, 0.f, 0.f, 0.f};
+        const bf16_t* wp = g.W + frag_tile(strip, 0, ksteps, lane);
+#pragma unroll
+        for (int u = 0; u < DW_KS; ++u)
+            wf[t][u] = kb + u < ke ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)(kb + u) * 512))
+                                   : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    bf16x8_t xf[DW_KS][4];
+#pragma unroll
+    for (int u = 0; u < DW_KS; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            xf[u][i] = kb + u < ke ? *reinterpret_cast<const bf16x8_t*>(X + frag_tile(i, kb + u, ksteps, lane))
+                                   : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f32x4_t acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < DW_KS; ++u) {
+            if (kb + u < ke) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = mfma16(wf[t][u], xf[u][i], acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[t][wave][i][lane] = acc[i];
+    }
+    __syncthreads();
+    float mean = 0.f, rstd = 1.f;
+    if (g.stats_in) stats_finish(sl, g.inv_d, g.eps_in, mean, rstd);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int strip = (int)blockIdx.x * 2 + t;
+        if (strip >= nstrips) break;
+        const int fn = strip * 16 + lg * 4;
+        f32x4_t tot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const f32x4_t p = red[t][w][wave][lane];
+            tot[0] += p[0]; tot[1] += p[1]; tot[2] += p[2]; tot[3] += p[3];
+        }
+        float v[4] = {tot[0], tot[1], tot[2], tot[3]};
+        const float biasv[4] = {bias4[t].x, bias4[t].y, bias4[t].z, bias4[t].w};
+        if (g.stats_in) {
+            const float cs[4] = {cs4[t].x, cs4[t].y, cs4[t].z, cs4[t].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * cs[r]) + biasv[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += biasv[r];
+        }
+        if (g.act != GITMI_ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], g.act);
+        }
+        if (fm_raw >= g.M || fn >= g.N) continue;
+        if (g.c_frag) {
+            uint2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C) + frag_offset(fm, fn, g.N >> 5)) = o;
+            continue;
+        }
+        bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (size_t)fm * g.ldc + fn;
+        if (fn + 3 < g.N && (g.ldc & 3) == 0) {
+            uint2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(cp) = o;
+        } else {
+            for (int r = 0; r < 4; ++r)
+                if (fn + r < g.N) cp[r] = f2bf(v[r]);
+        }
+    }
+}
+
 // ---- vocabulary head + running top-M / log-sum-exp ---------------------------------------------------------
 // grid = (ceil(V / (16*NS)), ceil(M/(16*MT))); block = 256 (K split over 4 waves, K <= 768).
 // A workgroup owns NS 16-column strips.  EVERY weight fragment of its strips is requested before the first MFMA
@@ -563,6 +677,8 @@ static hipError_t launch_dgemm_t(const DGemmArgs& g, hipStream_t s) {
         hipLaunchKernelGGL((dgemm_kernel<1, 4, EPI>), dim3((g.N + 15) / 16, 1), dim3(256), 0, s, g);
     } else if (g.M <= 32) {
         hipLaunchKernelGGL((dgemm_kernel<2, 4, EPI>), dim3((g.N + 15) / 16, 1), dim3(256), 0, s, g);
+    } else if (EPI == DEPI_BF16 && g.M <= 64 && (g.K >> 5) <= 4 * DW_KS && (g.two_strips || (g.dbg & 32))) {
+        hipLaunchKernelGGL(dgemm_wide2_kernel, dim3((g.N + 31) / 32, 1), dim3(256), 0, s, g);           // two strips per workgroup
     } else if (EPI == DEPI_BF16 && g.M > 64 && (g.K >> 5) <= 4 * DW_KS && !g.dbg && !g.no_row_walk) {
         hipLaunchKernelGGL(dgemm_wide_rows_kernel, dim3((g.N + 15) / 16, 1), dim3(256), 0, s, g);       // weights once for all row blocks
     } else {

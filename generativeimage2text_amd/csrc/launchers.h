@@ -43,6 +43,7 @@ struct DGemmArgs {
     int M, N, K, lda, ldc, act;
     int dbg;                    // timing experiments only: 1 no activation loads, 2 no weight loads, 4 no MFMA, 8 no epilogue loads
     int rows_per_wg;            // N = 768 form: rows per workgroup (0 / 16 default, 32, 64)
+    int two_strips;             // wide form, 33..64 rows: two 16-column strips per workgroup, one after the other (serving policy)
     int no_row_walk;            // A/B: wide form over > 64 rows as one workgroup per (strip, row block) instead of the row-walking kernel
 };
 hipError_t launch_dgemm(const DGemmArgs& g, hipStream_t s);

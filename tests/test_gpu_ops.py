@@ -169,6 +169,14 @@ def test_dgemm_qkv_ffn1_form(M, N, K, act, fold):
         assert (out.cpu().double() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
         if N % 32 == 0:      # fragment-major output (operand of the next chain GEMM) holds the same values
             assert torch.equal(E.op_dgemm(A.cuda(), W.bfloat16().cuda(), bias.cuda(), act=act, frag_out=True), out)
+        if 32 < M <= 64 and N >= 1536:      # two strips per workgroup (serving policy) == one strip per workgroup, bit for bit
+            lib = E.load_library()
+            lib.gitmi_debug_set_dgemm(32)
+            try:
+                two = E.op_dgemm(A.cuda(), W.bfloat16().cuda(), bias.cuda(), act=act)
+            finally:
+                lib.gitmi_debug_set_dgemm(0)
+            assert torch.equal(two, out)
         if M > 64:           # the row-walking kernel (> 64 rows) == the one-block kernel on the same rows, bit for bit
             hi = min(M, 128)
             sub = E.op_dgemm(A[64:hi].contiguous().cuda(), W.bfloat16().cuda(), bias.cuda(), act=act)
@@ -183,6 +191,14 @@ def test_dgemm_qkv_ffn1_form(M, N, K, act, fold):
     Wf, bf, cs = _fold(W, bias, gamma, beta)
     stats = E.strip_stats(x.cuda())
     out_dev = E.op_dgemm(x.bfloat16().cuda(), Wf.cuda(), bf.cuda(), cs.cuda(), stats, 1e-12, act)
+    if 32 < M <= 64 and N >= 1536:
+        lib = E.load_library()
+        lib.gitmi_debug_set_dgemm(32)
+        try:
+            two = E.op_dgemm(x.bfloat16().cuda(), Wf.cuda(), bf.cuda(), cs.cuda(), stats, 1e-12, act)
+        finally:
+            lib.gitmi_debug_set_dgemm(0)
+        assert torch.equal(two, out_dev)
     if M > 64:               # row-walking kernel vs one-block kernel, folded LayerNorm included
         hi = min(M, 128)
         sub = E.op_dgemm(x[64:hi].bfloat16().contiguous().cuda(), Wf.cuda(), bf.cuda(), cs.cuda(),
