@@ -213,3 +213,26 @@ def test_bench_control_flow_all_schedules(monkeypatch, capsys):
         _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "7", "--coalesce", "2"])
     with pytest.raises(SystemExit):
         _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--decode-group", "3"])
+
+
+def test_bench_reads_the_pmc_summary_taken_for_this_csrc(tmp_path, monkeypatch):
+    """bench.pmc_profile: of several committed summaries the one whose `csrc_sha` header equals the tree's hash is read
+    (whatever its name sorts like) and reported fresh; with none matching, the last by name is read and reported stale."""
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    hdr = "kernel\tDISPATCHES\tHBM_BYTES\tMFMA_UTIL_PCT\tL2_HIT_PCT\n"
+
+    def write(name, sha, hbm):
+        (prof / name).write_text("# comment\n# csrc_sha=%s\n%svoid gitmi::gemm_p8_kernel<x>\t10\t%d\t30.5\t70\n"
+                                 "void gitmi::gemm_p8_kernel<y>\t30\t%d\t32.5\t74\nother_kernel\t5\t1\t-\t-\n" % (sha, hdr, hbm, 2 * hbm))
+    write("r03_final_pmc_summary.tsv", "aaaa", 100)
+    write("r03_zz_pmc_summary.tsv", "bbbb", 1000)              # sorts last by name
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_sha", lambda: "aaaa")
+    p = bench.pmc_profile({"gemm": "gemm_p8", "none": "no_such_kernel"})
+    assert p["source"].endswith("r03_final_pmc_summary.tsv") and p["stale"] is False and "none" not in p
+    assert p["gemm"]["hbm_bytes"] == round((10 * 100 + 30 * 200) / 40, 2) and p["gemm"]["mfma_util_pct"] == 32.0
+    monkeypatch.setattr(bench, "csrc_sha", lambda: "cccc")
+    p = bench.pmc_profile({"gemm": "gemm_p8"})
+    assert p["source"].endswith("r03_zz_pmc_summary.tsv") and p["stale"] is True and p["gemm"]["hbm_bytes"] == 1750.0
