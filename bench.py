@@ -311,6 +311,9 @@ def main(argv=None, engine_factory=None):
                          "first (at most --encoder-chains at a time), then its G decode chains side by side with no "
                          "encoder running (gitmi_generate_encode / gitmi_generate_decode); 0: every context submits "
                          "whole calls and the phases of different batches mix freely")
+    ap.add_argument("--experiment", action="store_true",
+                    help="A/B harness only: load libgitmi_exp.so (the bf16 build with -DGITMI_EXPERIMENT), whose engine reads "
+                         "kernel-shape overrides from GITMI_* environment variables; the line says so in config.library")
     ap.add_argument("--cpu-sweep", action="store_true",
                     help="only time the CPU port at several thread counts (median of 3, bs=8) and print JSON")
     args = ap.parse_args(argv)
@@ -348,6 +351,9 @@ def main(argv=None, engine_factory=None):
     from generativeimage2text_amd.engine import Engine
     from generativeimage2text_amd.synthetic import random_state_dict, random_frames
 
+    if args.experiment:
+        from generativeimage2text_amd.engine import use_experiment_build
+        use_experiment_build(True)
     cfg = config_for_model(args.model)
     beams = 1 if args.search == "greedy" else 4
     coalesce = max(1, args.coalesce)
@@ -571,6 +577,9 @@ def main(argv=None, engine_factory=None):
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "decode_steps_per_caption": steps_run, "seq_len_returned": info_h[0],
                        "hip_graph": not args.no_graph, "contexts_in_flight": len(ctxs),
+                       "library": ("libgitmi_exp.so (measurement build: " + " ".join(
+                           f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("GITMI_")) + ")") if args.experiment
+                       else {"bf16": "libgitmi.so", "f16": "libgitmi_f16.so"}.get(args.precision, "libgitmi.so"),
                        "shared_device_policy": bool(args.contexts > 1 and not args.solo_policy),
                        "encoder_chains": 0 if (args.free_run or len(ctxs) <= chains) else chains,
                        "schedule": (f"mixed, {coalesce} requests of {args.batch} images coalesced per engine pass" if coalesce > 1

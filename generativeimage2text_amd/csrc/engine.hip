@@ -141,12 +141,14 @@ struct gitmi_engine {
     int attn_dbg = 0, dgemm_dbg = 0;    // timing experiments (GITMI_ATTN_DBG, GITMI_DGEMM_DBG)
     int attn_pw = 0;                    // (sentence, head) pairs per workgroup of the decode attention (GITMI_ATTN_PW; 0 = by policy)
     int attn_nh = 0;                    // waves per (sentence, head) pair of the decode attention (GITMI_ATTN_NH: 1 / 2)
+    int attn_ppw = 0;                   // pairs a wave of the packed one-wave decode attention serves one after the other (0 = by policy)
     bool shared_device = false;         // gitmi_set_shared_device: other contexts run beside this one
     int dgemm_no_row_walk = -1;         // A/B (GITMI_DGEMM_NO_ROW_WALK=0|1; -1 = by policy)
-    int dgemm_two_strips = -1;          // A/B (GITMI_DGEMM_WIDE2=0|1; -1 = by policy)
+    int dgemm_strips = -1;              // 16-column strips per workgroup of the wide chain GEMMs at <= 64 rows (1, 2, 4, 6; -1 = by policy)
+    int vocab_wgs = -1;                 // workgroups of the vocabulary head (each walks ceil(239 / n) column blocks; 0 = one per block; -1 = by policy)
     int dgemm_rows = 0;                 // rows per workgroup of the N = 768 chain GEMMs (GITMI_DGEMM_ROWS: 16 / 32 / 64; 0 = by policy)
-    int decode_skip = 0;                // timing experiment (GITMI_DECODE_SKIP): launches of the decode chain left out --
-                                        // 1 attention, 2 QKV / FFN1 GEMMs, 4 out-proj / FFN2 GEMMs, 8 vocabulary head (ids are garbage)
+    int decode_skip = 0;                // MEASUREMENT BUILDS ONLY (GITMI_EXPERIMENT, GITMI_DECODE_SKIP): launches of the decode chain left
+                                        // out -- 1 attention, 2 QKV / FFN1 GEMMs, 4 out-proj / FFN2 GEMMs, 8 vocabulary head (ids are garbage)
     bool use_temb = true;               // add img_temperal_embedding[i] to frame i (the reference does so only for a LIST of frames)
     std::vector<int> plen_host, img_of_host;
     const float* const* frames_dummy = nullptr;
@@ -331,20 +333,26 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     e->max_pixels = std::max((size_t)c.image_size * c.image_size, (size_t)c.max_image_pixels);
     e->Kp = 3 * c.patch * c.patch;
     e->Kp_pad = round_up(e->Kp, 64);
+    e->stream_f16 = !e->f32;
+#ifdef GITMI_EXPERIMENT
+    // measurement builds only (libgitmi_exp.so, `make exp`): kernel-shape overrides and work-skipping switches for A/B runs
+    // and timing decompositions.  The product libraries read no environment.
     if (const char* env = getenv("GITMI_ATTN_IMPL")) e->attn_impl = e->f32 ? 0 : atoi(env);
     if (const char* env = getenv("GITMI_GRAPH")) e->use_graph = atoi(env) != 0;
     if (const char* env = getenv("GITMI_ATTN_DBG")) e->attn_dbg = atoi(env);
     if (const char* env = getenv("GITMI_ATTN_PW")) e->attn_pw = atoi(env);
     if (const char* env = getenv("GITMI_ATTN_NH")) e->attn_nh = atoi(env);
+    if (const char* env = getenv("GITMI_ATTN_PPW")) e->attn_ppw = atoi(env);
     if (const char* env = getenv("GITMI_DECODE_SKIP")) e->decode_skip = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_ROWS")) e->dgemm_rows = atoi(env);
-    if (const char* env = getenv("GITMI_DGEMM_WIDE2")) e->dgemm_two_strips = atoi(env);
+    if (const char* env = getenv("GITMI_DGEMM_STRIPS")) e->dgemm_strips = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_NO_ROW_WALK")) e->dgemm_no_row_walk = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_DBG")) e->dgemm_dbg = atoi(env);
+    if (const char* env = getenv("GITMI_VOCAB_WGS")) e->vocab_wgs = atoi(env);
     if (const char* env = getenv("GITMI_SKINNY")) e->skinny = atoi(env) != 0;
-    e->stream_f16 = !e->f32;
     if (const char* env = getenv("GITMI_STREAM_F16")) e->stream_f16 = !e->f32 && atoi(env) != 0;
     if (const char* env = getenv("GITMI_GEMM_IMPL")) set_gemm_impl(atoi(env));
+#endif
     if (attn_decode_configure() != hipSuccess) { delete e; return fail("hipFuncSetAttribute failed"); }
     *out = e;
     return 0;
@@ -793,8 +801,8 @@ static int clone_impl(gitmi_engine* src, int max_batch, gitmi_engine** out) {
     e->N_nat = e->N = src->N_nat; e->g_nat = e->gh = e->gw = src->g_nat; e->H = e->W = src->cfg.image_size;
     e->Nmax = src->Nmax; e->max_pixels = src->max_pixels;
     e->use_graph = src->use_graph; e->skinny = src->skinny; e->use_temb = src->use_temb;
-    e->attn_dbg = src->attn_dbg; e->dgemm_dbg = src->dgemm_dbg; e->attn_pw = src->attn_pw; e->attn_nh = src->attn_nh; e->decode_skip = src->decode_skip;
-    e->shared_device = src->shared_device; e->dgemm_rows = src->dgemm_rows; e->dgemm_two_strips = src->dgemm_two_strips; e->dgemm_no_row_walk = src->dgemm_no_row_walk;
+    e->attn_dbg = src->attn_dbg; e->dgemm_dbg = src->dgemm_dbg; e->attn_pw = src->attn_pw; e->attn_nh = src->attn_nh; e->attn_ppw = src->attn_ppw; e->decode_skip = src->decode_skip;
+    e->shared_device = src->shared_device; e->dgemm_rows = src->dgemm_rows; e->dgemm_strips = src->dgemm_strips; e->vocab_wgs = src->vocab_wgs; e->dgemm_no_row_walk = src->dgemm_no_row_walk;
     e->parent = src->parent ? src->parent : src;
     e->conv_w = src->conv_w; e->cls = src->cls; e->pos = src->pos; e->pos_cur = src->pos;
     e->lnpre_g = src->lnpre_g; e->lnpre_b = src->lnpre_b; e->lnpost_g = src->lnpost_g; e->lnpost_b = src->lnpost_b;
@@ -959,6 +967,13 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
     return 0;
 }
 
+// work-skipping for timing decompositions exists in measurement builds only: the product libraries cannot be told to
+// return wrong answers faster
+#ifdef GITMI_EXPERIMENT
+#define GITMI_SKIPPED(e, bit) (((e)->decode_skip & (bit)) != 0)
+#else
+#define GITMI_SKIPPED(e, bit) false
+#endif
 // ---- decode step ---------------------------------------------------------------------------------------
 // bf16: the folded-LayerNorm GEMM chain of kernels_dgemm.hip, 5 launches per layer
 //   QKV (LayerNorm of the previous layer folded) -> attention -> out-proj (+ residual, strip partials)
@@ -978,7 +993,7 @@ static int dgemm(gitmi_engine* e, hipStream_t s, const DGemmArgs& g_in) {
     // fragments in registers when other contexts share the device (beam-4: 7.18k -> 7.30k captions/s in the mixed schedule,
     // profiles/r03_zzz_ab_bench_lines.txt); alone, one workgroup per (strip, row block) is 3.5 us faster per launch
     g.no_row_walk = e->dgemm_no_row_walk >= 0 ? e->dgemm_no_row_walk : e->shared_device ? 0 : 1;
-    g.two_strips = e->dgemm_two_strips >= 0 ? e->dgemm_two_strips : e->shared_device ? 1 : 0;
+    g.strips_per_wg = e->dgemm_strips >= 0 ? e->dgemm_strips : e->shared_device ? 2 : 1;
     g.rows_per_wg = e->dgemm_rows > 0 ? e->dgemm_rows : (e->shared_device || g.M > 64) ? 64 : 16;
     SpanGuard sp(e, s, TAG_GEMM_OTHER, 2.0 * (double)g.M * (double)g.N * (double)g.K);
     HIPCK(launch_dgemm(g, s));
@@ -1002,7 +1017,7 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
             q.bias = L.bqkv_f;
             if (l > 0) { q.colsum = L.cs_qkv; q.stats_in = e->stats_o; q.strips_in = strips; q.inv_d = inv_d; q.eps_in = 1e-12f; }
             q.C = e->d_qkv; q.ldc = 3 * d; q.act = 0; q.M = R; q.N = 3 * d; q.K = d;
-            if (!(e->decode_skip & 2)) RCK(dgemm(e, s, q));
+            if (!GITMI_SKIPPED(e, 2)) RCK(dgemm(e, s, q));
         } else {
             RCK(gemm(e, s, e->d_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->d_qkv, 3 * d, e->f32, R, 3 * d, d, 0, TAG_GEMM_OTHER));
         }
@@ -1016,8 +1031,9 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
         a.dbg = e->attn_dbg;
         a.waves_per_pair = e->attn_nh;
         a.pairs_per_wg = e->attn_pw > 0 ? e->attn_pw : e->shared_device ? 8 : 4;
+        a.pairs_per_wave = e->attn_ppw > 0 ? e->attn_ppw : 1;
         if (e->f32) HIPCK(launch_attn_decode(a, B, c.dec_heads, true, s));
-        else if (!(e->decode_skip & 1)) HIPCK(launch_attn_decode_mfma(a, B, c.dec_heads, s));
+        else if (!GITMI_SKIPPED(e, 1)) HIPCK(launch_attn_decode_mfma(a, B, c.dec_heads, s));
         if (chain) {
             DGemmArgs o{};
             o.A = (const unsigned short*)e->d_ctx; o.lda = d; o.W = (const unsigned short*)L.wo_p; o.bias = L.bo;
@@ -1025,19 +1041,19 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
             if (l > 0) { o.res_stats = e->stats_o; o.res_strips = strips; o.res_gamma = Lp->lnog; o.res_beta = Lp->lnob; o.res_inv_d = inv_d; o.res_eps = 1e-12f; }
             o.x_out = e->xa_f; o.xb_out = (unsigned short*)e->xa_b; o.stats_out = e->stats_a;
             o.M = R; o.N = d; o.K = d;
-            if (!(e->decode_skip & 4)) RCK(dgemm(e, s, o));
+            if (!GITMI_SKIPPED(e, 4)) RCK(dgemm(e, s, o));
             DGemmArgs f1{};
             f1.A = (const unsigned short*)e->xa_b; f1.lda = d; f1.W = (const unsigned short*)L.w1_f; f1.bias = L.b1_f; f1.colsum = L.cs_1;
             f1.stats_in = e->stats_a; f1.strips_in = strips; f1.inv_d = inv_d; f1.eps_in = 1e-12f;
             f1.C = e->d_u; f1.ldc = ffn; f1.c_frag = 1; f1.act = 2; f1.M = R; f1.N = ffn; f1.K = d;
-            if (!(e->decode_skip & 2)) RCK(dgemm(e, s, f1));
+            if (!GITMI_SKIPPED(e, 2)) RCK(dgemm(e, s, f1));
             DGemmArgs f2{};
             f2.A = (const unsigned short*)e->d_u; f2.lda = ffn; f2.W = (const unsigned short*)L.w2_p; f2.bias = L.b2;
             f2.res_x = e->xa_f; f2.res_stats = e->stats_a; f2.res_strips = strips; f2.res_gamma = L.lnag; f2.res_beta = L.lnab;
             f2.res_inv_d = inv_d; f2.res_eps = 1e-12f;
             f2.x_out = e->xo_f; f2.xb_out = (unsigned short*)e->xo_b; f2.stats_out = e->stats_o;
             f2.M = R; f2.N = d; f2.K = ffn;
-            if (!(e->decode_skip & 4)) RCK(dgemm(e, s, f2));
+            if (!GITMI_SKIPPED(e, 4)) RCK(dgemm(e, s, f2));
         } else {
             RCK(gemm(e, s, e->d_ctx, d, L.wo, L.bo, e->d_hf, d, e->d_y, d, true, R, d, d, 0, TAG_GEMM_OTHER));
             HIPCK(launch_layernorm(e->d_y, d, L.lnag, L.lnab, 1e-12f, nullptr, e->d_ht, d, e->f32, e->d_hf, d, R, d, 0, 0, 0, s));
@@ -1074,13 +1090,18 @@ static int decode_head_impl(gitmi_engine* e, const int* ids, int ld_ids, int cur
         v.A = (const unsigned short*)e->xo_b; v.lda = d; v.W = (const unsigned short*)e->out_w_f; v.bias = e->out_b_f; v.colsum = e->cs_out;
         v.stats_in = e->stats_o; v.strips_in = d / 16; v.inv_d = 1.0f / (float)d; v.eps_in = 1e-12f;
         v.M = R; v.N = c.vocab; v.K = d; v.cols_per_wg = e->vocab_cols;
+        // workgroups of the head: by default one per column block (one HBM round trip; fastest alone); when other contexts
+        // share the device, ~60 workgroups that each WALK four column blocks with a rolling weight refill -- the launch is
+        // bound by the chip's HBM rate either way, and every CU that holds one of its waves is closed to the image encoder's
+        // GEMM workgroups for the whole launch
+        v.max_wgs = e->vocab_wgs >= 0 ? e->vocab_wgs : e->shared_device ? 60 : 0;
         v.ids = ids; v.ld_ids = ld_ids; v.cur_len = cur_len; v.plen = e->plen_dev; v.beams = beams; v.suppress_kind = suppress_kind;
         v.rep_penalty = ids ? rep_penalty_of(e) : 0.f;
         v.part_val = e->part_val; v.part_idx = e->part_idx; v.part_lse = e->part_lse;
         v.logits_out = logits_out; v.ld_logits = ldl;
         {
             SpanGuard sp(e, s, TAG_GEMM_OTHER, 2.0 * (double)R * (double)c.vocab * (double)d);
-            if (!(e->decode_skip & 8)) HIPCK(launch_vocab_topm(v, M, s));
+            if (!GITMI_SKIPPED(e, 8)) HIPCK(launch_vocab_topm(v, M, s));
         }
         cands->nparts = e->vocab_nparts; cands->slots = vocab_mtop_slots(M);
         if (sampling) RCK(sample_candidates(e, logits_out, ldl, R, cur_len, s, cands));
@@ -1860,12 +1881,18 @@ extern "C" int gitmi_op_attention(const void* qkv, void* out, int B, int N, int 
 }
 
 // ---- decode-chain kernels (kernels_dgemm.hip), one launch each -----------------------------------------------
+#ifdef GITMI_EXPERIMENT
 static int g_dgemm_dbg = 0;
-extern "C" int gitmi_debug_set_dgemm(int dbg) { g_dgemm_dbg = dbg; return 0; }
+extern "C" int gitmi_debug_set_dgemm(int dbg) { g_dgemm_dbg = dbg; return 0; }      // timing bits of kernels_dgemm.hip
+#else
+static const int g_dgemm_dbg = 0;
+#endif
 extern "C" int gitmi_op_dgemm(const void* A, const void* W, const float* bias, const float* colsum, const float* stats,
-                              int strips, float eps, void* C, int c_frag, int M, int N, int K, int act, void* stream) {
+                              int strips, float eps, void* C, int c_frag, int M, int N, int K, int act, int strips_per_wg,
+                              void* stream) {
     DGemmArgs g{};
     g.dbg = g_dgemm_dbg;
+    g.strips_per_wg = strips_per_wg;
     g.c_frag = c_frag;
     if (c_frag && N % 32) return fail("op_dgemm: a fragment-major output needs N %% 32 == 0");
     g.A = (const unsigned short*)A; g.lda = K; g.W = (const unsigned short*)W; g.bias = bias;
@@ -1892,12 +1919,13 @@ extern "C" int gitmi_op_dgemm_res(const void* A, const void* W, const float* bia
 extern "C" int gitmi_op_vocab_topm(const void* A, const void* W, const float* bias, const float* colsum, const float* stats,
                                    int strips, float eps, int M, int V, int K, int cols_per_wg, int mtop,
                                    const int* suppress_tok, float* part_val, int* part_idx, float* part_lse,
-                                   float* logits_out, void* stream) {
+                                   float* logits_out, int max_wgs, void* stream) {
     VocabArgs v{};
+    v.max_wgs = max_wgs;
     v.A = (const unsigned short*)A; v.lda = K; v.W = (const unsigned short*)W; v.bias = bias;
     if (stats) { v.colsum = colsum; v.stats_in = (const float2*)stats; v.strips_in = strips; v.inv_d = 1.0f / (float)K; v.eps_in = eps; }
     v.M = M; v.N = V; v.K = K; v.cols_per_wg = cols_per_wg;
-    if (cols_per_wg != 64 && cols_per_wg != 128) return fail("op_vocab_topm: cols_per_wg must be 64 or 128");
+    if (cols_per_wg != 128) return fail("op_vocab_topm: cols_per_wg must be 128");
     // the rule is driven through the search tables in the engine; the unit entry point takes one token per row
     // (ids [M][1], cur_len 1, prefix length 0 => "past the first step")
     static int* zero_plen = nullptr;

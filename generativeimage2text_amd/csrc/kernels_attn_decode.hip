@@ -79,7 +79,10 @@ constexpr int ACS = 4;          // key steps per chunk and wave
 // packs the one-wave kernel (launch_attn_decode_mfma).
 // NH: waves per pair.  2 = the two waves of a head split its key steps (one memory round trip each); 1 = ONE wave walks
 // all key steps in chunks of ACS (two round trips at 197 image keys): half the resident waves for ~1.3x the time.
-template <int KB, int TI = 3, int PW = 1, int NH = 2>
+// LOOP (packed one-wave form only): a wave serves a.pairs_per_wave pairs one after the other, the next pair's first K/V
+// chunk requested while the current pair's merge and output are worked off.  A separate instantiation: the loop-carried
+// K/V registers cost the 512-thread form a few spilled registers, which the single-pair form must not pay.
+template <int KB, int TI = 3, int PW = 1, int NH = 2, bool LOOP = false>
 __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDecodeArgs a) {
     __shared__ float part[PW][NH][KB][HD + 2];    // [pair][half][beam]: o[64], m, l
     constexpr int PT = 64 * NH;                   // threads of a pair
@@ -88,47 +91,67 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
     const int l15 = lane & 15, lg = lane >> 4;
     const int hp = wave / NH, half = wave % NH;    // pair of the workgroup, half of the head's keys
     const int H = a.d / HD;
-    const int pair = PW == 1 ? (int)(blockIdx.y * H + blockIdx.x) : (int)blockIdx.x * PW + hp;
-    const bool head_on = PW == 1 || pair < a.n_pairs;
-    const int h = head_on ? pair % H : 0, b = head_on ? pair / H : 0;
     const int k = a.beams;                       // k <= KB <= 8 < 16 MFMA rows
     const bf16_t* QKV = reinterpret_cast<const bf16_t*>(a.qkv);
     bf16_t* TK = reinterpret_cast<bf16_t*>(a.txt_k);
     bf16_t* TV = reinterpret_cast<bf16_t*>(a.txt_v);
     bf16_t* O = reinterpret_cast<bf16_t*>(a.out);
     const int ld3 = 3 * a.d;
-    const int row0 = b * k;
-    const int bi = a.img_of ? a.img_of[b] : b;   // sentence -> image (several questions per image)
     const int Np = a.N_pad, nsteps = Np >> 5;
-    const int hh = head_on ? h : 0;
-    const bf16_t* Kf = reinterpret_cast<const bf16_t*>(a.img_k) + ((size_t)bi * H + hh) * Np * HD;
-    const bf16_t* Vt = reinterpret_cast<const bf16_t*>(a.img_v) + ((size_t)bi * H + hh) * Np * HD;
+    // a wave serves `reps` pairs one after the other (launcher: 1 unless the one-wave kernel is packed further): pair index
+    // of repetition r.  PW == 1 keeps the (head, sentence) grid of the two-wave kernel.
+    const int reps = LOOP ? a.pairs_per_wave : 1;
+    auto pair_of = [&](int r) {
+        if constexpr (NH == 2) return (int)(blockIdx.y * H + blockIdx.x);      // grid = (H, sentences)
+        else return ((int)blockIdx.x * reps + r) * PW + hp;
+    };
+    struct PairKV { const bf16_t* Kf; const bf16_t* Vt; int nimg_steps; };
+    auto kv_of = [&](int pair) {
+        const bool on = PW == 1 || pair < a.n_pairs;
+        const int h = on ? pair % H : 0, b = on ? pair / H : 0;
+        const int bi = a.img_of ? a.img_of[b] : b;   // sentence -> image (several questions per image)
+        PairKV r;
+        r.Kf = reinterpret_cast<const bf16_t*>(a.img_k) + ((size_t)bi * H + h) * Np * HD;
+        r.Vt = reinterpret_cast<const bf16_t*>(a.img_v) + ((size_t)bi * H + h) * Np * HD;
+        r.nimg_steps = (!on || (a.dbg & 1)) ? 0 : nsteps;
+        return r;
+    };
 
-    // ---- image K/V of this wave's first chunk: requested before anything else (the longest latency) ---------------
-    const int nimg_steps = (!head_on || (a.dbg & 1)) ? 0 : nsteps;
+    // ---- image K/V of a chunk of key steps: requested before anything else (the longest latency) ---------------
     bf16x8_t kq[ACS][2][2], vq[ACS][4];
-    auto load_chunk = [&](int s0) {              // steps s0, s0 + NH, ... (this half's parity)
+    auto load_chunk = [&](const PairKV& p, int s0) {              // steps s0, s0 + NH, ... (this half's parity)
 #pragma unroll
         for (int c = 0; c < ACS; ++c) {
             const int s = s0 + NH * c;
-            const bool on = s < nimg_steps && !(a.dbg & 8);
-            const bf16_t* kp = Kf + frag_tile(2 * s, 0, 2, lane);            // the step's 4 KiB of K, then of V^T: contiguous
-            const bf16_t* vp = Vt + ((size_t)s * 4 * 64 + lane) * 8;
+            const bool on = s < p.nimg_steps && !(a.dbg & 8);
+            const bf16_t* kp = p.Kf + frag_tile(2 * s, 0, 2, lane);            // the step's 4 KiB of K, then of V^T: contiguous
+            const bf16_t* vp = p.Vt + ((size_t)s * 4 * 64 + lane) * 8;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int ds = 0; ds < 2; ++ds) {
-                    const bf16x8_t* p = reinterpret_cast<const bf16x8_t*>(kp + (t * 2 + ds) * 512);
-                    kq[c][t][ds] = !on ? bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0} : (a.dbg & 16) ? *p : __builtin_nontemporal_load(p);
+                    const bf16x8_t* q = reinterpret_cast<const bf16x8_t*>(kp + (t * 2 + ds) * 512);
+                    kq[c][t][ds] = !on ? bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0} : (a.dbg & 16) ? *q : __builtin_nontemporal_load(q);
                 }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8_t* p = reinterpret_cast<const bf16x8_t*>(vp + dt * 512);
-                vq[c][dt] = !on ? bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0} : (a.dbg & 16) ? *p : __builtin_nontemporal_load(p);
+                const bf16x8_t* q = reinterpret_cast<const bf16x8_t*>(vp + dt * 512);
+                vq[c][dt] = !on ? bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0} : (a.dbg & 16) ? *q : __builtin_nontemporal_load(q);
             }
         }
     };
-    load_chunk(half);
+    PairKV cur = kv_of(pair_of(0));
+    load_chunk(cur, half);
+
+  for (int rep = 0; rep < reps; ++rep) {
+    const int pair = pair_of(rep);
+    const bool head_on = PW == 1 || pair < a.n_pairs;
+    const int h = head_on ? pair % H : 0, b = head_on ? pair / H : 0;
+    const int row0 = b * k;
+    const int nimg_steps = cur.nimg_steps;
+    if constexpr (LOOP) {
+        if (rep > 0 && (a.dbg & 32)) load_chunk(cur, half);
+    }
 
     // ---- text items: the 16 eight-lane groups of the head's two waves share them ----------------------------------
     const int grp = (tid % PT) >> 3, sub = tid & 7;      // 8 * NH eight-lane groups per pair
@@ -183,7 +206,7 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
     for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     for (int s0 = half; s0 < nimg_steps; s0 += NH * ACS) {
-        if (s0 != half) load_chunk(s0);                    // later chunks (long image sequences: video, VQA resolutions)
+        if (s0 != half) load_chunk(cur, s0);               // later chunks (long image sequences: video, VQA resolutions)
         // every score tile of the chunk: lane (row l15, lg) holds keys 32s + t*16 + lg*4 + r
         f32x4_t sc[ACS][2];
         float cm = -INFINITY;
@@ -239,7 +262,6 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
     }
     l_i += __shfl_xor(l_i, 16, 64);
     l_i += __shfl_xor(l_i, 32, 64);
-
     // ---- text keys (beam-specific): 8 lanes per key, online update -------------------------------------------------
     float q[KB][8], m[KB], l[KB], o[KB][8];
 #pragma unroll
@@ -308,6 +330,14 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
             text_item(j, kv, vv);
         }
     }
+    // the K/V registers (and the text items) are free: the first chunk of the wave's NEXT pair travels while this pair's
+    // merge and output are worked off (requested any earlier -- behind the image part -- the 512-thread form spills)
+    if constexpr (LOOP) {
+        if (rep + 1 < reps) {
+            cur = kv_of(pair_of(rep + 1));
+            if (!(a.dbg & 32)) load_chunk(cur, half);      // dbg 32 (A/B): no look-ahead, the chunk is requested at the top of the pair
+        }
+    }
     // merge the 8 groups of the wave (lanes with equal `sub`): lanes 0..7 end up with the wave's text partial (m, l, o[8])
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
@@ -336,7 +366,9 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
             for (int r = 0; r < 4; ++r) part[hp][half][l15][dt * 16 + lg * 4 + r] = oacc[dt][r];
         if (lg == 0) { part[hp][half][l15][HD] = m_i; part[hp][half][l15][HD + 1] = l_i; }
     }
-    __syncthreads();
+    // NH == 1: a wave reads back only what it wrote itself (LDS operations of a wave complete in order): no workgroup barrier
+    // -- a __syncthreads() here would also wait for the next pair's K/V loads
+    if constexpr (NH > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
     // fold the text partial of this wave into its slot (lanes 0..7, one beam row at a time), then combine the halves
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
@@ -350,8 +382,8 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
             if (sub == 0) { part[hp][half][j][HD] = mn; part[hp][half][j][HD + 1] = li * a1 + l[j] * a2; }
         }
     }
-    __syncthreads();
-    if (!head_on) return;
+    if constexpr (NH > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    if (head_on)
     for (int i = tid % PT; i < k * HD; i += PT) {
         const int j = i / HD, dd = i % HD;
         if constexpr (NH == 1) {
@@ -371,6 +403,8 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
         if (a.out_frag) O[frag_offset(row0 + j, h * HD + dd, a.d >> 5)] = f2bf(r);
         else O[(size_t)(row0 + j) * a.d + h * HD + dd] = f2bf(r);
     }
+    if constexpr (NH == 1) __builtin_amdgcn_wave_barrier();      // the next pair reuses this wave's LDS slot
+  }
 }
 
 // ---- host launchers ------------------------------------------------------------------
@@ -410,9 +444,16 @@ hipError_t launch_attn_decode_mfma(const AttnDecodeArgs& a, int B, int H, hipStr
     // never fewer than 96 workgroups: a small batch packed onto a handful of CUs streams its K/V through too few of them
     int pw = a.pairs_per_wg >= 8 ? 8 : a.pairs_per_wg >= 4 || a.pairs_per_wg <= 0 ? 4 : a.pairs_per_wg >= 2 ? 2 : 1;
     while (pw > 1 && p.n_pairs / pw < 96) pw >>= 1;
+    // pairs per WAVE (one after the other, the same per-pair arithmetic): only on top of full workgroups, and never fewer
+    // than 24 workgroups
+    int ppw = pw == 8 && a.pairs_per_wave > 1 ? a.pairs_per_wave : 1;
+    while (ppw > 1 && p.n_pairs / (pw * ppw) < 24) --ppw;
+    p.pairs_per_wave = ppw;
+    const int per_wg = pw * ppw;
 #define GITMI_ATTN1(KBV)                                                                                                   \
     do {                                                                                                                   \
-        if (pw == 8) hipLaunchKernelGGL((attn_decode_mfma_kernel<KBV, 3, 8, 1>), dim3((p.n_pairs + 7) / 8), dim3(512), 0, s, p);      \
+        if (pw == 8 && ppw > 1) hipLaunchKernelGGL((attn_decode_mfma_kernel<KBV, 3, 8, 1, true>), dim3((p.n_pairs + per_wg - 1) / per_wg), dim3(512), 0, s, p); \
+        else if (pw == 8) hipLaunchKernelGGL((attn_decode_mfma_kernel<KBV, 3, 8, 1>), dim3((p.n_pairs + 7) / 8), dim3(512), 0, s, p); \
         else if (pw == 4) hipLaunchKernelGGL((attn_decode_mfma_kernel<KBV, 3, 4, 1>), dim3((p.n_pairs + 3) / 4), dim3(256), 0, s, p); \
         else if (pw == 2) hipLaunchKernelGGL((attn_decode_mfma_kernel<KBV, 3, 2, 1>), dim3((p.n_pairs + 1) / 2), dim3(128), 0, s, p); \
         else hipLaunchKernelGGL((attn_decode_mfma_kernel<KBV, 3, 1, 1>), dim3(p.n_pairs), dim3(64), 0, s, p);                         \
@@ -420,7 +461,7 @@ hipError_t launch_attn_decode_mfma(const AttnDecodeArgs& a, int B, int H, hipStr
     if (a.beams <= 1) GITMI_ATTN1(1);
     else if (a.beams <= 2) GITMI_ATTN1(2);
     else if (a.beams <= 4) GITMI_ATTN1(4);
-    else { if (pw == 8) pw = 4; GITMI_ATTN1(8); }       // 8 beams: 269 registers, one wave per SIMD: 4 pairs fill a CU
+    else { if (pw == 8) { pw = 4; ppw = 1; p.pairs_per_wave = 1; } GITMI_ATTN1(8); }       // 8 beams: 269 registers, one wave per SIMD: 4 pairs fill a CU
 #undef GITMI_ATTN1
     return hipGetLastError();
 }

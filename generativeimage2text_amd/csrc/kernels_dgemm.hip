@@ -33,6 +33,7 @@
 #include "gitmi_common.h"
 #include "launchers.h"
 #include <type_traits>
+#include <utility>
 
 namespace gitmi {
 
@@ -50,6 +51,16 @@ __device__ __forceinline__ void stats_issue(RowStatLoads& L, const float2* __res
     for (int u = 0; u < STRIP_SLOTS; ++u) {
         const int sidx = lg + 4 * u;
         L.v[u] = sidx < strips ? stats[(size_t)sidx * M + row] : float2{0.f, 0.f};
+    }
+}
+// branch-free form (clamped strip index, zero-selected): no control flow around the loads
+__device__ __forceinline__ void stats_issue_nb(RowStatLoads& L, const float2* __restrict__ stats, int strips, int M,
+                                               int row, int lg) {
+#pragma unroll
+    for (int u = 0; u < STRIP_SLOTS; ++u) {
+        const int sidx = lg + 4 * u;
+        const float2 v = stats[(size_t)min(sidx, strips - 1) * M + row];
+        L.v[u] = sidx < strips ? v : float2{0.f, 0.f};
     }
 }
 __device__ __forceinline__ void stats_finish(const RowStatLoads& L, float inv_d, float eps, float& mean, float& rstd) {
@@ -350,14 +361,15 @@ __global__ __launch_bounds__(256) void dgemm_wide_rows_kernel(DGemmArgs g) {
     }
 }
 
-// ---- wide form, <= 64 rows, TWO adjacent 16-column strips per workgroup ---------------------------------------------
-// grid = (ceil(N/32), 1); block = 256.  Per element the arithmetic of dgemm_kernel<4, 4, DEPI_BF16> (K split over 4 waves,
-// partials summed in wave order): bit-identical results.  The four waves load the activation fragments of their K slice
-// ONCE and the weight fragments of both strips up front (one memory round trip, as before), then run the two strips
-// back to back: half the workgroups / resident waves and half the activation traffic for ~1 us more per launch -- what
-// a decode launch costs the image encoders running beside it is its resident waves x time.
-__global__ __launch_bounds__(256) void dgemm_wide2_kernel(DGemmArgs g) {
-    __shared__ __attribute__((aligned(16))) f32x4_t red[2][4][4][64];      // [strip][wave][row tile][lane]
+// ---- wide form, <= 64 rows, NST adjacent 16-column strips per workgroup ----------------------------------------------
+// grid = (ceil(strips / NST), 1); block = 256.  Per element the arithmetic of dgemm_kernel<4, 4, DEPI_BF16> (K split over 4
+// waves, partials summed in wave order): bit-identical results.  The four waves load the activation fragments of their K
+// slice ONCE and the weight fragments of all NST strips up front (one memory round trip, as before), then run the strips
+// back to back: 1/NST of the workgroups / resident waves and of the activation traffic for ~1 us more per extra strip --
+// what a decode launch costs the image encoders running beside it is its resident waves x time.
+template <int NST>
+__global__ __launch_bounds__(256) void dgemm_wide_strips_kernel(DGemmArgs g) {
+    __shared__ __attribute__((aligned(16))) f32x4_t red[NST][4][4][64];      // [strip][wave][row tile][lane]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -379,11 +391,11 @@ __global__ __launch_bounds__(256) void dgemm_wide2_kernel(DGemmArgs g) {
     };
     RowStatLoads sl;
     if (g.stats_in) stats_issue(sl, g.stats_in, g.strips_in, g.M, fm, lg);
-    float4 bias4[2], cs4[2];
-    bf16x8_t wf[2][DW_KS];
+    float4 bias4[NST], cs4[NST];
+    bf16x8_t wf[NST][DW_KS];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int strip = min((int)blockIdx.x * 2 + t, nstrips - 1);
+    for (int t = 0; t < NST; ++t) {
+        const int strip = min((int)blockIdx.x * NST + t, nstrips - 1);
         const int fn = strip * 16 + lg * 4;
         bias4[t] = ld4(g.bias, fn);
         cs4[t] = g.stats_in ? ld4(g.colsum, fn) : float4{0.f, 0.f, 0.f, 0.f};
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(256) void dgemm_wide2_kernel(DGemmArgs g) {
             xf[u][i] = kb + u < ke ? *reinterpret_cast<const bf16x8_t*>(X + frag_tile(i, kb + u, ksteps, lane))
                                    : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NST; ++t) {
         f32x4_t acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -419,8 +431,8 @@ __global__ __launch_bounds__(256) void dgemm_wide2_kernel(DGemmArgs g) {
     float mean = 0.f, rstd = 1.f;
     if (g.stats_in) stats_finish(sl, g.inv_d, g.eps_in, mean, rstd);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int strip = (int)blockIdx.x * 2 + t;
+    for (int t = 0; t < NST; ++t) {
+        const int strip = (int)blockIdx.x * NST + t;
         if (strip >= nstrips) break;
         const int fn = strip * 16 + lg * 4;
         f32x4_t tot = {0.f, 0.f, 0.f, 0.f};
@@ -465,168 +477,253 @@ __global__ __launch_bounds__(256) void dgemm_wide2_kernel(DGemmArgs g) {
 }
 
 // ---- vocabulary head + running top-M / log-sum-exp ---------------------------------------------------------
-// grid = (ceil(V / (16*NS)), ceil(M/(16*MT))); block = 256 (K split over 4 waves, K <= 768).
-// A workgroup owns NS 16-column strips.  EVERY weight fragment of its strips is requested before the first MFMA
-// (NS*VKS 16-byte loads per lane = up to 96 KiB in flight per workgroup): the kernel is one HBM round trip, then NS
-// short compute/exchange rounds -- with a strip-at-a-time prefetch the same sweep waited one memory latency per strip
-// (24.7 us at 128 columns; profiles/r02_a_decode_kernel_ablation.txt).
+// grid = min(column blocks, max_wgs); block = 256 (K split over 4 waves, K <= 768).  A column block = NS 16-column strips.
+// A workgroup WALKS its column blocks (block b, b + gridDim.x, ...) with every weight fragment of a block in registers
+// (NS*VKS 16-byte loads per lane = up to 96 KiB per workgroup): as soon as the last row block has consumed strip st of the
+// current column block, the registers of that strip are refilled with strip st of the NEXT block, so a workgroup always has
+// a whole block of weights in flight and never waits a full memory latency after its first block.  Why walk: with one
+// workgroup per column block (round 3: 239 workgroups, one HBM round trip, 21 us) the launch is bound by the chip's HBM
+// rate while EVERY CU that holds one of its 256-register waves is closed to the image encoder's GEMM workgroups for the
+// whole 21 us; ~60 walking workgroups stream the same 47 MB at the same rate and leave the other CUs alone.  Results do
+// not depend on the grid: a (row, column block) pair produces the same candidate list whichever workgroup computes it.
 constexpr int VKS = 6;      // k-steps of 32 per wave held in registers
+constexpr int VOC_NS = 8;   // 16-column strips per column block
+constexpr int VOC_MAX_BLOCKS = 8;      // column blocks a workgroup may walk (bias / colsum of all of them sit in LDS)
 
-template <int MT, int MTOP, int NS>
+// Orders this workgroup's LDS traffic only.  __syncthreads() also fences global memory: with the refill loads of the next
+// column block in flight that would be an s_waitcnt vmcnt(0) per strip -- one memory latency per strip instead of none.
+#define VOC_LDS_BARRIER()                                  \
+    do {                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier();                      \
+        asm volatile("" ::: "memory");                     \
+    } while (0)
+
+// MT = 4 row tiles (64 rows, the padding of every activation buffer) per row block and NS = 8 strips (128 columns) per
+// column block are fixed.  MODE selects what the column-block loop may contain:
+//   VOC_GREEDY  one row block (<= 64 rows), K = 768, no logits output, no repetition penalty: activations and row
+//               statistics stay in registers, the candidate lists are parked in LDS until the walk is over, and the loop
+//               contains NOTHING but MFMAs, the LDS exchange and the rolling refill.  On gfx9 loads and stores share
+//               `vmcnt` and complete out of order with respect to each other, so a single global store inside the loop
+//               (or a branch around a load) turns every counted `s_waitcnt vmcnt(42)` into `vmcnt(0)` -- one exposed
+//               memory latency per strip.
+//   VOC_BEAM    several row blocks, K = 768: the rows' activations are re-read (from the L2) per (column block, row
+//               block), which drains the queue once per row block anyway; the refill runs behind the last row block.
+//   VOC_GENERIC any K <= 768, logits output, repetition penalty: conditional loads, stores in the loop.
+enum { VOC_GENERIC = 0, VOC_BEAM = 1, VOC_GREEDY = 2 };
+
+// f(integral_constant<int, I>) for I = B .. N-1, fully unrolled with I a compile-time constant in the body
+template <int B, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < N) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, N>(f);
+    }
+}
+
+template <int MTOP, int MODE>
 __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
-    __shared__ __attribute__((aligned(16))) f32x4_t red[2][4][MT][64];     // double-buffered exchange: one barrier per strip
+    constexpr int MT = 4, NS = VOC_NS;
+    constexpr bool FULLK = MODE != VOC_GENERIC, ONE_RB = MODE == VOC_GREEDY, PARK = MODE == VOC_GREEDY;
+    // ONE LDS object (a second __shared__ array makes hipcc drain the vector-memory queue before LDS reads): the exchange
+    // buffers (double-buffered: one barrier per strip), bias / column sum of every column this workgroup walks, and
+    // (VOC_GREEDY) the parked candidate lists [walked block][row][2 + 2*MTOP]
+    constexpr int RED_F4 = 2 * 4 * MT * 64;
+    constexpr int COLC_F = VOC_MAX_BLOCKS * 16 * NS * 2;
+    constexpr int OUT_W = 2 + 2 * MTOP;
+    constexpr int PARK_F = PARK ? VOC_MAX_BLOCKS * 64 * OUT_W : 0;
+    __shared__ __attribute__((aligned(16))) f32x4_t smem[RED_F4 + (COLC_F + PARK_F) / 4];
+    f32x4_t(*red)[4][MT][64] = reinterpret_cast<f32x4_t(*)[4][MT][64]>(smem);
+    float* colc = reinterpret_cast<float*>(smem + RED_F4);   // [walked block][0: bias, 1: colsum][16*NS]
+    float* park = colc + COLC_F;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int c0 = blockIdx.x * (16 * NS);
-    const int ncols = max(0, min(16 * NS, g.N - c0));
-    const int nstrips = (ncols + 15) / 16;
-    const bool finisher = wave < MT;
     const bool fold = g.stats_in != nullptr;
+    const int nblk = g.nblk;                                 // column blocks of 16*NS columns (launcher)
+    // bias and colsum are padded to a multiple of 16*NS entries; a workgroup walks <= VOC_MAX_BLOCKS blocks (launcher)
+    for (int i = tid; i < VOC_MAX_BLOCKS * 16 * NS; i += 256) {
+        const int w = i / (16 * NS), c = i % (16 * NS);
+        const int blk = (int)blockIdx.x + w * (int)gridDim.x;
+        if (blk < nblk) {
+            colc[(w * 2 + 0) * (16 * NS) + c] = g.bias[blk * (16 * NS) + c];
+            colc[(w * 2 + 1) * (16 * NS) + c] = fold ? g.colsum[blk * (16 * NS) + c] : 0.f;
+        }
+    }
 
-    // ---- every weight fragment of this wave's K range, requested up front; they stay in registers for EVERY block of
-    // 16*MT rows the workgroup walks (gridDim.y = 1 for beam batches: 256 rows = four row blocks used to be four workgroups
-    // per column slice, each streaming the same 196 KB of weights again -- 92 us instead of 21 for the 64-row batch)
     const int ksteps = g.K >> 5;
     const int per = (ksteps + 3) / 4;
     const int kb = wave * per;
-    const int ks = max(0, min(kb + per, ksteps) - kb);        // <= VKS (checked by the launcher)
-    const int tile0 = c0 >> 4;                              // first 16-column tile of this workgroup
+    const int ks = max(0, min(kb + per, ksteps) - kb);        // <= VKS (checked by the launcher); == VKS when FULLK
+
+    // weight fragments of this wave's K range, one column block.  The packed matrix is zero-padded to a multiple of 128
+    // rows (fold_layernorm / gitmi_op_vocab_topm): every strip of every column block is readable.
     bf16x8_t wf[NS][VKS];
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
-        const bf16_t* wp = g.W + frag_tile(tile0 + st, kb, ksteps, lane);        // rows >= N are zero in the packed matrix
+    const bf16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto fill_strip = [&](auto stc, int blk) {                // strip st of column block blk < nblk
+        constexpr int st = decltype(stc)::value;
+        const bf16_t* wp = g.W + frag_tile(blk * NS + st, kb, ksteps, lane);
 #pragma unroll
         for (int u = 0; u < VKS; ++u) {
-            if (u < ks && st < nstrips) wf[st][u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)u * 512));
-            else wf[st][u] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            if (FULLK || u < ks) wf[st][u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)u * 512));
+            else wf[st][u] = zero8;
         }
-    }
-    // bias / column sums of the columns this lane finishes (bias and colsum are padded to a multiple of 16*NS entries)
-    float4 eb[NS], ec[NS];
-    if (finisher) {
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            const int n = c0 + st * 16 + lg * 4;
-            eb[st] = *reinterpret_cast<const float4*>(g.bias + n);
-            ec[st] = fold ? *reinterpret_cast<const float4*>(g.colsum + n) : float4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
+    };
+    auto for_strips = [&](auto&& f) { static_for<0, NS>(f); };
+    for_strips([&](auto stc) { fill_strip(stc, (int)blockIdx.x); });
 
-    const int nrb = (g.M + 16 * MT - 1) / (16 * MT);
-    for (int rb = blockIdx.y; rb < nrb; rb += gridDim.y) {
-        const int m0 = rb * (16 * MT);
-        const int fm_raw = m0 + wave * 16 + l15;
+    const int nrb = ONE_RB ? 1 : (g.M + 16 * MT - 1) / (16 * MT);
+    bf16x8_t xf[VKS][MT];
+    float mean = 0.f, rstd = 1.f;
+    int last_tok = -1;
+    auto load_rows = [&](int rb) {            // everything that depends on the row block only (wave i finishes row tile i)
+        const int fm_raw = rb * (16 * MT) + wave * 16 + l15;
         const int fm = fm_raw < g.M ? fm_raw : g.M - 1;
-
         RowStatLoads sl;
-        int last_tok = -1;
-        if (finisher) {
-            if (fold) stats_issue(sl, g.stats_in, g.strips_in, g.M, fm, lg);
-            if (g.ids) {
-                const int sent = fm / g.beams;
-                const bool suppress = g.suppress_kind && g.cur_len > g.plen[sent];      // decoder.py:330 (not on a sentence's first step)
-                if (suppress) last_tok = g.ids[(size_t)fm * g.ld_ids + g.cur_len - 1];
-            }
+        last_tok = -1;
+        if (fold) stats_issue_nb(sl, g.stats_in, g.strips_in, g.M, fm, lg);
+        if (g.ids) {
+            const int sent = fm / g.beams;
+            const bool suppress = g.suppress_kind && g.cur_len > g.plen[sent];      // decoder.py:330 (not on a sentence's first step)
+            if (suppress) last_tok = g.ids[(size_t)fm * g.ld_ids + g.cur_len - 1];
         }
-        // repetition penalty: which of this lane's columns (bit st*4 + r <-> column c0 + st*16 + lg*4 + r) are in the row's history
-        unsigned int pen_mask = 0u;
-        const bool pen = g.ids != nullptr && g.rep_penalty != 0.f && g.rep_penalty != 1.f;
-        if (finisher && pen) {
-            for (int s = 0; s < g.cur_len; ++s) {
-                const int rel = g.ids[(size_t)fm * g.ld_ids + s] - c0;
-                if (rel >= 0 && rel < 16 * NS && ((rel >> 2) & 3) == lg) pen_mask |= 1u << ((rel >> 4) * 4 + (rel & 3));
-            }
-        }
-
-        // ---- activation fragments of this row block (this wave's K range)
-        bf16x8_t xf[VKS][MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const bf16_t* xp = g.A + frag_tile(rb * MT + i, kb, ksteps, lane);
 #pragma unroll
             for (int u = 0; u < VKS; ++u) {
-                if (u < ks) xf[u][i] = *reinterpret_cast<const bf16x8_t*>(xp + (size_t)u * 512);
-                else xf[u][i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                if (FULLK || u < ks) xf[u][i] = *reinterpret_cast<const bf16x8_t*>(xp + (size_t)u * 512);
+                else xf[u][i] = zero8;
             }
         }
+        mean = 0.f; rstd = 1.f;
+        if (fold) stats_finish(sl, g.inv_d, g.eps_in, mean, rstd);
+    };
+    if constexpr (ONE_RB) {
+        load_rows(0);
+        // The compiler must KNOW these loads have landed before the loop: its wait counts at the top of the loop body are
+        // computed for the merged (entry + back edge) state, and with the activation loads -- the youngest of the prologue
+        // -- still pending there, the first strip of EVERY column block would wait for (almost) all 48 refill loads.
+#pragma unroll
+        for (int u = 0; u < VKS; ++u)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(xf[u][i]));
+    }
 
-        // running per-lane state of the finisher: sorted top-MTOP of its 4 columns per strip, online log-sum-exp
-        float tv[MTOP];
-        int ti[MTOP];
+    const bool pen = MODE == VOC_GENERIC && g.ids != nullptr && g.rep_penalty != 0.f && g.rep_penalty != 1.f;
+    int xbuf = 0;      // exchange buffer of the next strip: alternates across row and column blocks (an odd strip count -- the
+                       // vocabulary tail -- must not reuse buffer 0 for the last strip of one pass and the first of the next)
+    VOC_LDS_BARRIER();                                       // colc is complete
+    // One column block.  REFILL (every block but the workgroup's last) is a COMPILE-TIME property of the call: a branch
+    // around the refill loads -- even a workgroup-uniform one -- makes hipcc's wait-count bookkeeping age the older loads
+    // at every join, and the counted waits of the rolling refill collapse to vmcnt(0..5).  For the same reason every block
+    // computes all NS strips: past the vocabulary the packed weights, bias and column sums are zero and the columns are
+    // skipped in the candidate update, so the tail block needs no per-strip branch.
+    auto column_block = [&](auto refill_c, const int blk, const int walked) {
+        constexpr bool REFILL = decltype(refill_c)::value;
+        const int c0 = blk * (16 * NS);
+        const int nxt = blk + (int)gridDim.x;
+        const float* cb = colc + walked * 2 * (16 * NS);
+        for (int rb = 0; rb < nrb; ++rb) {
+            const bool last_rb = rb == nrb - 1;
+            const int fm_raw = rb * (16 * MT) + wave * 16 + l15;
+            const int fm = fm_raw < g.M ? fm_raw : g.M - 1;
+            if constexpr (!ONE_RB) load_rows(rb);
+            // repetition penalty: which of this lane's columns (bit st*4 + r <-> column c0 + st*16 + lg*4 + r) are in the row's history
+            unsigned int pen_mask = 0u;
+            if constexpr (MODE == VOC_GENERIC) {
+                if (pen) {
+                    for (int s2 = 0; s2 < g.cur_len; ++s2) {
+                        const int rel = g.ids[(size_t)fm * g.ld_ids + s2] - c0;
+                        if (rel >= 0 && rel < 16 * NS && ((rel >> 2) & 3) == lg) pen_mask |= 1u << ((rel >> 4) * 4 + (rel & 3));
+                    }
+                }
+            }
+            // running per-lane state: sorted top-MTOP of its 4 columns per strip, online log-sum-exp
+            float tv[MTOP];
+            int ti[MTOP];
 #pragma unroll
-        for (int j = 0; j < MTOP; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
-        float mx = -INFINITY, sm = 0.f;
-        float mean = 0.f, rstd = 1.f;
-        if (finisher && fold) stats_finish(sl, g.inv_d, g.eps_in, mean, rstd);
+            for (int j = 0; j < MTOP; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+            float mx = -INFINITY, sm = 0.f;
 
+            for_strips([&](auto stc) {
+                constexpr int st = decltype(stc)::value;
+                {
+                    f32x4_t acc[MT];
 #pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            if (st >= nstrips) break;
-            f32x4_t acc[MT];
+                    for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    for (int u = 0; u < VKS; ++u)
 #pragma unroll
-            for (int u = 0; u < VKS; ++u)
+                        for (int i = 0; i < MT; ++i)
+                            acc[i] = mfma16(wf[st][u], xf[u][i], acc[i]);
+                    const int buf = xbuf;
+                    xbuf ^= 1;
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    acc[i] = mfma16(wf[st][u], xf[u][i], acc[i]);
-            const int buf = st & 1;
+                    for (int i = 0; i < MT; ++i) red[buf][wave][i][lane] = acc[i];
+                    VOC_LDS_BARRIER();
+                    f32x4_t tot = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < MT; ++i) red[buf][wave][i][lane] = acc[i];
-            __syncthreads();
-            if (finisher) {
-                f32x4_t tot = {0.f, 0.f, 0.f, 0.f};
+                    for (int w = 0; w < 4; ++w) {
+                        const f32x4_t t = red[buf][w][wave][lane];
+                        tot[0] += t[0]; tot[1] += t[1]; tot[2] += t[2]; tot[3] += t[3];
+                    }
+                    const int n = c0 + st * 16 + lg * 4;
+                    float v[4] = {tot[0], tot[1], tot[2], tot[3]};
+                    const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(cb + st * 16 + lg * 4);
+                    const f32x4_t cc = *reinterpret_cast<const f32x4_t*>(cb + 16 * NS + st * 16 + lg * 4);
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const f32x4_t t = red[buf][w][wave][lane];
-                    tot[0] += t[0]; tot[1] += t[1]; tot[2] += t[2]; tot[3] += t[3];
-                }
-                const int n = c0 + st * 16 + lg * 4;
-                float v[4] = {tot[0], tot[1], tot[2], tot[3]};
-                const float bb[4] = {eb[st].x, eb[st].y, eb[st].z, eb[st].w}, cc[4] = {ec[st].x, ec[st].y, ec[st].z, ec[st].w};
+                    for (int r = 0; r < 4; ++r) {
+                        if (fold) v[r] = rstd * (v[r] - mean * cc[r]) + bb[r];
+                        else v[r] += bb[r];
+                    }
+                    if constexpr (MODE == VOC_GENERIC) {
+                        if (g.logits_out && fm_raw < g.M) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (fold) v[r] = rstd * (v[r] - mean * cc[r]) + bb[r];
-                    else v[r] += bb[r];
-                }
-                if (g.logits_out && fm_raw < g.M) {
+                            for (int r = 0; r < 4; ++r)
+                                if (n + r < g.N) g.logits_out[(size_t)fm * g.ld_logits + n + r] = v[r];
+                        }
+                    }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < g.N) g.logits_out[(size_t)fm * g.ld_logits + n + r] = v[r];
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        float x = v[r];
+                        const int idx = n + r;
+                        if (idx >= g.N) continue;
+                        if constexpr (MODE == VOC_GENERIC) {
+                            if ((pen_mask >> (st * 4 + r)) & 1u) x = rep_penalize(x, g.rep_penalty);
+                        }
+                        if (idx == last_tok) x = -10000.f;
+                        if (x > mx) { sm = sm * fast_exp(mx - x) + 1.f; mx = x; }
+                        else sm += fast_exp(x - mx);
+                        if (x > tv[MTOP - 1]) {
+                            tv[MTOP - 1] = x; ti[MTOP - 1] = idx;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = v[r];
-                    const int idx = n + r;
-                    if (idx >= g.N) continue;
-                    if ((pen_mask >> (st * 4 + r)) & 1u) x = rep_penalize(x, g.rep_penalty);
-                    if (idx == last_tok) x = -10000.f;
-                    if (x > mx) { sm = sm * fast_exp(mx - x) + 1.f; mx = x; }
-                    else sm += fast_exp(x - mx);
-                    if (x > tv[MTOP - 1]) {
-                        tv[MTOP - 1] = x; ti[MTOP - 1] = idx;
-#pragma unroll
-                        for (int j = MTOP - 1; j > 0; --j) {
-                            if (tv[j] > tv[j - 1]) {
-                                const float a = tv[j]; tv[j] = tv[j - 1]; tv[j - 1] = a;
-                                const int c = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = c;
+                            for (int j = MTOP - 1; j > 0; --j) {
+                                if (tv[j] > tv[j - 1]) {
+                                    const float a = tv[j]; tv[j] = tv[j - 1]; tv[j - 1] = a;
+                                    const int c = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = c;
+                                }
                             }
                         }
                     }
                 }
-            }
-        }
-        if (finisher) {
-            // ---- merge the 4 lanes of a row (equal lane & 15): log-sum-exp, then MTOP rounds of 4-way arg-max ------
+                // strip st of this column block is done for the last row block: its registers take the next block's strip
+                if constexpr (REFILL) {
+                    if (ONE_RB || last_rb) fill_strip(stc, nxt);
+                }
+            });
+            // ---- merge the 4 lanes of a row (equal lane & 15): log-sum-exp, then MTOP rounds of 4-way arg-max ----------
             float bm = fmaxf(mx, __shfl_xor(mx, 16, 64));
             bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
             float part = mx == -INFINITY ? 0.f : sm * fast_exp(mx - bm);
             part += __shfl_xor(part, 16, 64);
             part += __shfl_xor(part, 32, 64);
-            const size_t slot = (size_t)fm * gridDim.x + blockIdx.x;
+            const size_t slot = (size_t)fm * nblk + blk;
             const bool writer = lg == 0 && fm_raw < g.M;
-            if (writer) g.part_lse[slot] = float2{bm, part};
+            float* pk = park + ((size_t)walked * 64 + wave * 16 + l15) * OUT_W;      // VOC_GREEDY: this lane's parked list
+            if (writer) {
+                if constexpr (PARK) { pk[0] = bm; pk[1] = part; }
+                else g.part_lse[slot] = float2{bm, part};
+            }
 #pragma unroll
             for (int round = 0; round < MTOP; ++round) {
                 float v = tv[0];
@@ -640,13 +737,36 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
                     if (ov > v || (ov == v && oi < id)) { v = ov; id = oi; who = ow; }
                 }
                 if (writer) {
-                    g.part_val[slot * MTOP + round] = v;
-                    g.part_idx[slot * MTOP + round] = id;
+                    if constexpr (PARK) { pk[2 + round] = v; pk[2 + MTOP + round] = __int_as_float(id); }
+                    else {
+                        g.part_val[slot * MTOP + round] = v;
+                        g.part_idx[slot * MTOP + round] = id;
+                    }
                 }
                 if (who == lg) {                                   // pop the winner's head (static shifts: no dynamic register index)
 #pragma unroll
                     for (int j = 0; j + 1 < MTOP; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
                     tv[MTOP - 1] = -INFINITY; ti[MTOP - 1] = 0x7fffffff;
+                }
+            }
+        }
+    };
+    const int nwalk = (nblk - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;      // blockIdx.x < nblk (launcher)
+    for (int w = 0; w + 1 < nwalk; ++w) column_block(std::true_type{}, (int)blockIdx.x + w * (int)gridDim.x, w);
+    column_block(std::false_type{}, (int)blockIdx.x + (nwalk - 1) * (int)gridDim.x, nwalk - 1);
+    const int walked = nwalk;
+    if constexpr (PARK) {
+        // the walk is over, nothing is in flight: every writer lane stores the lists it parked (it reads its own LDS words)
+        const int fm = wave * 16 + l15;
+        if (lg == 0 && fm < g.M) {
+            for (int w = 0; w < walked; ++w) {
+                const float* pk = park + ((size_t)w * 64 + fm) * OUT_W;
+                const size_t slot = (size_t)fm * nblk + (blockIdx.x + (size_t)w * gridDim.x);
+                g.part_lse[slot] = float2{pk[0], pk[1]};
+#pragma unroll
+                for (int round = 0; round < MTOP; ++round) {
+                    g.part_val[slot * MTOP + round] = pk[2 + round];
+                    g.part_idx[slot * MTOP + round] = __float_as_int(pk[2 + MTOP + round]);
                 }
             }
         }
@@ -677,8 +797,12 @@ static hipError_t launch_dgemm_t(const DGemmArgs& g, hipStream_t s) {
         hipLaunchKernelGGL((dgemm_kernel<1, 4, EPI>), dim3((g.N + 15) / 16, 1), dim3(256), 0, s, g);
     } else if (g.M <= 32) {
         hipLaunchKernelGGL((dgemm_kernel<2, 4, EPI>), dim3((g.N + 15) / 16, 1), dim3(256), 0, s, g);
-    } else if (EPI == DEPI_BF16 && g.M <= 64 && (g.K >> 5) <= 4 * DW_KS && (g.two_strips || (g.dbg & 32))) {
-        hipLaunchKernelGGL(dgemm_wide2_kernel, dim3((g.N + 31) / 32, 1), dim3(256), 0, s, g);           // two strips per workgroup
+    } else if (EPI == DEPI_BF16 && g.M <= 64 && (g.K >> 5) <= 4 * DW_KS && g.strips_per_wg >= 2) {
+        const int nst = g.strips_per_wg >= 6 ? 6 : g.strips_per_wg >= 4 ? 4 : 2;                        // strips per workgroup
+        const dim3 grid(((g.N + 15) / 16 + nst - 1) / nst, 1);
+        if (nst == 6) hipLaunchKernelGGL(dgemm_wide_strips_kernel<6>, grid, dim3(256), 0, s, g);
+        else if (nst == 4) hipLaunchKernelGGL(dgemm_wide_strips_kernel<4>, grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL(dgemm_wide_strips_kernel<2>, grid, dim3(256), 0, s, g);
     } else if (EPI == DEPI_BF16 && g.M > 64 && (g.K >> 5) <= 4 * DW_KS && !g.dbg && !g.no_row_walk) {
         hipLaunchKernelGGL(dgemm_wide_rows_kernel, dim3((g.N + 15) / 16, 1), dim3(256), 0, s, g);       // weights once for all row blocks
     } else {
@@ -703,29 +827,32 @@ hipError_t launch_dgemm(const DGemmArgs& g, hipStream_t s) {
 int vocab_parts(int V, int cols_per_wg) { return (V + cols_per_wg - 1) / cols_per_wg; }
 int vocab_mtop_slots(int mtop) { return mtop <= 1 ? 1 : mtop <= 2 ? 2 : mtop <= 4 ? 4 : mtop <= 8 ? 8 : 16; }
 
-template <int MTOP, int NS>
-static hipError_t launch_vocab_m(const VocabArgs& g, hipStream_t s) {
-    const int nwg = vocab_parts(g.N, 16 * NS);
-    if (g.M <= 16) hipLaunchKernelGGL((vocab_topm_kernel<1, MTOP, NS>), dim3(nwg, 1), dim3(256), 0, s, g);
-    else if (g.M <= 32) hipLaunchKernelGGL((vocab_topm_kernel<2, MTOP, NS>), dim3(nwg, 1), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((vocab_topm_kernel<4, MTOP, NS>), dim3(nwg, 1), dim3(256), 0, s, g);     // the workgroup walks the row blocks
+template <int MTOP>
+static hipError_t launch_vocab_m(const VocabArgs& g_in, hipStream_t s) {
+    VocabArgs g = g_in;
+    g.nblk = vocab_parts(g.N, 16 * VOC_NS);
+    int nwg = g.max_wgs > 0 && g.max_wgs < g.nblk ? g.max_wgs : g.nblk;              // each workgroup walks nblk / nwg column blocks
+    if ((g.nblk + nwg - 1) / nwg > VOC_MAX_BLOCKS) nwg = (g.nblk + VOC_MAX_BLOCKS - 1) / VOC_MAX_BLOCKS;
+    const bool pen = g.ids != nullptr && g.rep_penalty != 0.f && g.rep_penalty != 1.f;
+    const bool fast = (g.K >> 5) == 4 * VKS && !g.logits_out && !pen;
+    if (!fast) hipLaunchKernelGGL((vocab_topm_kernel<MTOP, VOC_GENERIC>), dim3(nwg), dim3(256), 0, s, g);
+    else if (g.M <= 64) hipLaunchKernelGGL((vocab_topm_kernel<MTOP, VOC_GREEDY>), dim3(nwg), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((vocab_topm_kernel<MTOP, VOC_BEAM>), dim3(nwg), dim3(256), 0, s, g);     // walks the row blocks too
     return hipGetLastError();
 }
 
-// cols_per_wg: 64 (default) or 128 columns per workgroup; bias / colsum must be readable up to the next multiple of it
+// 128 columns per column block (cols_per_wg, kept in the argument list as a check); bias / colsum / the packed weight rows
+// must be readable up to the next multiple of 128; activations up to the next multiple of 64 rows
 hipError_t launch_vocab_topm(const VocabArgs& g, int mtop, hipStream_t s) {
     if (g.M <= 0) return hipSuccess;
-    if (g.K % 32 != 0 || (g.K >> 5) > 4 * VKS || (g.cols_per_wg != 64 && g.cols_per_wg != 128) || mtop < 1 || mtop > 16)
+    if (g.K % 32 != 0 || (g.K >> 5) > 4 * VKS || g.cols_per_wg != 16 * VOC_NS || mtop < 1 || mtop > 16)
         return hipErrorInvalidValue;
     if (g.stats_in && (!g.colsum || g.strips_in > 4 * STRIP_SLOTS)) return hipErrorInvalidValue;
-#define GITMI_VOC(MM)                                                 \
-    return g.cols_per_wg == 64 ? launch_vocab_m<MM, 4>(g, s) : launch_vocab_m<MM, 8>(g, s)
-    if (mtop <= 1) { GITMI_VOC(1); }
-    if (mtop <= 2) { GITMI_VOC(2); }
-    if (mtop <= 4) { GITMI_VOC(4); }
-    if (mtop <= 8) { GITMI_VOC(8); }
-    GITMI_VOC(16);
-#undef GITMI_VOC
+    if (mtop <= 1) return launch_vocab_m<1>(g, s);
+    if (mtop <= 2) return launch_vocab_m<2>(g, s);
+    if (mtop <= 4) return launch_vocab_m<4>(g, s);
+    if (mtop <= 8) return launch_vocab_m<8>(g, s);
+    return launch_vocab_m<16>(g, s);
 }
 
 }  // namespace gitmi

@@ -43,7 +43,7 @@ struct DGemmArgs {
     int M, N, K, lda, ldc, act;
     int dbg;                    // timing experiments only: 1 no activation loads, 2 no weight loads, 4 no MFMA, 8 no epilogue loads
     int rows_per_wg;            // N = 768 form: rows per workgroup (0 / 16 default, 32, 64)
-    int two_strips;             // wide form, 33..64 rows: two 16-column strips per workgroup, one after the other (serving policy)
+    int strips_per_wg;          // wide form, 33..64 rows: 16-column strips per workgroup, one after the other (1, 2, 4, 6; serving policy: 2)
     int no_row_walk;            // A/B: wide form over > 64 rows as one workgroup per (strip, row block) instead of the row-walking kernel
 };
 hipError_t launch_dgemm(const DGemmArgs& g, hipStream_t s);
@@ -56,8 +56,10 @@ struct VocabArgs {
     // no-immediate-repeat rule (decoder.py:330): rows of AUTOREGRESSIVE sentences past their first search step
     const int* ids; int ld_ids, cur_len; const int* plen; int beams, suppress_kind;
     float rep_penalty;          // GENERATOR repetition penalty over ids[row][0..cur_len) (decoder.py:1135-1144); 0 or 1: off
-    float* part_val; int* part_idx; float2* part_lse;     // [M][gridDim.x][slots], [M][gridDim.x] (max, sum exp)
+    float* part_val; int* part_idx; float2* part_lse;     // [M][column blocks][slots], [M][column blocks] (max, sum exp)
     float* logits_out; int ld_logits;                      // optional full logits (teacher-forced parity hook)
+    int max_wgs;                // workgroups of the launch (0: one per column block); fewer = each walks several column blocks
+    int nblk;                   // column blocks (set by the launcher)
 };
 hipError_t launch_vocab_topm(const VocabArgs& g, int mtop, hipStream_t s);
 int vocab_parts(int V, int cols_per_wg);
@@ -105,6 +107,8 @@ struct AttnDecodeArgs {
     float scale;
     int dbg;             // timing experiments: 1 skip image K/V loads, 2 skip scores, 4 skip PV
     int pairs_per_wg;    // MFMA kernel: (sentence, head) pairs per workgroup (1, 2, 4, 8); > 1 packs the launch onto fewer CUs
+    int pairs_per_wave;  // one-wave MFMA kernel: pairs a wave serves one after the other (the next pair's first K/V chunk is
+                         // requested while the current pair's text keys / output are worked off); 0 / 1 = one
     int n_pairs;         // set by the launcher
     int waves_per_pair;  // MFMA kernel: 0 / 1 = one wave walks all key steps of a pair (default); 2 = two waves split them (A/B)
 };

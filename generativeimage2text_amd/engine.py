@@ -15,6 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgitmi.so")                 # bf16 operands: the benchmarked build
 LIB_PATH_F16 = os.path.join(_HERE, "libgitmi_f16.so")         # the same sources built for fp16 operands (-DGITMI_OPS_F16)
+LIB_PATH_EXP = os.path.join(_HERE, "libgitmi_exp.so")         # measurement build of libgitmi.so (-DGITMI_EXPERIMENT): see use_experiment_build
 
 PREC_BF16, PREC_F32 = 0, 1
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
@@ -65,14 +66,25 @@ class GitmiError(RuntimeError):
 
 
 _libs: Dict[str, C.CDLL] = {}
+_experiment = False
+
+
+def use_experiment_build(on: bool = True) -> None:
+    """Measurement harnesses only (bench.py --experiment, tools/): serve "bf16" from libgitmi_exp.so, the same kernels built
+    with -DGITMI_EXPERIMENT -- kernel-shape overrides and work-skipping switches read from GITMI_* environment variables
+    at gitmi_create.  The product libraries read no environment; nothing in the package turns this on."""
+    global _experiment
+    _experiment = bool(on)
 
 
 def load_library(operands: str = "bf16") -> C.CDLL:
     """dlopen libgitmi.so (operands="bf16") or libgitmi_f16.so (operands="f16"); raises (never falls back) when it has
     not been built."""
+    if operands == "bf16" and _experiment:
+        operands = "exp"
     if operands in _libs:
         return _libs[operands]
-    path = {"bf16": LIB_PATH, "f16": LIB_PATH_F16}[operands]
+    path = {"bf16": LIB_PATH, "f16": LIB_PATH_F16, "exp": LIB_PATH_EXP}[operands]
     if not os.path.exists(path):
         raise GitmiError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -109,9 +121,9 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     lib.gitmi_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_attention.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
-    lib.gitmi_op_dgemm.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, vp, i32, i32, i32, i32, i32, vp]
+    lib.gitmi_op_dgemm.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_dgemm_res.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, vp]
-    lib.gitmi_op_vocab_topm.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.gitmi_op_vocab_topm.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]
     lib.gitmi_generate_prefixed.argtypes = [vp, C.POINTER(vp), i32, i32, vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                             i32, C.POINTER(GitmiSearch), vp, vp, vp, vp, vp]
     lib.gitmi_debug_set_gemm_impl.argtypes = [i32]
@@ -131,7 +143,7 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     if lib.gitmi_abi_version() != 6:
         raise GitmiError("libgitmi.so ABI version mismatch")
     lib.gitmi_operand_dtype.restype = C.c_int
-    if lib.gitmi_operand_dtype() != {"bf16": DTYPE_BF16, "f16": DTYPE_F16}[operands]:
+    if lib.gitmi_operand_dtype() != {"bf16": DTYPE_BF16, "f16": DTYPE_F16, "exp": DTYPE_BF16}[operands]:
         raise GitmiError(f"{path} was not built for {operands} operands")
     _libs[operands] = lib
     return lib
@@ -567,7 +579,7 @@ def _pad_vec(v: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
 
 def op_dgemm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, colsum: Optional[torch.Tensor] = None,
              stats: Optional[torch.Tensor] = None, eps: float = 1e-12, act: int = ACT_NONE,
-             frag_out: bool = False, packed: bool = False) -> torch.Tensor:
+             frag_out: bool = False, packed: bool = False, strips_per_wg: int = 0) -> torch.Tensor:
     """Decode-chain GEMM, QKV / FFN1 form (kernels_dgemm.hip): bf16 A [M,K], W [N,K] -> bf16 [M,N].
     With `stats` ([K/16][M][2] strip partials of the raw rows behind A) the LayerNorm in front of the GEMM is folded:
     out = rstd * (A W^T - mean * colsum) + bias.  Operands are given row-major and packed here (packed=True: A, W are
@@ -584,7 +596,7 @@ def op_dgemm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, colsum: Optio
     out = torch.empty((M + 15) // 16 * 16 if frag_out else M, N, device=A.device, dtype=torch.bfloat16)
     strips = 0 if stats is None else int(stats.shape[0])
     _ck(lib.gitmi_op_dgemm(Af.data_ptr(), Wf.data_ptr(), bias.data_ptr(), _ptr(colsum), _ptr(stats), strips, eps,
-                           out.data_ptr(), 1 if frag_out else 0, M, N, K, act, _stream()))
+                           out.data_ptr(), 1 if frag_out else 0, M, N, K, act, int(strips_per_wg), _stream()))
     return from_frag(out, M) if (frag_out and not packed) else out
 
 
@@ -610,7 +622,7 @@ def op_dgemm_res(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, res_x: to
 def op_vocab_topm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, mtop: int, cols_per_wg: int = 128,
                   colsum: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, eps: float = 1e-12,
                   suppress_tok: Optional[torch.Tensor] = None, want_logits: bool = False, packed: bool = False,
-                  rows: Optional[int] = None, V: Optional[int] = None):
+                  rows: Optional[int] = None, V: Optional[int] = None, max_wgs: int = 0):
     """Vocabulary head with the fused running top-M / log-sum-exp: -> (part_val [M, nparts, slots], part_idx,
     part_lse [M, nparts, 2] = (max, sum exp), logits [M, V] or None).  packed=True: A / W fragment-major (W rows and
     bias / colsum padded to a multiple of cols_per_wg), `rows` = M, `V` = vocabulary size."""
@@ -632,7 +644,7 @@ def op_vocab_topm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, mtop: in
     strips = 0 if stats is None else int(stats.shape[0])
     _ck(lib.gitmi_op_vocab_topm(Af.data_ptr(), Wf.data_ptr(), bp.data_ptr(), _ptr(cp), _ptr(stats), strips, eps,
                                 M, V, K, cols_per_wg, mtop, _ptr(suppress_tok), pv.data_ptr(), pi.data_ptr(),
-                                pl.data_ptr(), _ptr(lg), _stream()))
+                                pl.data_ptr(), _ptr(lg), int(max_wgs), _stream()))
     return pv, pi, pl, lg
 
 

@@ -13,9 +13,19 @@ import torch
 from .configs import GitModelConfig
 
 
-def random_state_dict(cfg: GitModelConfig, seed: int = 1234, eos_bias: float = -5.0) -> Dict[str, torch.Tensor]:
+def random_state_dict(cfg: GitModelConfig, seed: int = 1234, eos_bias: float = -5.0,
+                      successor: float = 0.0) -> Dict[str, torch.Tensor]:
     """eos_bias < 0 keeps captions from ending early so that every caption costs max_steps-1 decode steps
-    (the fixed-work protocol of SURVEY.md 8d)."""
+    (the fixed-work protocol of SURVEY.md 8d).
+
+    successor > 0: the WIDE-MARGIN variant of the same weights (tests/golden/full_wide_*: the regime in which "greedy ids
+    identical to the reference" is decidable for a 16-bit pipeline).  Plain random-init weights give Gaussian logits over
+    30522 tokens, whose top-1 / top-2 gap is below any 16-bit pipeline's logit error somewhere in almost every 19-step
+    row; a trained captioner is confident at most steps.  Here the output matrix is untied and carries a successor
+    structure, W_out[v] = N(0, .02) + successor * E[perm[v]] (E = word embedding, perm a seeded permutation): after
+    token u the logit of perm^-1(u) stands out by ~2 (20 x the bf16 logit error).  The word embedding of [CLS] and
+    position 0 are zero, so the hidden state of the first step is what attention reads from the IMAGE: the first token
+    is image-dependent, every later one follows the chain of its predecessor -- rows differ, no row loops."""
     g = torch.Generator().manual_seed(seed)
 
     def rn(*shape, std):
@@ -69,6 +79,15 @@ def random_state_dict(cfg: GitModelConfig, seed: int = 1234, eos_bias: float = -
     ob = torch.zeros(V)
     ob[cfg.eos] = eos_bias
     sd["textual.output.bias"] = ob          # textual.output.weight tied to the word embedding
+    if successor != 0.0:
+        g2 = torch.Generator().manual_seed(seed + 7919)
+        perm = torch.randperm(V, generator=g2)
+        boost = successor * sd["textual.embedding.words.weight"][perm]
+        boost[perm == cfg.sos] = 0.0        # nothing is "the successor of [CLS]": the first token is read from the image
+        boost[cfg.eos] = 0.0                # [SEP] is never a successor: every caption runs max_steps - 1 decode steps
+        sd["textual.output.weight"] = torch.randn(V, d, generator=g2) * 0.02 + boost
+        sd["textual.embedding.words.weight"][cfg.sos] = 0.0
+        sd["textual.embedding.positions.weight"][0] = 0.0
     for i in range(cfg.num_frames):
         sd[f"img_temperal_embedding.{i}"] = rn(1, 1, D, std=0.02)
     return sd
@@ -77,3 +96,13 @@ def random_state_dict(cfg: GitModelConfig, seed: int = 1234, eos_bias: float = -
 def random_frames(cfg: GitModelConfig, batch: int, frames: int = 1, seed: int = 0, device="cuda") -> List[torch.Tensor]:
     g = torch.Generator().manual_seed(seed)
     return [torch.randn(batch, 3, cfg.image_size, cfg.image_size, generator=g).to(device) for _ in range(frames)]
+
+
+def seeded_images(cfg: GitModelConfig, image_seeds, device="cuda") -> List[torch.Tensor]:
+    """One single-frame batch whose image i is drawn from its OWN generator (seed image_seeds[i]): a fixture can name
+    the images it kept (tests/golden/full_wide_*.npz `image_seeds`) without storing them."""
+    imgs = []
+    for sd in image_seeds:
+        g = torch.Generator().manual_seed(7_000_000 + int(sd))
+        imgs.append(torch.randn(3, cfg.image_size, cfg.image_size, generator=g))
+    return [torch.stack(imgs).to(device)]

@@ -316,21 +316,27 @@ int  gitmi_op_attention(const void* qkv, void* out, int B, int N, int H, int dty
  *   gitmi_op_dgemm     : C bf16 [M,N] = act( LN_fold(A) W^T + bias ); stats == NULL: plain A W^T + bias.
  *                        With stats: W must be bf16(W . gamma), bias = beta W^T + b, colsum[n] = sum_k W'[n][k].
  *   gitmi_op_dgemm_res : x = A W^T + bias + r,  r = res_x (res_stats == NULL) or LayerNorm(res_x; res_gamma, res_beta)
- *                        rebuilt from res_stats; writes x fp32, its bf16 copy and stats_out [N/16][M][2].  N % 16 == 0. */
+ *                        rebuilt from res_stats; writes x fp32, its bf16 copy and stats_out [N/16][M][2].  N % 16 == 0.
+ *                        strips_per_wg (QKV / FFN1 form, 33..64 rows): 16-column strips a workgroup computes one after
+ *                        the other -- 0 / 1 (one workgroup per strip), 2, 4 or 6; results do not depend on it. */
 int  gitmi_op_dgemm(const void* A, const void* W, const float* bias, const float* colsum, const float* stats,
-                    int strips, float eps, void* C, int c_frag, int M, int N, int K, int act, void* stream);
+                    int strips, float eps, void* C, int c_frag, int M, int N, int K, int act, int strips_per_wg,
+                    void* stream);
 int  gitmi_op_dgemm_res(const void* A, const void* W, const float* bias, const float* res_x, const float* res_stats,
                         int res_strips, const float* res_gamma, const float* res_beta, float res_eps,
                         float* x_out, void* xb_out, float* stats_out, int M, int N, int K, void* stream);
 /* vocabulary head with the search's top-M and log-softmax statistics fused (replaces decoder.py:1054 + the
- * log_softmax/topk of :265-271, 358-366, 1169-1175): one workgroup sweeps cols_per_wg columns for all rows and writes
- * (64 or 128) a sorted list of `slots` = {1,2,4,8,16} >= mtop (logit, token) pairs + (max, sum exp) per (row, workgroup):
- * part_val/part_idx [M][ceil(V/cols_per_wg)][slots], part_lse [..][2].  suppress_tok int32 [M] (or NULL): that
- * token's logit counts as -10000 (decoder.py:330).  logits_out fp32 [M,V] optional.  K <= 768. */
+ * log_softmax/topk of :265-271, 358-366, 1169-1175): per COLUMN BLOCK of cols_per_wg = 128 columns and row, a sorted list
+ * of `slots` = {1,2,4,8,16} >= mtop (logit, token) pairs + (max, sum exp):
+ * part_val/part_idx [M][ceil(V/128)][slots], part_lse [..][2].  suppress_tok int32 [M] (or NULL): that
+ * token's logit counts as -10000 (decoder.py:330).  logits_out fp32 [M,V] optional.  K <= 768.
+ * max_wgs: workgroups of the launch -- 0 = one per column block; n > 0 = at most n, each WALKING its column blocks with a
+ * rolling refill of the weight registers (at most 8 blocks per workgroup); results do not depend on it.
+ * A rows must be readable up to the next multiple of 64, W rows / bias / colsum up to the next multiple of 128. */
 int  gitmi_op_vocab_topm(const void* A, const void* W, const float* bias, const float* colsum, const float* stats,
                          int strips, float eps, int M, int V, int K, int cols_per_wg, int mtop,
                          const int* suppress_tok, float* part_val, int* part_idx, float* part_lse,
-                         float* logits_out, void* stream);
+                         float* logits_out, int max_wgs, void* stream);
 
 /* decode attention for one new text position (unit parity / timing): qkv [R,3d] (R = B*beams), text caches
  * [R][T_max][d] (position `pos` is appended), kv_src int32 [R][T_max], out [R,d].

@@ -169,14 +169,9 @@ def test_dgemm_qkv_ffn1_form(M, N, K, act, fold):
         assert (out.cpu().double() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
         if N % 32 == 0:      # fragment-major output (operand of the next chain GEMM) holds the same values
             assert torch.equal(E.op_dgemm(A.cuda(), W.bfloat16().cuda(), bias.cuda(), act=act, frag_out=True), out)
-        if 32 < M <= 64 and N >= 1536:      # two strips per workgroup (serving policy) == one strip per workgroup, bit for bit
-            lib = E.load_library()
-            lib.gitmi_debug_set_dgemm(32)
-            try:
-                two = E.op_dgemm(A.cuda(), W.bfloat16().cuda(), bias.cuda(), act=act)
-            finally:
-                lib.gitmi_debug_set_dgemm(0)
-            assert torch.equal(two, out)
+        if 32 < M <= 64 and N >= 1536:      # 2 / 4 / 6 strips per workgroup (serving policy) == one strip per workgroup, bit for bit
+            for nst in (2, 4, 6):
+                assert torch.equal(E.op_dgemm(A.cuda(), W.bfloat16().cuda(), bias.cuda(), act=act, strips_per_wg=nst), out)
         if M > 64:           # the row-walking kernel (> 64 rows) == the one-block kernel on the same rows, bit for bit
             hi = min(M, 128)
             sub = E.op_dgemm(A[64:hi].contiguous().cuda(), W.bfloat16().cuda(), bias.cuda(), act=act)
@@ -192,13 +187,9 @@ def test_dgemm_qkv_ffn1_form(M, N, K, act, fold):
     stats = E.strip_stats(x.cuda())
     out_dev = E.op_dgemm(x.bfloat16().cuda(), Wf.cuda(), bf.cuda(), cs.cuda(), stats, 1e-12, act)
     if 32 < M <= 64 and N >= 1536:
-        lib = E.load_library()
-        lib.gitmi_debug_set_dgemm(32)
-        try:
-            two = E.op_dgemm(x.bfloat16().cuda(), Wf.cuda(), bf.cuda(), cs.cuda(), stats, 1e-12, act)
-        finally:
-            lib.gitmi_debug_set_dgemm(0)
-        assert torch.equal(two, out_dev)
+        for nst in (2, 4, 6):
+            assert torch.equal(E.op_dgemm(x.bfloat16().cuda(), Wf.cuda(), bf.cuda(), cs.cuda(), stats, 1e-12, act,
+                                          strips_per_wg=nst), out_dev)
     if M > 64:               # row-walking kernel vs one-block kernel, folded LayerNorm included
         hi = min(M, 128)
         sub = E.op_dgemm(x[64:hi].bfloat16().contiguous().cuda(), Wf.cuda(), bf.cuda(), cs.cuda(),
@@ -240,14 +231,19 @@ def test_dgemm_residual_stats_form(M, N, K, ln_res):
     assert torch.equal(x3, x[:3])
 
 
-@pytest.mark.parametrize("M,V,K,mtop,cols", [(64, 30522, 768, 1, 128), (64, 30522, 768, 8, 128), (256, 30522, 768, 8, 128),
-                                             (5, 1000, 128, 4, 128), (33, 1000, 128, 2, 64), (16, 5003, 256, 16, 128),
-                                             (64, 30522, 768, 1, 64), (40, 999, 96, 8, 64)])
+@pytest.mark.parametrize("M,V,K,mtop", [(64, 30522, 768, 1), (64, 30522, 768, 8), (256, 30522, 768, 8), (130, 30522, 768, 4),
+                                        (5, 1000, 128, 4), (33, 1000, 128, 2), (16, 5003, 256, 16), (40, 999, 96, 8),
+                                        (200, 1000, 128, 4), (7, 1000, 768, 16), (100, 2000, 768, 2)])
 @pytest.mark.parametrize("fold", [False, True])
-def test_vocab_head_fused_topm(M, V, K, mtop, cols, fold):
-    """Vocabulary head with running top-M / log-sum-exp: merging the per-workgroup lists must give exactly the top-M
-    and the log-softmax of the logits the same kernel materialises on request; those logits against fp64."""
+def test_vocab_head_fused_topm(M, V, K, mtop, fold):
+    """Vocabulary head with running top-M / log-sum-exp: merging the per-column-block lists must give exactly the top-M
+    and the log-softmax of the logits the same kernel materialises on request; those logits against fp64.  Then the same
+    lists, bit for bit, from the kernels that run in the decode loop (no logits output: the one-row-block kernel with the
+    lists parked in LDS, the row-block-walking kernel) for several grid sizes: one workgroup per column block, and fewer
+    workgroups that WALK their column blocks with the rolling weight refill (an odd number of blocks per workgroup, an
+    uneven split, 8 blocks per workgroup; V = 1000 / 999 end in a 7-strip tail block)."""
     from generativeimage2text_amd import engine as E
+    cols = 128
     W = _rand(V, K, seed=41, scale=K ** -0.5 * 2.0)
     bias = _rand(V, seed=42, scale=0.5)
     x = _rand(M, K, seed=43, scale=1.1) + 0.15
@@ -285,6 +281,18 @@ def test_vocab_head_fused_topm(M, V, K, mtop, cols, fold):
     got = torch.log((pl[:, :, 1].double() * torch.exp(pl[:, :, 0].double() - pl[:, :, 0].double().max(1, keepdim=True).values)).sum(1)) \
         + pl[:, :, 0].double().max(1).values
     assert (got - lse).abs().max().item() < 1e-4
+    # the decode-loop kernels (no logits output), every grid size
+    for max_wgs in (0, 1000, (nparts + 2) // 3, max(1, nparts - 1), (nparts + 7) // 8, 60):
+        if fold:
+            qv, qi, ql, _ = E.op_vocab_topm(x.bfloat16().cuda(), Wf.cuda(), bf.cuda(), mtop, cols, cs.cuda(), E.strip_stats(x.cuda()),
+                                            1e-12, sup.cuda(), False, max_wgs=max_wgs)
+        else:
+            qv, qi, ql, _ = E.op_vocab_topm(x.bfloat16().cuda(), W.bfloat16().cuda(), bias.cuda(), mtop, cols, suppress_tok=sup.cuda(),
+                                            want_logits=False, max_wgs=max_wgs)
+        k = min(mtop, cols)
+        assert torch.equal(qv.cpu()[:, :, :k], pv[:, :, :k]), max_wgs
+        assert torch.equal(qi.cpu().long()[:, :, :k], pi[:, :, :k]), max_wgs
+        assert torch.equal(ql.cpu(), pl), max_wgs
 
 
 @pytest.mark.parametrize("B,H,N_img,pos,beams", [(2, 2, 17, 0, 1), (3, 12, 197, 5, 1), (2, 12, 197, 7, 4), (1, 2, 300, 3, 3),

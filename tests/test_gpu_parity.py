@@ -226,6 +226,37 @@ def test_full_batch_ids_against_reference(name):
                 record_measurement(**rec)
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
+def test_wide_margin_batch_ids_identical_to_reference(prec):
+    """north_star: "greedy outputs bit-identical to reference token IDs".  With plain random-init weights that clause is
+    undecidable for ANY 16-bit pipeline: Gaussian logits over 30522 tokens put a top-1 / top-2 gap below the pipeline's own
+    logit error somewhere in almost every 19-step row (on the benchmark's golden every one of the 64 rows has such a
+    step).  tests/golden/full_wide_b64_greedy.npz is BASELINE's cfg2 (GIT_BASE, B = 64, greedy, 19 steps) in the regime
+    where it IS decidable -- the benchmark's weight family with a successor structure on the output matrix
+    (synthetic.random_state_dict(successor=1.0)) and 64 images on which EVERY decision of the fp32 reference has a margin
+    >= 0.2 (oracle/make_golden.py: select_wide_images; first tokens differ with the image, 20 distinct ids per row) -- and
+    there every precision of the engine must return the reference's ids on 64 of 64 rows."""
+    from generativeimage2text_amd.parity import ids_parity
+    name = "full_wide_b64_greedy"
+    g = load_golden(name)
+    cfg, w, frames, search, _ = MG.full_case_inputs(name)
+    B = frames[0].shape[0]
+    assert float(g["step_margin"].min()) >= 0.1 and B == 64
+    eng = make_engine(cfg, w, prec, B, search)
+    tokens, logprobs, info = eng.generate([f.cuda() for f in frames], search_struct(search))
+    preds, lps = format_like_reference(search, tokens, logprobs, info, None)
+    logits = eng.step_logits(torch.from_numpy(g["tf_tokens"]))[:4, ::3].cpu().numpy()
+    eng.close()
+    lerr = float(np.abs(logits - g["tf_logits"]).max())
+    span = float(g["tf_logits"].max() - g["tf_logits"].min())
+    stats = ids_parity(preds.numpy(), g["predictions"], g["step_margin"], 0.1, chained=False, min_identical=B)
+    record_measurement(case=name + "@" + prec, config=cfg.name, lerr=round(lerr, 5), span=round(span, 3),
+                       lerr_frac=round(lerr / span, 6), min_margin=round(float(g["step_margin"].min()), 4), **stats)
+    assert stats["identical"] == B and stats["safe_rows"] == B, stats
+    assert np.allclose(lps.numpy(), g["logprobs"], atol=1e-4 if prec == "f32" else 0.05), np.abs(lps.numpy() - g["logprobs"]).max()
+    assert len({tuple(r) for r in preds.numpy().tolist()}) >= 8        # the rows are not copies of each other
+
+
 # ---- the search seam with scripted logits (no model): device search == reference search ----------
 @pytest.mark.parametrize("name", sorted(MG.SCRIPTED))
 def test_device_search_scripted(name):
