@@ -11,20 +11,14 @@ AB_STEPS=40 AB_WARMUP=8 bash tools/gpu_ab.sh $TAG 2 \
   "base:$B" \
   "v60:GITMI_VOCAB_WGS=60 GITMI_DGEMM_STRIPS=2" \
   "v40:GITMI_VOCAB_WGS=40 GITMI_DGEMM_STRIPS=2" \
-  "v80:GITMI_VOCAB_WGS=80 GITMI_DGEMM_STRIPS=2" \
-  "v120:GITMI_VOCAB_WGS=120 GITMI_DGEMM_STRIPS=2" \
   "s4:GITMI_VOCAB_WGS=0 GITMI_DGEMM_STRIPS=4" \
-  "s6:GITMI_VOCAB_WGS=0 GITMI_DGEMM_STRIPS=6" \
   "ppw2:$B GITMI_ATTN_PPW=2" \
-  "ppw2np:$B GITMI_ATTN_PPW=2 GITMI_ATTN_DBG=32" \
-  "ppw3:$B GITMI_ATTN_PPW=3" \
   "combo:GITMI_VOCAB_WGS=60 GITMI_DGEMM_STRIPS=4 GITMI_ATTN_PPW=2"
 AB_STEPS=40 AB_WARMUP=8 bash tools/gpu_ab.sh ${TAG}_beam 1 \
   "base:$B -- --search beam" \
-  "v60:GITMI_VOCAB_WGS=60 GITMI_DGEMM_STRIPS=2 -- --search beam" \
-  "v40ppw2:GITMI_VOCAB_WGS=40 GITMI_DGEMM_STRIPS=2 GITMI_ATTN_PPW=2 -- --search beam"
+  "v60:GITMI_VOCAB_WGS=60 GITMI_DGEMM_STRIPS=2 -- --search beam"
 t "solo decode step per variant (one context: roofline_decode)"
-for v in "GITMI_VOCAB_WGS=0" "GITMI_VOCAB_WGS=60" "GITMI_VOCAB_WGS=40" "GITMI_DGEMM_STRIPS=4" "GITMI_ATTN_PPW=2 GITMI_ATTN_PW=8"; do
+for v in "GITMI_VOCAB_WGS=0" "GITMI_VOCAB_WGS=60" "GITMI_DGEMM_STRIPS=4" "GITMI_ATTN_PPW=2 GITMI_ATTN_PW=8"; do
   env $v timeout 200 python bench.py --experiment --no-cpu-baseline --contexts 1 --steps 10 --warmup 2 2>/dev/null | tail -n 1 | python -c "
 import sys, json; d = json.loads(sys.stdin.read()); print('$v', 'solo ms/pass', d['ms_per_step'], 'decode step', d['roofline_decode'].get('avg_step_ms'), 'identical', (d.get('parity') or {}).get('identical'))"
 done
