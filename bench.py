@@ -351,6 +351,9 @@ def main(argv=None, engine_factory=None):
     from generativeimage2text_amd.engine import Engine
     from generativeimage2text_amd.synthetic import random_state_dict, random_frames
 
+    if (args.decode_group > 1 or args.phased > 0 or os.environ.get("BENCH_GEMM_IMPL")) and not args.experiment and not standin:
+        raise SystemExit("--decode-group / --phased / BENCH_GEMM_IMPL are schedules and switches of the measurement build "
+                         "(they measured slower than the default mixed schedule: DESIGN.md section 4): add --experiment")
     if args.experiment:
         from generativeimage2text_amd.engine import use_experiment_build
         use_experiment_build(True)

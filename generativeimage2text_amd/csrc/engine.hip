@@ -22,6 +22,15 @@
 
 using namespace gitmi;
 
+// Entry points of the measurement build (include/gitmi_experiment.h): schedules that measured slower than the default and
+// debug hooks.  The product libraries keep the code paths (they share the generate machinery) but do not export them.
+#ifdef GITMI_EXPERIMENT
+#include "../../include/gitmi_experiment.h"
+#define GITMI_EXP_EXPORT extern "C"
+#else
+#define GITMI_EXP_EXPORT [[maybe_unused]] static
+#endif
+
 // ---------------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
 static int fail(const char* fmt, ...) {
@@ -821,7 +830,7 @@ static int clone_impl(gitmi_engine* src, int max_batch, gitmi_engine** out) {
 extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
     return clone_impl(src, src ? src->cfg.max_batch : 0, out);
 }
-extern "C" int gitmi_clone_sized(gitmi_engine* src, int max_batch, gitmi_engine** out) {
+GITMI_EXP_EXPORT int gitmi_clone_sized(gitmi_engine* src, int max_batch, gitmi_engine** out) {
     return clone_impl(src, max_batch, out);
 }
 
@@ -1612,7 +1621,7 @@ static int check_generate_args(gitmi_engine* e, int F, int B, const int64_t* pre
     return 0;
 }
 
-extern "C" int gitmi_generate_encode(gitmi_engine* e, const float* const* frames, int F, int B, const int64_t* prefix, int P,
+GITMI_EXP_EXPORT int gitmi_generate_encode(gitmi_engine* e, const float* const* frames, int F, int B, const int64_t* prefix, int P,
                                      const gitmi_search* sp, void* stream) {
     RCK(check_ready(e));
     if (!frames) return fail("generate_encode: null argument");
@@ -1621,7 +1630,7 @@ extern "C" int gitmi_generate_encode(gitmi_engine* e, const float* const* frames
     return generate_run(e, frames, F, B, B, P, P, false, sp, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream, 1);
 }
 
-extern "C" int gitmi_generate_decode(gitmi_engine* e, int F, int B, const int64_t* prefix, int P, const gitmi_search* sp,
+GITMI_EXP_EXPORT int gitmi_generate_decode(gitmi_engine* e, int F, int B, const int64_t* prefix, int P, const gitmi_search* sp,
                                      int64_t* tokens_out, float* logprob_out, int32_t* info_out, void* stream) {
     RCK(check_ready(e));
     if (!tokens_out || !logprob_out || !info_out) return fail("generate_decode: null argument");
@@ -1642,7 +1651,7 @@ static void unlink_decode_group(gitmi_engine* m) {
     destroy_graph(m);                   // its graphs write into the group's cache
 }
 
-extern "C" int gitmi_set_decode_group(gitmi_engine* member, gitmi_engine* group, int image_offset) {
+GITMI_EXP_EXPORT int gitmi_set_decode_group(gitmi_engine* member, gitmi_engine* group, int image_offset) {
     if (!member) return fail("set_decode_group: null member");
     HIPCK(hipSetDevice(member->device));
     HIPCK(hipDeviceSynchronize());
@@ -1673,7 +1682,7 @@ extern "C" int gitmi_set_decode_group(gitmi_engine* member, gitmi_engine* group,
     return 0;
 }
 
-extern "C" int gitmi_group_decode(gitmi_engine* e, int F, int B, const int64_t* prefix, int P, const gitmi_search* sp,
+GITMI_EXP_EXPORT int gitmi_group_decode(gitmi_engine* e, int F, int B, const int64_t* prefix, int P, const gitmi_search* sp,
                                   int64_t* tokens_out, float* logprob_out, int32_t* info_out, void* stream) {
     RCK(check_ready(e));
     if (!tokens_out || !logprob_out || !info_out) return fail("group_decode: null argument");
@@ -1959,7 +1968,7 @@ extern "C" int gitmi_op_sample_rows(const float* logits, int R, int V, float tem
 // of the SAME model in the other precision, so that a stage can be switched between bf16 and fp32 on its own.
 //   stage 1: visual features (image encoder output)        -> dst runs prefill + decode itself
 //   stage 2: + the image K/V of every decoder layer (prefill) -> dst runs only the decode steps itself
-extern "C" int gitmi_debug_import_stage(gitmi_engine* dst, gitmi_engine* src, int stage, void* stream) {
+GITMI_EXP_EXPORT int gitmi_debug_import_stage(gitmi_engine* dst, gitmi_engine* src, int stage, void* stream) {
     RCK(check_ready(dst));
     if (!src || !src->finalized) return fail("debug_import_stage: bad source");
     if (stage != 1 && stage != 2) return fail("debug_import_stage: stage must be 1 or 2");
@@ -1984,7 +1993,7 @@ extern "C" int gitmi_debug_import_stage(gitmi_engine* dst, gitmi_engine* src, in
 }
 // the vocabulary head of `dst` (bf16: the fused, LayerNorm-folded head) applied to the last hidden state that `src`
 // (an fp32 context) computed in its most recent gitmi_step_logits over R rows: logits_out fp32 [R, vocab] (device)
-extern "C" int gitmi_debug_head_from(gitmi_engine* dst, gitmi_engine* src, int R, float* logits_out, void* stream) {
+GITMI_EXP_EXPORT int gitmi_debug_head_from(gitmi_engine* dst, gitmi_engine* src, int R, float* logits_out, void* stream) {
     RCK(check_ready(dst));
     if (!src || !src->f32 || !logits_out) return fail("debug_head_from: the source must be an fp32 context");
     if (dst->f32 || !dst->skinny) return fail("debug_head_from: the destination must run the bf16 decode chain");
@@ -1997,7 +2006,7 @@ extern "C" int gitmi_debug_head_from(gitmi_engine* dst, gitmi_engine* src, int R
     return decode_head_impl(dst, nullptr, c.max_text_len, 1, R, 1, 0, 1, logits_out, c.vocab, s, &cands);
 }
 
-extern "C" int gitmi_debug_set_gemm_impl(int impl) {
+GITMI_EXP_EXPORT int gitmi_debug_set_gemm_impl(int impl) {
     set_gemm_impl(impl);
     return 0;
 }

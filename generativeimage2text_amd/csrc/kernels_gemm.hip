@@ -295,39 +295,33 @@ void set_gemm_impl(int impl) {
     g_gemm_impl = impl;
 }
 
-// in_f32/out_f32: element types of A,W and of C
+// what the LDS-DMA kernel (kernels_gemm10.hip) needs of the operands besides its shape rules (gemm_p8_supports): bf16/fp16
+// operands, 16-byte aligned rows and bases
+static bool gemm_fast_operands(const GemmArgs& g, bool in_f32, bool out_f32) {
+    if (in_f32) return false;
+    if (g.K % 64 != 0 || g.N % 8 != 0 || g.lda % 8 != 0) return false;
+    if (g.ldc % (out_f32 ? 4 : 8) != 0) return false;
+    if (g.res && g.ldr % (g.out_f16 ? 8 : 4) != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W) | reinterpret_cast<uintptr_t>(g.C) |
+         reinterpret_cast<uintptr_t>(g.res)) & 15)
+        return false;
+    return true;
+}
+
+// in_f32/out_f32: element types of A,W and of C.  Two kernels: the 256x256x64 half-tile LDS-DMA pipeline
+// (kernels_gemm10.hip) for every 16-bit GEMM with more than 512 rows that meets its shape rules -- all of the image encoder
+// and the decoder prefill of every BASELINE configuration -- and the register-staged tile kernel of this file for the rest
+// (fp32 parity mode, small batches, odd shapes).  The three generations in between (128x128 direct-to-LDS, 256x128 and
+// 256x256x32 rings) were removed in round 4: no BASELINE configuration reached them any more.
+// impl (measurement builds: gitmi_debug_set_gemm_impl): -1 auto | 0 tile kernel only | 9 LDS-DMA kernel wherever it can run
 hipError_t launch_gemm(const GemmArgs& g_in, bool in_f32, bool out_f32, hipStream_t s) {
     GemmArgs g = g_in;
     g.dbg = g_gemm_dbg;
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
-    if (g.out_f16) {
-        // fp16 residual-stream rows out (and in, as the residual): the p8 kernel for the large-M phases, the generic
-        // kernel otherwise (the ring / direct-to-LDS generations have no fp16 epilogue)
-        if (in_f32 || out_f32 || g.K % 64 != 0) return hipErrorInvalidValue;
-        if (g_gemm_impl != 0 && g.M > 512 && gemm_dlds_supported(g, false, false) && (!g.res || g.ldr % 8 == 0) &&
-            gemm_p8_supports(g))
-            return launch_gemm_p8(g, false, s);
-        return launch_gemm_tiles<bf16_t, f16_t>(g, s);
-    }
-    // impl: -1 auto | 0 register-staged (also fp32, odd shapes) | 1 direct-to-LDS 128x128 | 2 256x128 3-stage ring |
-    //       6 256x256x32 4-stage ring | 9 256x256x64 half-tile pipeline (kernels_gemm10.hip)
-    if (g_gemm_impl != 0 && gemm_dlds_supported(g, in_f32, out_f32)) {
-        if (g_gemm_impl == 6) return launch_gemm_ring256(g, out_f32, s);
-        if (g_gemm_impl == 9 && gemm_p8_supports(g)) return launch_gemm_p8(g, out_f32, s);
-        // auto: narrow outputs (N <= 1024: out-proj, c_proj, patch embed) have too few 256x128 tiles per CU and
-        // run faster on the 256x256 4-stage ring; wide outputs on the 256x128 3-stage ring (measured, profiles/)
-        if (g_gemm_impl == -1 && g.M > 512 && gemm_p8_supports(g)) {
-            // 256x256 (or 192x256) half-tile pipeline vs 256x128 ring: a p8 tile does twice the work in ~1.5x the
-            // time; take it when its (one workgroup per CU) round count wins.  Units: ring round = 8/3, p8 round = 4|3
-            const long tm = (g.M + 255) / 256;
-            const long r_ring = (tm * ((g.N + 127) / 128) + 255) / 256;
-            const int c_p8 = gemm_p8_cost(g, 96) < gemm_p8_cost(g, 128) ? gemm_p8_cost(g, 96) : gemm_p8_cost(g, 128);
-            if (3 * c_p8 < 8 * r_ring) return launch_gemm_p8(g, out_f32, s);
-        }
-        if (g_gemm_impl == -1 && g.M > 512 && g.N <= 1024 && g.N % 256 == 0) return launch_gemm_ring256(g, out_f32, s);
-        if (g_gemm_impl == 2 || (g_gemm_impl == -1 && g.M > 512)) return launch_gemm_ring(g, out_f32, s);
-        if (g_gemm_impl == 1 || (g_gemm_impl == -1 && g.M > 256)) return launch_gemm_dlds(g, out_f32, s);
-    }
+    if (g.out_f16 && (in_f32 || out_f32 || g.K % 64 != 0)) return hipErrorInvalidValue;     // fp16 residual-stream rows: bf16 engine mode
+    const bool fast_ok = g_gemm_impl != 0 && gemm_fast_operands(g, in_f32, out_f32) && gemm_p8_supports(g);
+    if (fast_ok && (g.M > 512 || g_gemm_impl == 9)) return launch_gemm_p8(g, out_f32, s);
+    if (g.out_f16) return launch_gemm_tiles<bf16_t, f16_t>(g, s);
     if (in_f32) {
         if (g.K % 16 != 0) return hipErrorInvalidValue;
         return out_f32 ? launch_gemm_tiles<float, float>(g, s) : launch_gemm_tiles<float, bf16_t>(g, s);

@@ -3,8 +3,8 @@
 //
 //   C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) (+ residual[M,N])      K % 64 == 0, K >= 128, N % 256 == 0
 //
-// Why: the 256x128 ring kernels (kernels_gemm3.hip ...) need one operand byte from L2 per 85 FLOP and all
-// saturate near 12 TB/s of operand feed.  A 256x256 tile needs one byte per 128 FLOP; the 128 KiB of LDS
+// Why: a 256x128 tile (the ring kernels of rounds 1-2, removed in round 4) needs one operand byte from L2 per 85 FLOP
+// and saturates near 12 TB/s of operand feed.  A 256x256 tile needs one byte per 128 FLOP; the 128 KiB of LDS
 // that leaves room for only two K tiles are recycled at HALF-TILE granularity so that four half tiles
 // (64 KiB) are always in flight.
 //
@@ -13,7 +13,11 @@
 //     so that quadrant (qm,qn) of EVERY wave reads activation half qm (rows qm*128..) and weight half qn.
 //     MFMA 16x16x32 bf16 in swapped orientation (accumulator = C^T, see kernels_gemm.hip).
 //   * LDS: 2 K tiles x [A0 | A1 | B0 | B1], each half tile = 128 rows x 128 B = 16 KiB in the bank-conflict
-//     free image of kernels_gemm3.hip; a wave fills 2 KiB of every half tile (2 global_load_lds_dwordx4).
+//     free image below; a wave fills 2 KiB of every half tile (2 global_load_lds_dwordx4).
+//     LDS image: 128-byte rows paired into 256-byte bank rows; 16-byte chunk c of row r lives at
+//         (r>>1)*256 + ((r&1) ^ ((r>>3)&1))*128 + (c ^ ((r>>1)&7))*16
+//     which makes every ds_read_b128 lane group hit 16 distinct bank slots.  A direct-to-LDS load writes lane-linearly,
+//     so the permutation is applied to each lane's SOURCE address (and again on the fragment read).
 //   * K tile t, phase p = 1..4, each phase = [ds_reads, one half-tile prefetch, counted vmcnt] s_barrier
 //     [16 MFMAs] s_barrier:
 //         P1: read B0,A0 (12 ds_read_b128)   prefetch B1(t+1)   MFMA quadrant (0,0)
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         __builtin_amdgcn_global_load_lds((const void*)(src + o1), (lds_void_t*)(dst + 1024), 16, 0, 0);
     };
 
-    // ---- fragment addressing (bank-conflict free image, kernels_gemm3.hip) ---------------------------
+    // ---- fragment addressing (bank-conflict free image, see the header) -------------------------------
     const int rowpart = (l15 >> 1) * 256 + ((l15 & 1) ^ ((l15 >> 3) & 1)) * 128;
     const int x7 = (l15 >> 1) & 7;
     const int ch0 = ((0 * 4 + lg) ^ x7) * 16;
@@ -485,6 +489,21 @@ hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s) {
     g.tiles_n = g.N / BN;
     int max_cnt = 0;
     p8_plan(g, mh, &g.ng, &max_cnt);
+    if (g.dbg & (1024 | 2048 | 4096 | 8192)) {           // A/B (tools/gemm_bench.py): force the XCD partition ng = 1 / 2 / 4 / 8
+        const int ng = (g.dbg & 1024) ? 1 : (g.dbg & 2048) ? 2 : (g.dbg & 4096) ? 4 : 8;
+        g.dbg &= ~(1024 | 2048 | 4096 | 8192);
+        if (ng <= g.tiles_n) {
+            const int tiles_m = (g.M + 2 * mh - 1) / (2 * mh), mg = 8 / ng;
+            g.ng = ng; max_cnt = 0;
+            for (int x = 0; x < 8; ++x) {
+                const int gn = x % ng, gm = x / ng;
+                const int nn = (gn + 1) * g.tiles_n / ng - gn * g.tiles_n / ng;
+                const int tg = tiles_m * nn;
+                const int cnt = (gm + 1) * tg / mg - gm * tg / mg;
+                max_cnt = cnt > max_cnt ? cnt : max_cnt;
+            }
+        }
+    }
     g.nwg = 8 * max_cnt;
     const bool staged = (g.dbg & 256) != 0;              // A/B: fp32 outputs through the LDS-staged epilogue
     g.dbg &= ~256;

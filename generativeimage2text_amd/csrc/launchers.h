@@ -11,21 +11,16 @@ struct GemmArgs {
     int lda, ldc, ldr;
     int act;
     int tiles_n, nwg;
-    int ng;     // XCD tile partition: N split into ng groups, M into 8/ng (kernels_gemm3.hip)
-    int dbg;    // timing experiments only (gemm_ring_kernel): 1 no C stores, 2 no epilogue, 4 no MFMA, 8 no loads in loop
+    int ng;     // XCD tile partition: N split into ng groups, M into 8/ng (kernels_gemm10.hip)
+    int dbg;    // measurement builds only (gemm_p8_kernel): 1 no C stores, 2 no epilogue, 4 no MFMA, 8 no loads in loop
     int out_f16; // C and `res` are f16_t rows (residual stream of the bf16 engine mode); bf16 inputs, p8 + generic kernel only
     int shared;  // other contexts run beside this launch (serving schedule): tile choice by FLOP/byte, not by round fill
 };
 hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t s);
-// second-generation bf16 kernel (direct-to-LDS staging, swizzled LDS, LDS-staged epilogue)
-bool gemm_dlds_supported(const GemmArgs& g, bool in_f32, bool out_f32);
-hipError_t launch_gemm_dlds(GemmArgs g, bool out_f32, hipStream_t s);
-hipError_t launch_gemm_ring(GemmArgs g, bool out_f32, hipStream_t s);   // 256x128 tile, 3-stage ring
-hipError_t launch_gemm_ring256(GemmArgs g, bool out_f32, hipStream_t s); // 256x256x32, 8 waves of 128x64, 4-stage ring
 hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s);     // 256x256x64, half-tile pipeline, staggered wave groups
 bool gemm_p8_supports(const GemmArgs& g);
 int gemm_p8_cost(const GemmArgs& g, int mh);   // rounds x relative tile time of the 256-row (mh=128) / 192-row (96) tile
-void set_gemm_impl(int impl);   // -1 auto, 0 first-generation kernel only, 1 force direct-to-LDS kernel
+void set_gemm_impl(int impl);   // measurement builds: -1 auto, 0 tile kernel only, 9 LDS-DMA kernel wherever it can run (+ dbg bits << 8)
 
 // ---- decode-step GEMM chain (kernels_dgemm.hip): LayerNorm folded into the consumer, row partials from the producer
 struct DGemmArgs {

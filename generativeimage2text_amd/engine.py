@@ -28,11 +28,14 @@ EXPORTED_SYMBOLS = [
     "gitmi_generate", "gitmi_search_begin", "gitmi_search_rows", "gitmi_search_advance",
     "gitmi_search_finish", "gitmi_profile_enable", "gitmi_profile_read", "gitmi_set_graph",
     "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_dgemm", "gitmi_op_dgemm_res",
-    "gitmi_op_vocab_topm", "gitmi_debug_set_gemm_impl", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
+    "gitmi_op_vocab_topm", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
     "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after", "gitmi_op_sample_rows",
-    "gitmi_generate_encode", "gitmi_generate_decode", "gitmi_search_done_count",
-    "gitmi_debug_import_stage", "gitmi_debug_head_from", "gitmi_set_trie", "gitmi_operand_dtype",
-    "gitmi_clone_sized", "gitmi_set_decode_group", "gitmi_group_decode", "gitmi_set_shared_device",
+    "gitmi_search_done_count", "gitmi_set_trie", "gitmi_operand_dtype", "gitmi_set_shared_device",
+]
+# libgitmi_exp.so only (include/gitmi_experiment.h): schedules that measured slower than the default, debug hooks
+EXPERIMENT_SYMBOLS = [
+    "gitmi_generate_encode", "gitmi_generate_decode", "gitmi_clone_sized", "gitmi_set_decode_group", "gitmi_group_decode",
+    "gitmi_debug_import_stage", "gitmi_debug_head_from", "gitmi_debug_set_gemm_impl",
 ]
 
 
@@ -102,16 +105,12 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     lib.gitmi_prefill.argtypes = [vp, vp]
     lib.gitmi_step_logits.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.gitmi_generate.argtypes = [vp, C.POINTER(vp), i32, i32, vp, i32, C.POINTER(GitmiSearch), vp, vp, vp, vp]
-    lib.gitmi_generate_encode.argtypes = [vp, C.POINTER(vp), i32, i32, vp, i32, C.POINTER(GitmiSearch), vp]
-    lib.gitmi_generate_decode.argtypes = [vp, i32, i32, vp, i32, C.POINTER(GitmiSearch), vp, vp, vp, vp]
     lib.gitmi_search_begin.argtypes = [vp, C.POINTER(GitmiSearch), i32, vp, i32, i32, vp]
     lib.gitmi_search_rows.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]
     lib.gitmi_search_advance.argtypes = [vp, vp, vp]
     lib.gitmi_search_finish.argtypes = [vp, vp, vp, vp, vp]
     lib.gitmi_search_done_count.argtypes = [vp, C.POINTER(C.c_int), vp]
     lib.gitmi_set_trie.argtypes = [vp, i32, vp, vp, vp]
-    lib.gitmi_debug_import_stage.argtypes = [vp, vp, i32, vp]
-    lib.gitmi_debug_head_from.argtypes = [vp, vp, i32, vp, vp]
     lib.gitmi_profile_enable.argtypes = [vp, i32]
     lib.gitmi_profile_read.argtypes = [vp, C.POINTER(GitmiProfile)]
     lib.gitmi_set_graph.argtypes = [vp, i32]
@@ -126,21 +125,26 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     lib.gitmi_op_vocab_topm.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]
     lib.gitmi_generate_prefixed.argtypes = [vp, C.POINTER(vp), i32, i32, vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                             i32, C.POINTER(GitmiSearch), vp, vp, vp, vp, vp]
-    lib.gitmi_debug_set_gemm_impl.argtypes = [i32]
     lib.gitmi_clone.argtypes = [vp, C.POINTER(vp)]
-    lib.gitmi_clone_sized.argtypes = [vp, i32, C.POINTER(vp)]
-    lib.gitmi_set_decode_group.argtypes = [vp, vp, i32]
-    lib.gitmi_group_decode.argtypes = [vp, i32, i32, vp, i32, C.POINTER(GitmiSearch), vp, vp, vp, vp]
     lib.gitmi_preprocess_image.argtypes = [vp, i32, i32, i32, vp, C.c_size_t, vp, vp]
     lib.gitmi_preprocess_image_to.argtypes = [vp, i32, i32, i32, i32, vp, C.c_size_t, vp, vp]
     lib.gitmi_set_image_shape.argtypes = [vp, i32, i32, vp]
     lib.gitmi_op_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_kv_repack.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_sample_rows.argtypes = [vp, i32, i32, C.c_float, i32, C.c_float, i32, C.c_uint64, i32, vp, vp, vp, vp]
-    for name in EXPORTED_SYMBOLS:
+    if operands == "exp":
+        lib.gitmi_generate_encode.argtypes = [vp, C.POINTER(vp), i32, i32, vp, i32, C.POINTER(GitmiSearch), vp]
+        lib.gitmi_generate_decode.argtypes = [vp, i32, i32, vp, i32, C.POINTER(GitmiSearch), vp, vp, vp, vp]
+        lib.gitmi_debug_import_stage.argtypes = [vp, vp, i32, vp]
+        lib.gitmi_debug_head_from.argtypes = [vp, vp, i32, vp, vp]
+        lib.gitmi_debug_set_gemm_impl.argtypes = [i32]
+        lib.gitmi_clone_sized.argtypes = [vp, i32, C.POINTER(vp)]
+        lib.gitmi_set_decode_group.argtypes = [vp, vp, i32]
+        lib.gitmi_group_decode.argtypes = [vp, i32, i32, vp, i32, C.POINTER(GitmiSearch), vp, vp, vp, vp]
+    for name in EXPORTED_SYMBOLS + (EXPERIMENT_SYMBOLS if operands == "exp" else []):
         if name not in ("gitmi_last_error", "gitmi_destroy"):
             getattr(lib, name).restype = C.c_int
-    if lib.gitmi_abi_version() != 6:
+    if lib.gitmi_abi_version() != 7:
         raise GitmiError("libgitmi.so ABI version mismatch")
     lib.gitmi_operand_dtype.restype = C.c_int
     if lib.gitmi_operand_dtype() != {"bf16": DTYPE_BF16, "f16": DTYPE_F16, "exp": DTYPE_BF16}[operands]:
@@ -149,12 +153,23 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     return lib
 
 
-def _ck(rc: int) -> None:
+def _experiment_only(lib, name: str):
+    """An entry point of include/gitmi_experiment.h: present in libgitmi_exp.so only."""
+    try:
+        return getattr(lib, name)
+    except AttributeError:
+        raise GitmiError(f"{name} is exported by the measurement build only (libgitmi_exp.so): call "
+                         f"generativeimage2text_amd.engine.use_experiment_build() before creating the engine") from None
+
+
+def _ck(rc: int, lib=None) -> None:
+    """Raise GitmiError with the failing library's own message (the message is thread-local PER LIBRARY and is not cleared
+    by later successful calls: with both libgitmi.so and libgitmi_f16.so loaded, asking every library would report the other's
+    stale text as well)."""
     if rc != 0:
-        # the message is thread-local per library: report whichever loaded library holds one
-        msgs = [(k, lib.gitmi_last_error().decode("utf-8", "replace")) for k, lib in _libs.items()]
-        msgs = [(k, m) for k, m in msgs if m]
-        raise GitmiError(msgs[0][1] if len(msgs) == 1 else " | ".join(f"[{k} library] {m}" for k, m in msgs) or "gitmi call failed")
+        libs = [lib] if lib is not None else list(_libs.values())
+        msgs = [m for m in ((l.gitmi_last_error() or b"").decode("utf-8", "replace") for l in libs) if m]
+        raise GitmiError(" | ".join(msgs) or "gitmi call failed")
 
 
 def _stream() -> int:
@@ -201,12 +216,15 @@ class Engine:
         self.n_tok = (c.image_size // c.patch) ** 2 + 1          # tokens per frame at the CURRENT input resolution
         self._hw = (int(c.image_size), int(c.image_size))
         self._h = C.c_void_p()
-        _ck(self.lib.gitmi_create(C.byref(c), self.device, C.byref(self._h)))
+        self._ck(self.lib.gitmi_create(C.byref(c), self.device, C.byref(self._h)))
         self._finalized = False
         self._cur_B = 0
         self._cur_F = 0
 
     # -- lifecycle ---------------------------------------------------------------------------
+    def _ck(self, rc: int) -> None:
+        _ck(rc, self.lib)
+
     def clone(self, max_batch: Optional[int] = None) -> "Engine":
         """A second context sharing this engine's packed weights (own workspaces / KV caches / graph),
         for keeping several batches in flight on different streams.  Keep `self` alive while it is used.
@@ -219,7 +237,10 @@ class Engine:
         other.n_tok = (self.c.image_size // self.c.patch) ** 2 + 1
         other._hw = (int(self.c.image_size), int(self.c.image_size))
         other._h = C.c_void_p()
-        _ck(self.lib.gitmi_clone_sized(self._h, int(other.c.max_batch), C.byref(other._h)))
+        if max_batch is None or int(max_batch) == int(self.c.max_batch):
+            self._ck(self.lib.gitmi_clone(self._h, C.byref(other._h)))
+        else:       # a decode-group context (measurement build)
+            self._ck(_experiment_only(self.lib, "gitmi_clone_sized")(self._h, int(other.c.max_batch), C.byref(other._h)))
         other._finalized, other._cur_B, other._cur_F = True, 0, 0
         other._parent = self
         return other
@@ -245,8 +266,8 @@ class Engine:
             if t.dtype not in (torch.float32, torch.bfloat16, torch.float16):
                 t = t.float()
             shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
-            _ck(self.lib.gitmi_load_tensor(self._h, key.encode(), t.data_ptr(), shape, t.dim(), _torch_dtype_code(t)))
-        _ck(self.lib.gitmi_finalize_weights(self._h))
+            self._ck(self.lib.gitmi_load_tensor(self._h, key.encode(), t.data_ptr(), shape, t.dim(), _torch_dtype_code(t)))
+        self._ck(self.lib.gitmi_finalize_weights(self._h))
         self._finalized = True
 
     # -- phases --------------------------------------------------------------------------------
@@ -254,7 +275,7 @@ class Engine:
         """Input resolution of the following calls (CLIP/model.py:243-251: token grid (H//patch) x (W//patch),
         positional table resized on the device).  Called automatically from the frames' shape."""
         if (H, W) != self._hw:
-            _ck(self.lib.gitmi_set_image_shape(self._h, int(H), int(W), _stream()))
+            self._ck(self.lib.gitmi_set_image_shape(self._h, int(H), int(W), _stream()))
             self._hw = (int(H), int(W))
             self.n_tok = (H // self.c.patch) * (W // self.c.patch) + 1
 
@@ -274,18 +295,18 @@ class Engine:
         out = None
         if return_features:
             out = torch.empty(B, F_eff * self.n_tok, self.c.vit_width, device=keep[0].device, dtype=torch.float32)
-        _ck(self.lib.gitmi_encode_frames(self._h, arr, F, B, _ptr(out), _stream()))
+        self._ck(self.lib.gitmi_encode_frames(self._h, arr, F, B, _ptr(out), _stream()))
         self._cur_B, self._cur_F = B, F_eff
         return out
 
     def prefill(self) -> None:
-        _ck(self.lib.gitmi_prefill(self._h, _stream()))
+        self._ck(self.lib.gitmi_prefill(self._h, _stream()))
 
     def step_logits(self, tokens: torch.Tensor) -> torch.Tensor:
         tokens = tokens.to(device=f"cuda:{self.device}", dtype=torch.int64).contiguous()
         R, t = tokens.shape
         out = torch.empty(R, self.c.vocab, device=tokens.device, dtype=torch.float32)
-        _ck(self.lib.gitmi_step_logits(self._h, tokens.data_ptr(), R, t, out.data_ptr(), _stream()))
+        self._ck(self.lib.gitmi_step_logits(self._h, tokens.data_ptr(), R, t, out.data_ptr(), _stream()))
         return out
 
     @staticmethod
@@ -314,7 +335,7 @@ class Engine:
         if prefix is not None:
             pfx = prefix.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
             P = int(pfx.numel())
-        _ck(self.lib.gitmi_generate(self._h, arr, len(keep), B, _ptr(pfx), P, C.byref(search), tokens.data_ptr(),
+        self._ck(self.lib.gitmi_generate(self._h, arr, len(keep), B, _ptr(pfx), P, C.byref(search), tokens.data_ptr(),
                                     logprobs.data_ptr(), info.data_ptr(), _stream()))
         self._cur_B = B
         if sync:
@@ -349,14 +370,14 @@ class Engine:
         if prefix is not None:
             pfx = prefix.to(device=keep[0].device, dtype=torch.int64).reshape(-1).contiguous()
             P = int(pfx.numel())
-        _ck(self.lib.gitmi_generate_encode(self._h, arr, len(keep), B, _ptr(pfx), P, C.byref(search), _stream()))
+        self._ck(_experiment_only(self.lib, "gitmi_generate_encode")(self._h, arr, len(keep), B, _ptr(pfx), P, C.byref(search), _stream()))
         self._cur_B, self._half = B, (len(keep), B, pfx, P)
 
     def set_decode_group(self, group: Optional["Engine"], image_offset: int = 0) -> None:
         """Make this context a MEMBER of `group` (a clone(max_batch=...) context): generate_encode() writes the image K/V of
         its request into the group's cache at `image_offset`, group.group_decode() searches over all members' images in
         ONE decode chain.  group=None detaches."""
-        _ck(self.lib.gitmi_set_decode_group(self._h, group._h if group is not None else None, int(image_offset)))
+        self._ck(_experiment_only(self.lib, "gitmi_set_decode_group")(self._h, group._h if group is not None else None, int(image_offset)))
         self._group = group
 
     def group_decode(self, n_frames: int, n_images: int, search: GitmiSearch, prefix: Optional[torch.Tensor] = None,
@@ -372,7 +393,7 @@ class Engine:
         tokens = torch.empty(n_images, search.max_steps, device=dev, dtype=torch.int64)
         logprobs = torch.empty(n_images, device=dev, dtype=torch.float32)
         info = torch.empty(4, device=dev, dtype=torch.int32)
-        _ck(self.lib.gitmi_group_decode(self._h, int(n_frames), int(n_images), _ptr(pfx), P, C.byref(search),
+        self._ck(_experiment_only(self.lib, "gitmi_group_decode")(self._h, int(n_frames), int(n_images), _ptr(pfx), P, C.byref(search),
                                         tokens.data_ptr(), logprobs.data_ptr(), info.data_ptr(), _stream()))
         if sync:
             torch.cuda.synchronize(self.device)
@@ -385,7 +406,7 @@ class Engine:
         tokens = torch.empty(B, search.max_steps, device=dev, dtype=torch.int64)
         logprobs = torch.empty(B, device=dev, dtype=torch.float32)
         info = torch.empty(4, device=dev, dtype=torch.int32)
-        _ck(self.lib.gitmi_generate_decode(self._h, F, B, _ptr(pfx), P, C.byref(search), tokens.data_ptr(),
+        self._ck(_experiment_only(self.lib, "gitmi_generate_decode")(self._h, F, B, _ptr(pfx), P, C.byref(search), tokens.data_ptr(),
                                            logprobs.data_ptr(), info.data_ptr(), _stream()))
         if sync:
             torch.cuda.current_stream().synchronize()
@@ -412,7 +433,7 @@ class Engine:
         info = torch.empty(4, device=dev, dtype=torch.int32)
         lens_c = (C.c_int32 * Q)(*lens)
         img_c = None if image_of is None else (C.c_int32 * Q)(*[int(i) for i in image_of])
-        _ck(self.lib.gitmi_generate_prefixed(self._h, arr, len(keep), B, table.data_ptr(), ld, lens_c, img_c, Q,
+        self._ck(self.lib.gitmi_generate_prefixed(self._h, arr, len(keep), B, table.data_ptr(), ld, lens_c, img_c, Q,
                                              C.byref(search), tokens.data_ptr(), logprobs.data_ptr(), sent.data_ptr(),
                                              info.data_ptr(), _stream()))
         self._cur_B = B
@@ -424,53 +445,53 @@ class Engine:
     def search_begin(self, search: GitmiSearch, start: torch.Tensor, vocab: int) -> None:
         start = start.to("cpu", torch.int64).contiguous()
         B, P = start.shape
-        _ck(self.lib.gitmi_search_begin(self._h, C.byref(search), B, start.data_ptr(), P, vocab, _stream()))
+        self._ck(self.lib.gitmi_search_begin(self._h, C.byref(search), B, start.data_ptr(), P, vocab, _stream()))
         self._search_k = search.beam_size
         self._search_B = B
         self._search_T = search.max_steps
 
     def search_rows(self) -> torch.Tensor:
         R, t = C.c_int(), C.c_int()
-        _ck(self.lib.gitmi_search_rows(self._h, None, C.byref(R), C.byref(t), _stream()))
+        self._ck(self.lib.gitmi_search_rows(self._h, None, C.byref(R), C.byref(t), _stream()))
         out = torch.empty(R.value, t.value, device=f"cuda:{self.device}", dtype=torch.int64)
-        _ck(self.lib.gitmi_search_rows(self._h, out.data_ptr(), C.byref(R), C.byref(t), _stream()))
+        self._ck(self.lib.gitmi_search_rows(self._h, out.data_ptr(), C.byref(R), C.byref(t), _stream()))
         return out
 
     def search_advance(self, logits: torch.Tensor) -> None:
         logits = logits.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
         self._keep_logits = logits
-        _ck(self.lib.gitmi_search_advance(self._h, logits.data_ptr(), _stream()))
+        self._ck(self.lib.gitmi_search_advance(self._h, logits.data_ptr(), _stream()))
 
     def set_trie(self, child_off, child_tok, child_node) -> None:
         """Token trie of the "trie" search kind as CSR int32 arrays (include/gitmi.h gitmi_set_trie); None removes it."""
         if child_off is None:
-            _ck(self.lib.gitmi_set_trie(self._h, 0, None, None, None))
+            self._ck(self.lib.gitmi_set_trie(self._h, 0, None, None, None))
             return
         off = torch.as_tensor(child_off, dtype=torch.int32).cpu().contiguous()
         tok = torch.as_tensor(child_tok, dtype=torch.int32).cpu().contiguous()
         node = torch.as_tensor(child_node, dtype=torch.int32).cpu().contiguous()
         assert off.numel() >= 2 and tok.numel() == node.numel() == int(off[-1])
-        _ck(self.lib.gitmi_set_trie(self._h, int(off.numel()) - 1, off.data_ptr(), tok.data_ptr() if tok.numel() else None,
+        self._ck(self.lib.gitmi_set_trie(self._h, int(off.numel()) - 1, off.data_ptr(), tok.data_ptr() if tok.numel() else None,
                                     node.data_ptr() if node.numel() else None))
 
     # -- error attribution hooks (tools/error_attribution.py) ---------------------------------------
     def debug_import_stage(self, src: "Engine", stage: int) -> None:
         """Take the image features (stage 1) or features + image K/V of every decoder layer (stage 2) from `src`, a
         context of the same model in the other precision; step_logits() then continues from there."""
-        _ck(self.lib.gitmi_debug_import_stage(self._h, src._h, int(stage), _stream()))
+        self._ck(_experiment_only(self.lib, "gitmi_debug_import_stage")(self._h, src._h, int(stage), _stream()))
         self._cur_B = src._cur_B
 
     def debug_head_from(self, src: "Engine", R: int) -> torch.Tensor:
         """This (bf16) context's fused vocabulary head on the last hidden state of src's (fp32) latest step_logits."""
         out = torch.empty(R, self.c.vocab, device=f"cuda:{self.device}", dtype=torch.float32)
-        _ck(self.lib.gitmi_debug_head_from(self._h, src._h, int(R), out.data_ptr(), _stream()))
+        self._ck(_experiment_only(self.lib, "gitmi_debug_head_from")(self._h, src._h, int(R), out.data_ptr(), _stream()))
         torch.cuda.current_stream().synchronize()
         return out
 
     def search_done_count(self) -> int:
         """Sentences of the running search that need no further step (synchronises the stream)."""
         n = C.c_int()
-        _ck(self.lib.gitmi_search_done_count(self._h, C.byref(n), _stream()))
+        self._ck(self.lib.gitmi_search_done_count(self._h, C.byref(n), _stream()))
         return int(n.value)
 
     def search_finish(self):
@@ -478,7 +499,7 @@ class Engine:
         tokens = torch.empty(self._search_B, self._search_T, device=dev, dtype=torch.int64)
         logprobs = torch.empty(self._search_B, device=dev, dtype=torch.float32)
         info = torch.empty(4, device=dev, dtype=torch.int32)
-        _ck(self.lib.gitmi_search_finish(self._h, tokens.data_ptr(), logprobs.data_ptr(), info.data_ptr(), _stream()))
+        self._ck(self.lib.gitmi_search_finish(self._h, tokens.data_ptr(), logprobs.data_ptr(), info.data_ptr(), _stream()))
         torch.cuda.current_stream().synchronize()
         return tokens, logprobs, info
 
@@ -486,30 +507,30 @@ class Engine:
     def profile_enable(self, on) -> None:
         """False/0 off; True/1 eager launches with per-launch HIP events; 2 graph replays split into an
         (encode + prefill) graph and a decode graph with events between them."""
-        _ck(self.lib.gitmi_profile_enable(self._h, int(on)))
+        self._ck(self.lib.gitmi_profile_enable(self._h, int(on)))
 
     def profile_read(self) -> Dict[str, float]:
         p = GitmiProfile()
-        _ck(self.lib.gitmi_profile_read(self._h, C.byref(p)))
+        self._ck(self.lib.gitmi_profile_read(self._h, C.byref(p)))
         return p.as_dict()
 
     def set_shared_device(self, on: bool = True) -> None:
         """Serving policy: other contexts run beside this one (kernel shapes by whole-device cost; bit-identical results).
         Clones made afterwards inherit it."""
-        _ck(self.lib.gitmi_set_shared_device(self._h, 1 if on else 0))
+        self._ck(self.lib.gitmi_set_shared_device(self._h, 1 if on else 0))
 
     def set_encode_after(self, other: Optional["Engine"]) -> None:
         """Serving schedule: this context's image encoder starts only after `other`'s (most recently submitted) has
         finished; chain contexts in a ring in submission order (one encoder in flight, decode chains fill in)."""
-        _ck(self.lib.gitmi_set_encode_after(self._h, other._h if other is not None else None))
+        self._ck(self.lib.gitmi_set_encode_after(self._h, other._h if other is not None else None))
 
     def set_temporal_embedding(self, on: bool) -> None:
         """on (default): frames come as a list -> frame i gets img_temperal_embedding[i]; off: a bare image tensor
         (decoder.py:845-857 adds the embedding only in the list branch)."""
-        _ck(self.lib.gitmi_set_temporal_embedding(self._h, 1 if on else 0))
+        self._ck(self.lib.gitmi_set_temporal_embedding(self._h, 1 if on else 0))
 
     def set_graph(self, on: bool) -> None:
-        _ck(self.lib.gitmi_set_graph(self._h, 1 if on else 0))
+        self._ck(self.lib.gitmi_set_graph(self._h, 1 if on else 0))
 
 
 # ---- single-kernel entry points (unit parity tests) -----------------------------------------------
@@ -649,8 +670,9 @@ def op_vocab_topm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, mtop: in
 
 
 def set_gemm_impl(impl: int) -> None:
-    """-1 auto, 0 first-generation GEMM kernel, 1 direct-to-LDS kernel (A/B measurements)."""
-    _ck(load_library().gitmi_debug_set_gemm_impl(int(impl)))
+    """Measurement build only (use_experiment_build()): -1 auto, 0 register-staged tile kernel only, 9 the LDS-DMA kernel
+    wherever it can run; 9 | (bits << 8): 64 / 128 force its 192- / 256-row tile (tools/gemm_bench.py lists the others)."""
+    _ck(_experiment_only(load_library(), "gitmi_debug_set_gemm_impl")(int(impl)))
 
 
 def op_attn_decode(qkv, img_k, img_v, txt_k, txt_v, kv_src, B, H, N_img, T_max, pos, beams, dbg=0):

@@ -1,4 +1,6 @@
-"""GPU: decode groups (gitmi_clone_sized / gitmi_set_decode_group / gitmi_group_decode, include/gitmi.h ABI 6).
+"""GPU: decode groups (gitmi_clone_sized / gitmi_set_decode_group / gitmi_group_decode, include/gitmi_experiment.h: the
+measurement build -- the schedule measured slower than the default in rounds 3 and 4 and left the product ABI; it stays
+tested so that the measurement can be repeated).
 
 Several contexts encode + prefill their OWN requests and share ONE decode chain.  Captions do not depend on their batch
 neighbours (the reference decodes every batch on its own, decoder.py:313-417), so the bar is: every request gets bit for
@@ -7,7 +9,7 @@ arithmetic) -- over several rounds of hipGraph replays (the cross-context orderi
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("experiment_build")]
 
 
 def _setup(precision, sizes, beams=4, T=16, frames=1, cfg_name="TINY"):
@@ -25,7 +27,7 @@ def _setup(precision, sizes, beams=4, T=16, frames=1, cfg_name="TINY"):
     return O, cfg, eng, members, group, cap
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("precision", ["f32", "bf16"])          # the measurement build has bf16 operands
 def test_group_decode_equals_each_requests_own_call(precision):
     """Two / three members, greedy and beam-4 with a shared prefix, graph replays and eager launches, three rounds with
     different images per round: rows of the group's decode == the rows of each request's own generate() call."""

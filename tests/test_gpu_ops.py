@@ -40,33 +40,35 @@ def test_gemm_bf16(M, N, K, act):
     assert (out_b - ref_b).abs().max().item() < 1e-2 * max(1.0, ref_b.abs().max().item())
 
 
+@pytest.mark.usefixtures("experiment_build")
 @pytest.mark.parametrize("M,N,K", [(1000, 512, 128), (777, 256, 192), (2100, 768, 768), (515, 1024, 3072)])
 @pytest.mark.parametrize("act", [0, 1, 2])
-@pytest.mark.parametrize("tile", [9 | (128 << 8), 9 | (64 << 8)])          # forced 256x256 / 192x256 tile
-def test_gemm_bf16_p8_variant(M, N, K, act, tile):
-    """The 256x256 half-tile pipeline kernel (kernels_gemm10.hip), forced: shortest K (2 and 3 K tiles), ragged M,
-    every epilogue; it must also equal the 256x128 ring kernel bit for bit (same K order)."""
+def test_gemm_bf16_p8_variant(M, N, K, act):
+    """The 256x256 half-tile pipeline kernel (kernels_gemm10.hip) with its tile height forced (measurement build): shortest K
+    (2 and 3 K tiles), ragged M, every epilogue; the 192-row and the 256-row tile must agree bit for bit (same K order), and
+    both stay within summation-order error of the register-staged tile kernel (impl 0)."""
     from generativeimage2text_amd import engine as E
     A = _rand(M, K, seed=11).bfloat16()
     W = _rand(N, K, seed=12, scale=K ** -0.5).bfloat16()
     bias = _rand(N, seed=13)
     res = _rand(M, N, seed=14)
     ref = _act(A.double() @ W.double().t() + bias.double(), act)
+    outs = {}
     try:
-        E.set_gemm_impl(tile)
-        out = E.op_gemm(A.cuda(), W.cuda(), bias.cuda(), res.cuda(), act, torch.float32).cpu()
-        out_b = E.op_gemm(A.cuda(), W.cuda(), bias.cuda(), None, act, torch.bfloat16).cpu()
-        out_br = E.op_gemm(A.cuda(), W.cuda(), None, res.cuda(), act, torch.bfloat16).cpu()
-        E.set_gemm_impl(2)
-        ring = E.op_gemm(A.cuda(), W.cuda(), bias.cuda(), res.cuda(), act, torch.float32).cpu()
-        ring_b = E.op_gemm(A.cuda(), W.cuda(), bias.cuda(), None, act, torch.bfloat16).cpu()
+        for tile in (9 | (128 << 8), 9 | (64 << 8), 0):
+            E.set_gemm_impl(tile)
+            outs[tile] = (E.op_gemm(A.cuda(), W.cuda(), bias.cuda(), res.cuda(), act, torch.float32).cpu(),
+                          E.op_gemm(A.cuda(), W.cuda(), bias.cuda(), None, act, torch.bfloat16).cpu(),
+                          E.op_gemm(A.cuda(), W.cuda(), None, res.cuda(), act, torch.bfloat16).cpu())
     finally:
         E.set_gemm_impl(-1)
-    assert (out.double() - (ref + res.double())).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
-    assert (out_b.double() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
     ref_br = _act(A.double() @ W.double().t(), act) + res.double()
-    assert (out_br.double() - ref_br).abs().max().item() < 2e-2 * max(1.0, ref_br.abs().max().item())
-    assert torch.equal(out, ring) and torch.equal(out_b, ring_b)
+    for tile, (out, out_b, out_br) in outs.items():
+        assert (out.double() - (ref + res.double())).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), tile
+        assert (out_b.double() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item()), tile
+        assert (out_br.double() - ref_br).abs().max().item() < 2e-2 * max(1.0, ref_br.abs().max().item()), tile
+    hi, lo = outs[9 | (128 << 8)], outs[9 | (64 << 8)]
+    assert all(torch.equal(a, b) for a, b in zip(hi, lo))
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (64, 768, 3072), (300, 1002, 128), (1, 128, 64), (130, 70, 592)])

@@ -732,6 +732,7 @@ def test_generate_with_sampling_search():
         assert (a["predictions"][:, 0] == cfg.sos).all() and torch.isfinite(a["logprobs"]).all()
 
 
+@pytest.mark.usefixtures("experiment_build")
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
 def test_generate_as_two_submissions_equals_one_call(precision):
     """gitmi_generate_encode + gitmi_generate_decode (a call split into image encoder + prefill and search + results, for

@@ -13,8 +13,8 @@ from conftest import ROOT
 from generativeimage2text_amd import configs, engine, inference, model, tsv_io
 
 
-def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "gitmi.h")).read()
+def _declared_functions(header="gitmi.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(gitmi_[a-z_0-9]+)\s*\(", src)))
 
@@ -26,7 +26,40 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(engine.EXPORTED_SYMBOLS) == declared
-    assert lib.gitmi_abi_version() == 6
+    assert lib.gitmi_abi_version() == 7
+    assert len(declared) <= 40                  # the product ABI stays small: schedules that lost and debug hooks live elsewhere
+
+
+def test_product_libraries_export_the_c_abi_and_nothing_else():
+    """nm -D: exactly the entry points of include/gitmi.h (no C++ launcher symbols, no experiment entry points), no getenv
+    in the product (it reads no environment); the measurement build adds exactly include/gitmi_experiment.h (+ one timing
+    switch of the decode-chain unit entry point)."""
+    import shutil
+    import subprocess
+    if shutil.which("nm") is None:
+        pytest.skip("no nm")
+    declared = set(_declared_functions())
+    extra = set(_declared_functions("gitmi_experiment.h")) - declared
+    assert extra == set(engine.EXPERIMENT_SYMBOLS)
+
+    def dyn(path):
+        out = subprocess.run(["nm", "-D", path], capture_output=True, text=True, check=True).stdout.splitlines()
+        defined = {l.split()[-1] for l in out if " T " in l}
+        undefined = {l.split()[-1].split("@")[0] for l in out if " U " in l}
+        return defined, undefined
+    for path in (engine.LIB_PATH, engine.LIB_PATH_F16):
+        if not os.path.exists(path):
+            pytest.skip("library not built")
+        defined, undefined = dyn(path)
+        assert defined == declared, (path, sorted(defined ^ declared))
+        assert "getenv" not in undefined and "secure_getenv" not in undefined, path
+        lib = engine.load_library("bf16" if path == engine.LIB_PATH else "f16")
+        for name in extra:
+            assert not hasattr(lib, name), name
+    if os.path.exists(engine.LIB_PATH_EXP):
+        defined, undefined = dyn(engine.LIB_PATH_EXP)
+        assert defined == declared | extra | {"gitmi_debug_set_dgemm"}
+        assert "getenv" in undefined
 
 
 def test_struct_layouts_match_header():
@@ -332,7 +365,7 @@ def test_both_operand_builds_load_and_identify_themselves():
     same ABI, every declared symbol, and each says which 16-bit operand type it was built for."""
     a, b = engine.load_library("bf16"), engine.load_library("f16")
     assert a.gitmi_operand_dtype() == engine.DTYPE_BF16 and b.gitmi_operand_dtype() == engine.DTYPE_F16
-    assert a.gitmi_abi_version() == b.gitmi_abi_version() == 6
+    assert a.gitmi_abi_version() == b.gitmi_abi_version() == 7
     for name in engine.EXPORTED_SYMBOLS:
         getattr(b, name)
 

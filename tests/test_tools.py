@@ -171,7 +171,10 @@ def _run_bench_with_fakes(monkeypatch, capsys, argv):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BENCH_GEMM_IMPL"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline"] + argv)
-    bench.main()
+    try:
+        bench.main()
+    finally:
+        E.use_experiment_build(False)           # --experiment flips a module switch
     line = capsys.readouterr().out.strip().splitlines()[-1]
     return json.loads(line), log
 
@@ -189,7 +192,7 @@ def test_bench_control_flow_all_schedules(monkeypatch, capsys):
     timed = [e for e in log if e[0] == "generate"]
     assert len(timed) >= 4 + 3 + 8                      # priming pass over the contexts + warm-up + timed steps (+ roofline passes)
     # phased: every decode half follows its own encode half, groups of G
-    d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "10", "--warmup", "4", "--phased", "4"])
+    d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "10", "--warmup", "4", "--phased", "4", "--experiment"])
     assert d["config"]["schedule"].startswith("phased: groups of 4") and d["config"]["contexts_in_flight"] == 4
     halves = [e[0] for e in log if e[0] in ("encode", "decode")]
     assert halves.count("encode") == halves.count("decode") == 4 + 4 + 10
@@ -202,7 +205,7 @@ def test_bench_control_flow_all_schedules(monkeypatch, capsys):
     assert len(passes) == 4 + 2 + 4                     # priming (one pass per context), warm-up 4 steps, 8 timed steps
     # decode groups: every request encoded by its own member context, one decode per pair of requests; the serving
     # policy (gitmi_set_shared_device) is on for every context of a multi-context run
-    d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--warmup", "3", "--decode-group", "2"])
+    d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--warmup", "3", "--decode-group", "2", "--experiment"])
     assert "2 requests per decode chain (128 rows)" in d["config"]["schedule"] and d["warmup"] == 4 and d["config"]["shared_device_policy"]
     assert d["roofline_decode"]["rows_per_step"] == 128
     ev = [e for e in log if e[0] in ("encode", "group_decode")]
@@ -212,7 +215,11 @@ def test_bench_control_flow_all_schedules(monkeypatch, capsys):
     with pytest.raises(SystemExit):
         _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "7", "--coalesce", "2"])
     with pytest.raises(SystemExit):
-        _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--decode-group", "3"])
+        _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--decode-group", "3", "--experiment"])
+    # the schedules that lost live in the measurement build: without --experiment they are refused
+    for flags in (["--decode-group", "2"], ["--phased", "4"]):
+        with pytest.raises(SystemExit, match="measurement build"):
+            _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--warmup", "4"] + flags)
 
 
 def test_bench_reads_the_pmc_summary_taken_for_this_csrc(tmp_path, monkeypatch):

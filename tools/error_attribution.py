@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--model", default="GIT_BASE", choices=sorted(CASES))
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
+    from generativeimage2text_amd.engine import use_experiment_build
+    use_experiment_build(True)          # these hooks / schedules are exported by libgitmi_exp.so only
     from generativeimage2text_amd.configs import config_for_model
     from generativeimage2text_amd.engine import Engine
     from generativeimage2text_amd.synthetic import random_frames, random_state_dict

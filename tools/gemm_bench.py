@@ -1,9 +1,12 @@
 #!/usr/bin/env python
-"""A/B micro-benchmark of the large-M bf16 GEMM variants on the GIT_BASE bs=64 shapes (random data)."""
+"""A/B micro-benchmark of the large-M bf16 GEMM variants on the GIT_BASE bs=64 shapes (random data).
+impl codes (gitmi_debug_set_gemm_impl): 0 tile kernel, 9 LDS-DMA kernel; 9 | (bits << 8) with bits 64 / 128 = 192- / 256-row tile,
+256 staged fp32 epilogue, 512 plain stores, 1024 / 2048 / 4096 / 8192 = XCD partition ng 1 / 2 / 4 / 8."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from generativeimage2text_amd import engine as E
+E.use_experiment_build(True)          # gitmi_debug_set_gemm_impl lives in libgitmi_exp.so
 
 SHAPES = [  # (name, M, N, K, out dtype, act, residual)
     ("vit.qkv", 12608, 2304, 768, torch.bfloat16, 0, False),
@@ -29,7 +32,7 @@ def bench(fn, reps=20):
 
 
 def main():
-    impls = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["2", "6", "9"])]
+    impls = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else [str(9 | (128 << 8)), str(9 | (64 << 8))])]
     g = torch.Generator().manual_seed(0)
     only = os.environ.get("GEMM_BENCH_SHAPES")         # comma-separated shape names
     for name, M, N, K, odt, act, use_res in SHAPES:

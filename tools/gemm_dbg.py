@@ -3,6 +3,7 @@ import sys, os
 sys.path.insert(0, os.getcwd())
 import torch
 from generativeimage2text_amd import engine as E
+E.use_experiment_build(True)          # gitmi_debug_set_gemm_impl lives in libgitmi_exp.so
 from tools.gemm_bench import bench
 impl = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 variants = [(0, "full"), (1, "noStore"), (2, "noEpi"), (6, "loadsOnly"), (10, "mfmaOnly")] if impl == 9 else \

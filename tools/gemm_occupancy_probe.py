@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from generativeimage2text_amd import engine as E
+E.use_experiment_build(True)          # gitmi_debug_set_gemm_impl lives in libgitmi_exp.so
 from tools.gemm_bench import bench
 g = torch.Generator().manual_seed(0)
 E.set_gemm_impl(9 | (128 << 8))          # p8, 256-row tiles forced
