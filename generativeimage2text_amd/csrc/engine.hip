@@ -208,9 +208,9 @@ struct gitmi_engine {
     // hipGraph cache for gitmi_generate
     struct GraphKey {
         int B, Q, F, P, kind, k, pn, T, H, W, ragged, ident, temb; double lp;
-        int smp, top_k; double top_p, temp, rp; unsigned long long seed;
+        int smp, top_k, nh; double top_p, temp, rp; unsigned long long seed;
         bool operator==(const GraphKey& o) const {
-            return rp == o.rp && smp == o.smp && top_k == o.top_k && top_p == o.top_p && temp == o.temp && seed == o.seed && B == o.B && Q == o.Q && F == o.F && P == o.P && kind == o.kind && k == o.k && pn == o.pn && T == o.T &&
+            return rp == o.rp && nh == o.nh && smp == o.smp && top_k == o.top_k && top_p == o.top_p && temp == o.temp && seed == o.seed && B == o.B && Q == o.Q && F == o.F && P == o.P && kind == o.kind && k == o.k && pn == o.pn && T == o.T &&
                    H == o.H && W == o.W && ragged == o.ragged && ident == o.ident && temb == o.temb && lp == o.lp;
         }
     };
@@ -568,9 +568,12 @@ static int alloc_workspaces(gitmi_engine* e) {
     }
     RCK(dev_alloc_t(e, &s.done, (size_t)c.max_batch));
     RCK(dev_alloc_t(e, &s.hyp_n, (size_t)c.max_batch));
-    RCK(dev_alloc_t(e, &s.hyp_score, (size_t)c.max_batch));
-    RCK(dev_alloc_t(e, &s.hyp_len, (size_t)c.max_batch));
-    RCK(dev_alloc_t(e, &s.hyp_tok, (size_t)c.max_batch * T));
+    RCK(dev_alloc_t(e, &s.hyp_cnt, (size_t)c.max_batch));
+    RCK(dev_alloc_t(e, &s.hyp_worst, (size_t)c.max_batch));
+    RCK(dev_alloc_t(e, &s.hyp_score, (size_t)c.max_batch * SS_NHMAX));
+    RCK(dev_alloc_t(e, &s.hyp_len, (size_t)c.max_batch * SS_NHMAX));
+    RCK(dev_alloc_t(e, &s.hyp_seq, (size_t)c.max_batch * SS_NHMAX));
+    RCK(dev_alloc_t(e, &s.hyp_tok, (size_t)c.max_batch * SS_NHMAX * T));
     RCK(dev_alloc_t(e, &s.stop, (size_t)c.max_batch));
     RCK(dev_alloc_t(e, &s.early, (size_t)c.max_batch));
     RCK(dev_alloc_t(e, &s.info, 4));
@@ -579,8 +582,8 @@ static int alloc_workspaces(gitmi_engine* e) {
     RCK(dev_alloc_t(e, &e->plen_dev, (size_t)c.max_batch));
     RCK(dev_alloc_t(e, &e->img_of_dev, (size_t)c.max_batch));
     RCK(dev_alloc_t(e, &e->trie_cursor, (size_t)c.max_batch));
-    RCK(dev_alloc_t(e, &e->out_tokens, (size_t)c.max_batch * T));
-    RCK(dev_alloc_t(e, &e->out_lp, (size_t)c.max_batch));
+    RCK(dev_alloc_t(e, &e->out_tokens, (size_t)c.max_batch * SS_NHMAX * T));
+    RCK(dev_alloc_t(e, &e->out_lp, (size_t)c.max_batch * SS_NHMAX));
     RCK(dev_alloc_t(e, &e->out_info, 4));
     RCK(dev_alloc_t(e, &e->out_sent, (size_t)c.max_batch * 2));
     HIPCK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
@@ -1205,6 +1208,9 @@ static int search_begin_impl(gitmi_engine* e, const gitmi_search* sp, int B, int
         if (!(sp->repetition_penalty >= 1.0)) return fail("search: `repetition_penalty` should be >= 1 (decoder.py:1080)");
         if (sp->max_steps > 1024) return fail("search: repetition_penalty supports histories up to 1024 tokens");
     }
+    if (sp->num_keep_best < 0 || sp->num_keep_best > SS_NHMAX) return fail("search: num_keep_best %d outside [1,%d]", sp->num_keep_best, SS_NHMAX);
+    if (sp->num_keep_best > 1 && sp->kind != GITMI_SEARCH_GENERATOR)
+        return fail("search: num_keep_best belongs to GeneratorWithBeamSearch.search (decoder.py:1087)");
     if (sp->do_sample) {
         if (sp->kind != GITMI_SEARCH_GENERATOR) return fail("search: do_sample is implemented for GeneratorWithBeamSearch (decoder.py:1146-1166) only");
         if (sp->temperature < 0) return fail("search: temperature must be > 0");
@@ -1217,6 +1223,7 @@ static int search_begin_impl(gitmi_engine* e, const gitmi_search* sp, int B, int
     // the trie search shares AutoRegressiveBeamSearch's bookkeeping (beam 1): only the candidate selection differs
     st.V = V; st.eos = c.eos; st.kind = e->trie_search ? GITMI_SEARCH_AUTOREGRESSIVE : sp->kind; st.length_penalty = sp->length_penalty;
     st.ragged = ragged ? 1 : 0;
+    st.nh = sp->num_keep_best > 1 ? sp->num_keep_best : 1;
     st.sampled = sp->do_sample ? 1 : 0;
     e->sample = *sp;
     st.start = e->start_dev; st.ld_start = c.max_text_len; st.plen = e->plen_dev;
@@ -1496,7 +1503,7 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     key.T = sp->max_steps; key.H = e->H; key.W = e->W; key.lp = sp->length_penalty;
     key.ragged = ragged ? 1 : 0; key.ident = e->img_identity ? 1 : 0; key.temb = e->use_temb ? 1 : 0;
     key.smp = sp->do_sample; key.top_k = sp->top_k; key.top_p = sp->top_p; key.temp = sp->temperature; key.seed = sp->seed;
-    key.rp = sp->repetition_penalty;
+    key.rp = sp->repetition_penalty; key.nh = sp->num_keep_best > 1 ? sp->num_keep_best : 1;
     // two graphs (encode + prefill | decode) whenever something has to happen between them: profiling events, the
     // enc_done record other contexts wait for, or the caller submits the halves itself
     const bool split = e->profile_mode == 2 || e->enc_after != nullptr || !e->enc_watchers.empty() || phase != 0;
@@ -1578,8 +1585,9 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
         e->split_encode_ms += a; e->split_decode_ms += b; e->split_calls += 1; e->split_steps += sp->max_steps - 1;
     }
     if (phase != 1) {
-        HIPCK(hipMemcpyAsync(tokens_out, e->out_tokens, (size_t)Q * sp->max_steps * sizeof(long long), hipMemcpyDeviceToDevice, x));
-        HIPCK(hipMemcpyAsync(logprob_out, e->out_lp, (size_t)Q * sizeof(float), hipMemcpyDeviceToDevice, x));
+        const size_t nout = (size_t)Q * (size_t)(sp->num_keep_best > 1 ? sp->num_keep_best : 1);      // sequences returned
+        HIPCK(hipMemcpyAsync(tokens_out, e->out_tokens, nout * sp->max_steps * sizeof(long long), hipMemcpyDeviceToDevice, x));
+        HIPCK(hipMemcpyAsync(logprob_out, e->out_lp, nout * sizeof(float), hipMemcpyDeviceToDevice, x));
         HIPCK(hipMemcpyAsync(info_out, e->out_info, 4 * sizeof(int), hipMemcpyDeviceToDevice, x));
         if (sent_out) HIPCK(hipMemcpyAsync(sent_out, e->out_sent, (size_t)Q * 2 * sizeof(int), hipMemcpyDeviceToDevice, x));
     }

@@ -13,7 +13,7 @@
 //                  (word + position + LayerNorm, decoder.py:65-78) for the next decode step -- selection,
 //                  beam bookkeeping and the next step's embedding are one launch.
 //                    AUTOREGRESSIVE: decoder.py:257-298 (first step), 313-417
-//                    GENERATOR     : decoder.py:1169-1232 + BeamHypotheses 1292-1341 (n_hyp = 1)
+//                    GENERATOR     : decoder.py:1169-1232 + BeamHypotheses 1292-1341 (n_hyp = num_keep_best <= SS_NHMAX)
 //   finish       : select outputs.
 //
 // Sentences may carry their own prefix (VQA questions of different lengths in one batch; the reference runs them
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
     __shared__ int c_idx[SS_KMAX][SS_CMAX];
     __shared__ int sel_src[SS_KMAX], sel_word[SS_KMAX];
     __shared__ float sel_score[SS_KMAX];
-    __shared__ int s_hyp_row;                  // GENERATOR: row whose history becomes the new best hypothesis (-1: none)
+    __shared__ int s_nadd, s_add_slot[SS_CMAX * 2], s_add_row[SS_CMAX * 2];   // GENERATOR: hypotheses added this step (slot <- row)
     __shared__ float s_part[8];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
     const bool first = cur_len == P;                       // first search step of this sentence
     const int M = st.kind == 0 ? (first ? k : pn) : (st.sampled ? pn : pn * k);   // candidates needed per row
 
-    if (tid == 0) s_hyp_row = -1;
+    if (tid == 0) s_nadd = 0;
 
     // ---- phase A: merged top-M log-probabilities of every beam row of the sentence.  ONE WAVE PER ROW (rows j = wave,
     // wave + 4): a lane holds the sorted partial lists of parts lane, lane + 64, lane + 128, lane + 192 in registers, a
@@ -629,10 +629,14 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
                 }
                 n_max = fmaxf(n_max, n_score[c]);
             }
+            const int nh = st.nh;
+            double* h_score = st.hyp_score + (size_t)b * nh;
+            int* h_len = st.hyp_len + (size_t)b * nh;
+            int* h_seq = st.hyp_seq + (size_t)b * nh;
             int is_done = st.done[b];
-            if (!is_done && st.hyp_n[b] >= 1) {
+            if (!is_done && st.hyp_n[b] >= nh) {
                 // BeamHypotheses.is_done(max next score); self.max_length = max_length - 1
-                is_done = st.hyp_score[b] >= (double)n_max / st.len_norm[T - 1];
+                is_done = st.hyp_worst[b] >= (double)n_max / st.len_norm[T - 1];
             }
             if (is_done && !st.done[b]) atomicAdd(&st.info[0], 1);
             st.done[b] = is_done;
@@ -642,12 +646,30 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
                     const int word = n_word[c];
                     if (word == st.eos || cur_len + 1 == T) {
                         // hyps.add(input_ids[row, :cur_len], score)
+                        // BeamHypotheses.add (decoder.py:1316-1328): keep the nh best; a full list drops its lowest score
+                        // (sorted() on (score, list index): the earliest-added of equal scores) and worst_score becomes the
+                        // lowest score that is left
                         const double sc = (double)n_score[c] / st.len_norm[cur_len];
-                        if (st.hyp_n[b] < 1 || sc > st.hyp_score[b]) {
-                            st.hyp_n[b] = 1;
-                            st.hyp_score[b] = sc;
-                            st.hyp_len[b] = cur_len;
-                            s_hyp_row = b * k + n_beam[c];
+                        const int n = st.hyp_n[b];
+                        if (n < nh || sc > st.hyp_worst[b]) {
+                            int slot = n;
+                            if (n < nh) {
+                                st.hyp_n[b] = n + 1;
+                                st.hyp_worst[b] = sc < st.hyp_worst[b] ? sc : st.hyp_worst[b];
+                            } else {
+                                slot = 0;
+                                for (int i = 1; i < nh; ++i)
+                                    if (h_score[i] < h_score[slot] || (h_score[i] == h_score[slot] && h_seq[i] < h_seq[slot])) slot = i;
+                                double w = sc;
+                                for (int i = 0; i < nh; ++i)
+                                    if (i != slot && h_score[i] < w) w = h_score[i];
+                                st.hyp_worst[b] = w;
+                            }
+                            h_score[slot] = sc;
+                            h_len[slot] = cur_len;
+                            h_seq[slot] = st.hyp_cnt[b]++;
+                            s_add_slot[s_nadd] = slot; s_add_row[s_nadd] = b * k + n_beam[c];
+                            ++s_nadd;
                         }
                     } else {
                         sel_score[nb] = n_score[c]; sel_word[nb] = word; sel_src[nb] = b * k + n_beam[c];
@@ -668,8 +690,10 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
     __syncthreads();
 
     // ---- phase C: histories of the new beams (all threads), new token, scores -------------------------------------
-    if (s_hyp_row >= 0)
-        for (int s = tid; s < cur_len; s += 256) st.hyp_tok[(size_t)b * T + s] = ids_at(st, src, s_hyp_row, s);
+    for (int a = 0; a < s_nadd; ++a) {           // in the order of the adds: a slot refilled twice in one step keeps the later history
+        int* ht = st.hyp_tok + ((size_t)b * st.nh + s_add_slot[a]) * T;
+        for (int s = tid; s < cur_len; s += 256) ht[s] = ids_at(st, src, s_add_row[a], s);
+    }
     for (int j = 0; j < k; ++j) {
         const int r = b * k + j, rs = sel_src[j];
         for (int s = tid; s < cur_len; s += 256) {
@@ -750,7 +774,7 @@ __global__ void search_init_kernel(SearchState st) {
             st.score[0][r] = (st.kind == 1 && r % st.k > 0) ? -1e9f : 0.f;
         }
         for (int b = threadIdx.x; b < st.B; b += blockDim.x) {
-            st.done[b] = 0; st.hyp_n[b] = 0; st.hyp_score[b] = 0.0; st.hyp_len[b] = 0; st.stop[b] = 0; st.early[b] = 0;
+            st.done[b] = 0; st.hyp_n[b] = 0; st.hyp_cnt[b] = 0; st.hyp_worst[b] = 1e9; st.stop[b] = 0; st.early[b] = 0;
         }
         if (threadIdx.x < 4) st.info[threadIdx.x] = 0;
         // BeamHypotheses length norm ((5 + len) / 6) ** length_penalty for every length, once per search: the step kernel's
@@ -769,7 +793,8 @@ __global__ void search_finish_kernel(SearchState st, int cur, int cur_len, long 
     if (threadIdx.x == 0) { s_max_stop = 0; s_all_stop = 1; s_all_early = 1; }
     __syncthreads();
     for (int b = threadIdx.x; b < st.B; b += blockDim.x) {
-        long long* out = tokens_out + (size_t)b * st.T;
+        const int nout = st.kind == 0 ? 1 : st.nh;             // GENERATOR: num_keep_best sequences per sentence
+        long long* out = tokens_out + (size_t)b * nout * st.T;
         int L = st.T, early = 0;
         if (st.kind == 0) {
             const int r = b * st.k;
@@ -789,9 +814,24 @@ __global__ void search_finish_kernel(SearchState st, int cur, int cur_len, long 
             if (stop > 0) atomicMax(&s_max_stop, stop); else s_all_stop = 0;
             if (!early) s_all_early = 0;
         } else {
-            const int n = st.hyp_n[b] > 0 ? st.hyp_len[b] : 0;
-            for (int s = 0; s < st.T; ++s) out[s] = s < n ? st.hyp_tok[(size_t)b * st.T + s] : st.eos;
-            logprob_out[b] = st.hyp_n[b] > 0 ? (float)st.hyp_score[b] : -1e5f;
+            // decoder.py:1264-1290: the hypotheses by descending score (torch.topk over the list; equal scores in list
+            // order), each followed by EOS and EOS-padded; sequences the list cannot fill are all EOS with log-prob -1e5
+            const int nh = st.nh, have = st.hyp_n[b];
+            const double* h_score = st.hyp_score + (size_t)b * nh;
+            const int* h_seq = st.hyp_seq + (size_t)b * nh;
+            unsigned taken = 0u;
+            for (int i = 0; i < nh; ++i) {
+                int best = -1;
+                for (int j = 0; j < have; ++j) {
+                    if ((taken >> j) & 1u) continue;
+                    if (best < 0 || h_score[j] > h_score[best] || (h_score[j] == h_score[best] && h_seq[j] < h_seq[best])) best = j;
+                }
+                const int n = best >= 0 ? st.hyp_len[(size_t)b * nh + best] : 0;
+                const int* ht = st.hyp_tok + ((size_t)b * nh + (best >= 0 ? best : 0)) * st.T;
+                for (int s = 0; s < st.T; ++s) out[(size_t)i * st.T + s] = s < n ? ht[s] : st.eos;
+                logprob_out[(size_t)b * nh + i] = best >= 0 ? (float)h_score[best] : -1e5f;
+                if (best >= 0) taken |= 1u << best;
+            }
             if (sent_out) sent_out[2 * b + 1] = 0;
         }
         if (sent_out) sent_out[2 * b] = L;

@@ -115,6 +115,7 @@ hipError_t launch_kv_repack_frag(const void* qkv, void* kf, void* vt, int B, int
 hipError_t launch_attn_decode_mfma(const AttnDecodeArgs& a, int B, int H, hipStream_t s);
 hipError_t attn_decode_configure();
 
+constexpr int SS_NHMAX = 8;            // num_keep_best supported by the device search
 struct SearchState {
     int B, k, pn, T, V, eos, kind;      // B sentences of k beams; T = max_steps = row stride of ids / kv_src / hyp_tok
     int ragged;                         // 1: every sentence stands for its own batch-1 reference call (own prefix)
@@ -128,10 +129,15 @@ struct SearchState {
     int* kv_src[2];
     float* score[2];
     int* done;
-    int* hyp_n;
-    double* hyp_score;
-    int* hyp_len;
-    int* hyp_tok;
+    // GENERATOR: BeamHypotheses of every sentence (decoder.py:1292-1341), nh = num_keep_best slots each
+    int nh;                             // hypotheses kept per sentence (1 .. SS_NHMAX)
+    int* hyp_n;                         // [B] hypotheses held
+    int* hyp_cnt;                       // [B] hypotheses ever added (the next insertion number)
+    double* hyp_worst;                  // [B] BeamHypotheses.worst_score (1e9 while empty)
+    double* hyp_score;                  // [B][nh]
+    int* hyp_len;                       // [B][nh]
+    int* hyp_seq;                       // [B][nh] insertion number: the reference's list order (ties of its sorted())
+    int* hyp_tok;                       // [B][nh][T]
     int* stop;                          // AUTOREGRESSIVE: cur_len at which every beam of the sentence had ended (0: not yet)
     int* early;                         // AUTOREGRESSIVE, k == 1: the sentence's first prediction was EOS
     int* info;                          // [0] sentences ended / done so far, [2] steps run

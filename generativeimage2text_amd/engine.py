@@ -50,7 +50,8 @@ class GitmiSearch(C.Structure):
     _fields_ = [("kind", C.c_int32), ("beam_size", C.c_int32), ("per_node_beam_size", C.c_int32),
                 ("max_steps", C.c_int32), ("length_penalty", C.c_double),
                 ("do_sample", C.c_int32), ("top_k", C.c_int32), ("top_p", C.c_double), ("temperature", C.c_double),
-                ("seed", C.c_uint64), ("repetition_penalty", C.c_double)]
+                ("seed", C.c_uint64), ("repetition_penalty", C.c_double),
+                ("num_keep_best", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class GitmiProfile(C.Structure):
@@ -312,7 +313,8 @@ class Engine:
     @staticmethod
     def make_search(kind: str, max_steps: int, beam_size: int, per_node_beam_size: int,
                     length_penalty: float = 1.0, do_sample: bool = False, top_k: int = 0, top_p: float = 1.0,
-                    temperature: float = 1.0, seed: int = 0, repetition_penalty: float = 1.0) -> GitmiSearch:
+                    temperature: float = 1.0, seed: int = 0, repetition_penalty: float = 1.0,
+                    num_keep_best: int = 1) -> GitmiSearch:
         s = GitmiSearch()
         s.kind = (SEARCH_AUTOREGRESSIVE if kind in ("greedy", "autoregressive") else SEARCH_TRIE if kind == "trie"
                   else SEARCH_GENERATOR)
@@ -321,15 +323,24 @@ class Engine:
         s.do_sample, s.top_k, s.top_p = int(bool(do_sample)), int(top_k or 0), float(1.0 if top_p is None else top_p)
         s.temperature, s.seed = float(temperature), int(seed)
         s.repetition_penalty = float(repetition_penalty)
+        s.num_keep_best = int(num_keep_best)
         return s
+
+    @staticmethod
+    def _out(n_sent: int, search: GitmiSearch, dev):
+        """Output buffers of a search over n_sent sentences: [n, T] / [n], or [n, num_keep_best, T] / [n, num_keep_best]
+        when GeneratorWithBeamSearch keeps more than one hypothesis (decoder.py:1283-1290)."""
+        nh = max(1, int(search.num_keep_best))
+        shape = (n_sent,) if nh == 1 else (n_sent, nh)
+        return (torch.empty(*shape, search.max_steps, device=dev, dtype=torch.int64),
+                torch.empty(*shape, device=dev, dtype=torch.float32))
 
     def generate(self, frames: Sequence[torch.Tensor], search: GitmiSearch,
                  prefix: Optional[torch.Tensor] = None, sync: bool = True):
         """-> (tokens int64 [B, max_steps] incl. start tokens / EOS padded, logprobs fp32 [B], info int32 [4])"""
         arr, keep, B = self._frames_arg(frames)
         dev = keep[0].device
-        tokens = torch.empty(B, search.max_steps, device=dev, dtype=torch.int64)
-        logprobs = torch.empty(B, device=dev, dtype=torch.float32)
+        tokens, logprobs = self._out(B, search, dev)
         info = torch.empty(4, device=dev, dtype=torch.int32)
         P, pfx = 1, None
         if prefix is not None:
@@ -390,8 +401,7 @@ class Engine:
         if prefix is not None:
             pfx = prefix.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
             P = int(pfx.numel())
-        tokens = torch.empty(n_images, search.max_steps, device=dev, dtype=torch.int64)
-        logprobs = torch.empty(n_images, device=dev, dtype=torch.float32)
+        tokens, logprobs = self._out(n_images, search, dev)
         info = torch.empty(4, device=dev, dtype=torch.int32)
         self._ck(_experiment_only(self.lib, "gitmi_group_decode")(self._h, int(n_frames), int(n_images), _ptr(pfx), P, C.byref(search),
                                         tokens.data_ptr(), logprobs.data_ptr(), info.data_ptr(), _stream()))
@@ -403,8 +413,7 @@ class Engine:
         """Second half: the search over the text positions.  -> (tokens, logprobs, info) exactly as generate()."""
         F, B, pfx, P = self._half
         dev = f"cuda:{self.device}"
-        tokens = torch.empty(B, search.max_steps, device=dev, dtype=torch.int64)
-        logprobs = torch.empty(B, device=dev, dtype=torch.float32)
+        tokens, logprobs = self._out(B, search, dev)
         info = torch.empty(4, device=dev, dtype=torch.int32)
         self._ck(_experiment_only(self.lib, "gitmi_generate_decode")(self._h, F, B, _ptr(pfx), P, C.byref(search), tokens.data_ptr(),
                                            logprobs.data_ptr(), info.data_ptr(), _stream()))
@@ -427,8 +436,7 @@ class Engine:
         for q, p in enumerate(prefixes):
             table[q, :len(p)] = torch.as_tensor(list(p), dtype=torch.int64)
         table = table.to(dev)
-        tokens = torch.empty(Q, search.max_steps, device=dev, dtype=torch.int64)
-        logprobs = torch.empty(Q, device=dev, dtype=torch.float32)
+        tokens, logprobs = self._out(Q, search, dev)
         sent = torch.empty(Q, 2, device=dev, dtype=torch.int32)
         info = torch.empty(4, device=dev, dtype=torch.int32)
         lens_c = (C.c_int32 * Q)(*lens)
@@ -449,6 +457,7 @@ class Engine:
         self._search_k = search.beam_size
         self._search_B = B
         self._search_T = search.max_steps
+        self._search_cfg = search
 
     def search_rows(self) -> torch.Tensor:
         R, t = C.c_int(), C.c_int()
@@ -496,8 +505,7 @@ class Engine:
 
     def search_finish(self):
         dev = f"cuda:{self.device}"
-        tokens = torch.empty(self._search_B, self._search_T, device=dev, dtype=torch.int64)
-        logprobs = torch.empty(self._search_B, device=dev, dtype=torch.float32)
+        tokens, logprobs = self._out(self._search_B, self._search_cfg, dev)
         info = torch.empty(4, device=dev, dtype=torch.int32)
         self._ck(self.lib.gitmi_search_finish(self._h, tokens.data_ptr(), logprobs.data_ptr(), info.data_ptr(), _stream()))
         torch.cuda.current_stream().synchronize()

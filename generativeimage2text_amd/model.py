@@ -89,7 +89,7 @@ def _begin_and_run(decoder, start_predictions, step, search_struct, first_step_r
         if early:                                                       # decoder.py:279-291
             return tokens[:, P:P + 1], logprobs[:, None]
         return tokens[:, :seq_len], logprobs
-    return tokens, logprobs[:, None]
+    return tokens, (logprobs[:, None] if logprobs.dim() == 1 else logprobs)      # [B, num_keep_best]
 
 
 class AutoRegressiveBeamSearch:
@@ -231,13 +231,16 @@ class GeneratorWithBeamSearch:
     def search(self, input_ids: torch.Tensor, step, num_keep_best: int = 1, do_sample: bool = False, top_k=None,
                top_p=None, num_return_sequences: int = 1, seed: int = 0, _engine_factory=None):
         """decoder.py:1083-1290 with a caller-supplied `step`: -> (decoded int64 [B, max_steps] = best hypothesis + EOS,
-        right-padded with EOS, logprobs fp32 [B, 1]).  Like the reference, the loop stops calling `step` once every
-        sentence is done (decoder.py:1251)."""
-        if num_keep_best != 1 or num_return_sequences != 1:
-            raise NotImplementedError("GeneratorWithBeamSearch.search: num_keep_best = num_return_sequences = 1 only")
+        right-padded with EOS, logprobs fp32 [B, 1]); with num_keep_best = n > 1 the n best hypotheses of every sentence,
+        best first: ([B, n, max_steps], [B, n]), missing ones all EOS at -1e5 (decoder.py:1262-1290); B counts every
+        sentence num_return_sequences times (decoder.py:1093-1097).  Like the reference, the loop stops calling `step` once
+        every sentence is done (decoder.py:1251)."""
+        if num_return_sequences != 1:                   # decoder.py:1093-1097: every sentence num_return_sequences times
+            input_ids = input_ids[:, None, :].expand(input_ids.shape[0], num_return_sequences, input_ids.shape[1])
+            input_ids = input_ids.reshape(-1, input_ids.shape[-1])
         s = Engine.make_search("generator", self.max_steps, self.beam_size, self.per_node_beam_size, self.length_penalty,
                                do_sample=do_sample, top_k=top_k or 0, top_p=top_p, temperature=self.temperature, seed=seed,
-                               repetition_penalty=self.repetition_penalty)
+                               repetition_penalty=self.repetition_penalty, num_keep_best=num_keep_best)
         return _begin_and_run(self, input_ids, step, s, first_step_rows_per_sentence=False, stop_when_all_eos=False,
                               fmt="generator", engine_factory=_engine_factory)
 
@@ -338,14 +341,18 @@ class CaptioningModel:
         do_sample / top_k / top_p for GeneratorWithBeamSearch (decoder.py:1088-1090); `seed` selects the random stream."""
         d = self.decoder
         sp = dict(search_param or {})
-        unknown = set(sp) - {"do_sample", "top_k", "top_p", "seed"}
+        unknown = set(sp) - {"do_sample", "top_k", "top_p", "seed", "num_keep_best", "num_return_sequences"}
         if unknown:
             raise NotImplementedError(f"search parameters {sorted(unknown)} are not implemented")
+        if d.kind != "generator" and (int(sp.get("num_keep_best", 1)) != 1 or int(sp.get("num_return_sequences", 1)) != 1):
+            raise NotImplementedError("num_keep_best / num_return_sequences: GeneratorWithBeamSearch.search only "
+                                      "(the other classes use them in SCST training only)")
         return Engine.make_search(d.kind, d.max_steps, d.beam_size, d.per_node_beam_size, d.length_penalty,
                                   do_sample=bool(sp.get("do_sample", False)), top_k=sp.get("top_k") or 0,
                                   top_p=sp.get("top_p"), temperature=getattr(d, "temperature", 1.0),
                                   seed=int(sp.get("seed", 0)),
-                                  repetition_penalty=getattr(d, "repetition_penalty", 1.0))
+                                  repetition_penalty=getattr(d, "repetition_penalty", 1.0),
+                                  num_keep_best=int(sp.get("num_keep_best", 1)))
 
     def forward(self, batch: Mapping[str, Union[torch.Tensor, Sequence[torch.Tensor]]],
                 search_param: Optional[dict] = None) -> Dict[str, torch.Tensor]:
@@ -366,9 +373,20 @@ class CaptioningModel:
         if self.decoder.kind == "trie" and getattr(self, "_trie_loaded", None) is not self.decoder.trie:
             self.engine.set_trie(*self.decoder.trie.csr())
             self._trie_loaded = self.decoder.trie
-        tokens, logprobs, info = self.engine.generate(frames, search, prefix=prefix)
-        seq_len, early, _, _ = info.tolist()
         P = 1 if prefix is None else int(prefix.numel())
+        nret = int((search_param or {}).get("num_return_sequences", 1))
+        if nret != 1:
+            # decoder.py:1093-1097: every image's start tokens num_return_sequences times -- r sentences per image, each
+            # with its own beams (they differ only when sampling); rows b * r + j, as the reference returns them
+            B = int(frames[0].shape[0])
+            start = [int(self.cfg.sos)] if prefix is None else [int(t) for t in prefix.reshape(-1).tolist()]
+            if B * nret > self.engine.c.max_batch:
+                raise ValueError(f"{B} images x num_return_sequences={nret} exceed max_batch={self.engine.c.max_batch}")
+            tokens, logprobs, _, info = self.engine.generate_prefixed(
+                frames, search, [start] * (B * nret), image_of=[b for b in range(B) for _ in range(nret)])
+        else:
+            tokens, logprobs, info = self.engine.generate(frames, search, prefix=prefix)
+        seq_len, early, _, _ = info.tolist()
         if self.decoder.kind in ("autoregressive", "trie"):
             if early:                                                       # decoder.py:279-291 / trie_decoder.py:76-83
                 predictions = tokens[:, P:P + 1]
@@ -376,10 +394,11 @@ class CaptioningModel:
             else:
                 predictions = tokens[:, :seq_len]
         else:
-            predictions = tokens
-            logprobs = logprobs[:, None]                                    # [B, num_keep_best=1]
+            predictions = tokens                                            # [B, T], or [B, num_keep_best, T]
+            if logprobs.dim() == 1:
+                logprobs = logprobs[:, None]                                # [B, num_keep_best]
         if prefix is not None:
-            predictions = predictions[:, P:]                                # decoder.py:1004-1006
+            predictions = predictions[:, P:]                                # decoder.py:1004-1006 (dim 1, whatever it is)
         return {"predictions": predictions, "logprobs": logprobs}
 
     __call__ = forward

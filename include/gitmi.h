@@ -97,6 +97,13 @@ typedef struct gitmi_search {
      * filter) the raw score of every token already in a row's history (start tokens included) is multiplied by it when
      * negative and divided by it otherwise.  >= 1; 0 and 1 both mean off. */
     double  repetition_penalty;
+    /* GENERATOR only: `num_keep_best` of GeneratorWithBeamSearch.search (decoder.py:1087, 1113-1115, 1262-1290) -- every
+     * sentence keeps its n best finished hypotheses (BeamHypotheses(n_hyp = n)) and returns all of them, best first:
+     * tokens_out becomes [B, n, max_steps], logprob_out [B, n]; sequences the list cannot fill are all EOS with
+     * log-prob -1e5, as in the reference.  1 .. 8; 0 is read as 1.  (The reference's `num_return_sequences` -- r independent
+     * sentences per image -- is the host mirror's business: r sentences with the same image index, gitmi_generate_prefixed.) */
+    int32_t num_keep_best;
+    int32_t reserved_;
 } gitmi_search;
 
 /* per-phase device timings (ms) of the last profiled gitmi_generate(), see gitmi_profile_enable */

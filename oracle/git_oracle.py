@@ -520,17 +520,23 @@ class _Hypotheses:
 def search_generator(start: Tensor, step: Callable[[Tensor], Tensor], eos: int, max_steps: int,
                      beam_size: int = 4, per_node_beam_size: int = 2,
                      length_penalty: float = 0.6, trace: Optional[List[Tensor]] = None,
-                     repetition_penalty: float = 1.0) -> Tuple[Tensor, Tensor]:
-    """GeneratorWithBeamSearch.search, greedy-beam branch, num_keep_best=1
-    (decoder.py:1083-1290).  Shipped default: beam 4, per_node 2, length_penalty 0.6.
+                     repetition_penalty: float = 1.0, num_keep_best: int = 1,
+                     num_return_sequences: int = 1) -> Tuple[Tensor, Tensor]:
+    """GeneratorWithBeamSearch.search, greedy-beam branch (decoder.py:1083-1290).  Shipped default: beam 4, per_node 2,
+    length_penalty 0.6.
     repetition_penalty != 1 (decoder.py:1135-1144): the raw score of every token already in a row's history is
     multiplied (score < 0) or divided (score >= 0) by it before the log-softmax.
+    num_return_sequences r (decoder.py:1093-1097): every start row r times -> B*r sentences.
+    num_keep_best n (decoder.py:1113-1115, 1262-1290): every sentence returns its n best finished hypotheses, best first.
 
-    Returns (decoded int64 [B, max_steps] EOS-padded incl. start tokens, logprobs fp32 [B,1])."""
+    Returns (decoded int64 [B, max_steps] EOS-padded incl. start tokens, logprobs fp32 [B,1]); n > 1: ([B, n, max_steps],
+    [B, n]), hypotheses the list cannot fill all EOS at -1e5."""
+    if num_return_sequences != 1:
+        start = start[:, None, :].expand(start.shape[0], num_return_sequences, start.shape[1]).reshape(-1, start.shape[1])
     B, cur = start.shape
     k = beam_size
     ids = start[:, None, :].expand(B, k, cur).reshape(B * k, cur)
-    hyps = [_Hypotheses(1, max_steps, length_penalty) for _ in range(B)]
+    hyps = [_Hypotheses(num_keep_best, max_steps, length_penalty) for _ in range(B)]
     beam_scores = torch.zeros(B, k)
     beam_scores[:, 1:] = -1e9                                                   # :1118-1120
     beam_scores = beam_scores.reshape(-1)
@@ -578,13 +584,17 @@ def search_generator(start: Tensor, step: Callable[[Tensor], Tensor], eos: int, 
         cur += 1
         if all(done):
             break
-    out = torch.full((B, max_steps), eos, dtype=ids.dtype)                      # :1283-1289 (pad id = eos)
-    logprobs = torch.full((B, 1), -1e5)
+    out = torch.full((B, num_keep_best, max_steps), eos, dtype=ids.dtype)       # :1283-1289 (pad id = eos)
+    logprobs = torch.full((B, num_keep_best), -1e5)
     for b, h in enumerate(hyps):
-        if h.items:
-            score, seq = max(h.items, key=lambda it: it[0])
-            out[b, : len(seq)] = seq
-            logprobs[b, 0] = score
+        # :1270-1280: torch.topk over the list's scores (equal scores: list order)
+        order = sorted(range(len(h.items)), key=lambda j: (-h.items[j][0], j))[:num_keep_best]
+        for i, j in enumerate(order):
+            score, seq = h.items[j]
+            out[b, i, : len(seq)] = seq
+            logprobs[b, i] = score
+    if num_keep_best == 1:
+        out = out[:, 0]                                                         # :1288-1289
     return out, logprobs
 
 

@@ -397,9 +397,17 @@ SCRIPTED = {
     "s2_k3_pn3": ("beam", 2, 1, 60, 2, 9, 3, 3, 0.8, 12, (4,), 3.0),
     "s2_rep_penalty": ("beam", 3, 1, 60, 2, 12, 4, 2, 0.6, 13, (6, 7), 4.0),      # repetition_penalty 1.3 (SCRIPTED_RP)
     "s2_rep_penalty_prefix": ("beam", 1, 4, 60, 2, 12, 3, 2, 0.8, 33, (8,), 4.0),  # repetition_penalty 2.0, prefix tokens count
+    # num_keep_best / num_return_sequences of GeneratorWithBeamSearch.search (SCRIPTED_KEEP): EOS wins often, so that the
+    # n-best lists fill, overflow (the worst hypothesis is dropped) and decide `done`
+    "s2_keep3": ("beam", 3, 1, 60, 2, 12, 4, 2, 0.6, 41, (2, 3, 4, 6), 3.0),
+    "s2_keep8_short": ("beam", 2, 1, 60, 2, 6, 3, 2, 0.8, 42, tuple(range(1, 20)), -30.0),   # EOS never wins: only the 2k = 6 forced finishes -> two -1e5 rows
+    "s2_keep2_ret2_prefix": ("beam", 1, 3, 60, 2, 11, 4, 2, 0.6, 43, (4, 5, 7), 3.5),
+    "s2_ret3": ("beam", 2, 1, 60, 2, 9, 3, 2, 0.6, 44, (3, 5), 4.0),
 }
 # repetition_penalty of GeneratorWithBeamSearch (decoder.py:1135-1144) per scripted case (default 1 = off)
 SCRIPTED_RP = {"s2_rep_penalty": 1.3, "s2_rep_penalty_prefix": 2.0}
+# (num_keep_best, num_return_sequences) of GeneratorWithBeamSearch.search (decoder.py:1087, 1091) per scripted case
+SCRIPTED_KEEP = {"s2_keep3": (3, 1), "s2_keep8_short": (8, 1), "s2_keep2_ret2_prefix": (2, 2), "s2_ret3": (1, 3)}
 
 
 def run_scripted():
@@ -425,8 +433,14 @@ def run_scripted():
                 rpen = SCRIPTED_RP.get(name, 1.0)
                 ref_dec = D.GeneratorWithBeamSearch(eos_index=eos, max_steps=T, beam_size=k,
                                                     per_node_beam_size=pn, length_penalty=lpn, repetition_penalty=rpen)
-                rp, rl = ref_dec.search(start, counted)
-                op, ol = O.search_generator(start, step, eos, T, k, pn, lpn, repetition_penalty=rpen)
+                nkeep, nret = SCRIPTED_KEEP.get(name, (1, 1))
+                rp, rl = ref_dec.search(start, counted, num_keep_best=nkeep, num_return_sequences=nret)
+                op, ol = O.search_generator(start, step, eos, T, k, pn, lpn, repetition_penalty=rpen, num_keep_best=nkeep,
+                                            num_return_sequences=nret)
+                if nkeep > 1:       # the case must fill (or under-fill, by name) its lists with distinct hypotheses
+                    assert rp.dim() == 3 and rp.shape[1] == nkeep, rp.shape
+                    filled = (rl > -1e4).sum(dim=1)
+                    assert (filled >= 2).any() and (("short" in name) == bool((filled < nkeep).any())), (name, filled)
                 if rpen != 1.0:      # the case must actually exercise the penalty
                     np_, _ = D.GeneratorWithBeamSearch(eos_index=eos, max_steps=T, beam_size=k, per_node_beam_size=pn,
                                                        length_penalty=lpn).search(start, step)

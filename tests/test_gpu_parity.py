@@ -268,10 +268,13 @@ def test_device_search_scripted(name):
     step = MG.scripted_step_factory(seed, V, eos, at, boost)
     import dataclasses
     cfg = dataclasses.replace(O.CONFIGS["TINY"], eos=eos, vocab=1000)
-    eng = Engine(cfg, precision="f32", max_batch=B, max_beams=k, max_frames=1, max_text_len=T)
+    nkeep, nret = MG.SCRIPTED_KEEP.get(name, (1, 1))          # GeneratorWithBeamSearch.search(num_keep_best, num_return_sequences)
+    start = start.repeat_interleave(nret, dim=0)              # decoder.py:1093-1097: the seam sees every sentence nret times
+    eng = Engine(cfg, precision="f32", max_batch=start.shape[0], max_beams=k, max_frames=1, max_text_len=T)
     eng.load_state_dict(O.make_weights(cfg, seed=1))
     s = Engine.make_search("greedy" if kind == "greedy" else "beam", T, k, pn, lpn if lpn > 0 else 1.0,
-                           repetition_penalty=MG.SCRIPTED_RP.get(name, 1.0))       # decoder.py:1135-1144
+                           repetition_penalty=MG.SCRIPTED_RP.get(name, 1.0),       # decoder.py:1135-1144
+                           num_keep_best=nkeep)
     eng.search_begin(s, start, V)
     for _ in range(T - P):
         rows = eng.search_rows().cpu()
@@ -285,7 +288,7 @@ def test_device_search_scripted(name):
         else:
             got_p, got_l = tokens[:, :seq_len], logprobs
     else:
-        got_p, got_l = tokens, logprobs[:, None]
+        got_p, got_l = tokens, (logprobs[:, None] if nkeep == 1 else logprobs)
     assert got_p.shape == exp_p.shape, (got_p.shape, exp_p.shape)
     assert np.array_equal(got_p.cpu().numpy(), exp_p), (got_p, exp_p)
     assert np.allclose(got_l.cpu().numpy(), exp_l, atol=1e-4), (got_l, exp_l)
@@ -786,7 +789,9 @@ def test_search_method_scripted(name):
     def counted_step(rows):
         calls.append(int(rows.shape[1]))
         return step(rows.cpu()).cuda()
-    got_p, got_l = dec.search(start.cuda(), counted_step)
+    nkeep, nret = MG.SCRIPTED_KEEP.get(name, (1, 1))
+    keep_kw = {} if (nkeep, nret) == (1, 1) else {"num_keep_best": nkeep, "num_return_sequences": nret}
+    got_p, got_l = dec.search(start.cuda(), counted_step, **keep_kw)
     exp_p, exp_l = gold[name + ".pred"], gold[name + ".logprob"]
     assert got_p.shape == exp_p.shape, (got_p.shape, exp_p.shape)
     assert np.array_equal(got_p.cpu().numpy(), exp_p), (got_p, exp_p)
@@ -809,11 +814,48 @@ def test_search_method_scripted(name):
                                            fix_missing_prefix=True).search(start, ref_step)
             else:
                 D.GeneratorWithBeamSearch(eos_index=eos, max_steps=T, beam_size=k, per_node_beam_size=pn, length_penalty=lpn,
-                                          repetition_penalty=MG.SCRIPTED_RP.get(name, 1.0)).search(start, ref_step)
+                                          repetition_penalty=MG.SCRIPTED_RP.get(name, 1.0)).search(start, ref_step, **keep_kw)
         assert calls == ref_calls, (calls, ref_calls)
 
 
 # ---- trie-constrained greedy decoding (trie_decoder.py:27-257) -----------------------------------------------------
+def test_model_num_keep_best_and_num_return_sequences_match_oracle():
+    """model(batch, search_param={'num_keep_best': n, 'num_return_sequences': r}) with the shipped search class
+    (GeneratorWithBeamSearch.search keywords, decoder.py:1087-1097, 1262-1290; pinned against the reference itself by the
+    scripted goldens s2_keep* / s2_ret*): the n best hypotheses of every sentence, best first, ids bit for bit in f32
+    mode; r sentences per image (identical copies without sampling); the reference's prefix strip acts on dim 1."""
+    from oracle import git_oracle as O
+    from generativeimage2text_amd.model import CaptioningModel, GeneratorWithBeamSearch
+    cfg = O.CONFIGS["TINY"]
+    w = O.make_weights(cfg, seed=47, tie_output=False, successor=2.0, eos_bias=4.0)          # mixed: full-length and early-EOS hypotheses
+    frames = O.make_images(cfg, 3, 1, seed=12)
+    T, k, pn, lpn, n = 12, 4, 2, 0.6, 3
+    dec = GeneratorWithBeamSearch(eos_index=cfg.eos, max_steps=T, beam_size=k, per_node_beam_size=pn, length_penalty=lpn)
+    model = CaptioningModel(cfg, dec, precision="f32", max_batch=6)
+    model.load_state_dict(w)
+    with torch.no_grad():
+        feats = O.visual_features(cfg, w, frames)
+        start = torch.full((3, 1), cfg.sos, dtype=torch.long)
+        want_p, want_l = O.search_generator(start, O.make_step(cfg, w, feats, cached=True), cfg.eos, T, k, pn, lpn,
+                                            num_keep_best=n)
+    assert want_p.shape == (3, n, T) and (want_l > -1e4).sum() >= 6         # the lists hold real hypotheses
+    out = model({"image": frames[0].cuda()}, search_param={"num_keep_best": n})
+    assert torch.equal(out["predictions"].cpu(), want_p), (out["predictions"].cpu(), want_p)
+    assert torch.allclose(out["logprobs"].cpu(), want_l, atol=1e-3)
+    one = model({"image": frames[0].cuda()})                                # the default call is the first hypothesis
+    assert torch.equal(one["predictions"].cpu(), want_p[:, 0]) and one["logprobs"].shape == (3, 1)
+    # num_return_sequences = 2: rows b * 2 + j, every copy equal to the image's own result (no sampling)
+    rep = model({"image": frames[0].cuda()}, search_param={"num_keep_best": n, "num_return_sequences": 2})
+    assert rep["predictions"].shape == (6, n, T)
+    assert torch.equal(rep["predictions"].cpu(), want_p.repeat_interleave(2, dim=0))
+    with pytest.raises(ValueError):
+        model({"image": frames[0].cuda()}, search_param={"num_return_sequences": 3})       # 9 sentences > max_batch 6
+    from generativeimage2text_amd.engine import Engine, GitmiError
+    with pytest.raises(GitmiError, match="num_keep_best"):
+        model.engine.generate([frames[0].cuda()], Engine.make_search("greedy", T, 1, 1, num_keep_best=2))
+    model.engine.close()
+
+
 @pytest.mark.parametrize("name", sorted(MG.SCRIPTED_TRIE))
 def test_device_trie_search_scripted(name):
     """The device trie search (gitmi_set_trie + GITMI_SEARCH_TRIE behind decoder.search(start, step)) against the

@@ -64,9 +64,9 @@ def test_product_libraries_export_the_c_abi_and_nothing_else():
 
 def test_struct_layouts_match_header():
     assert engine.C.sizeof(engine.GitmiConfig) == 21 * 4
-    assert engine.C.sizeof(engine.GitmiSearch) == 64          # 4 x int32, double, 2 x int32, 2 x double, uint64, double
+    assert engine.C.sizeof(engine.GitmiSearch) == 72          # 4 x int32, double, 2 x int32, 2 x double, uint64, double, 2 x int32
     assert engine.GitmiSearch.length_penalty.offset == 16 and engine.GitmiSearch.top_p.offset == 32
-    assert engine.GitmiSearch.seed.offset == 48
+    assert engine.GitmiSearch.seed.offset == 48 and engine.GitmiSearch.num_keep_best.offset == 64
     import re, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "gitmi.h")).read()
@@ -649,8 +649,12 @@ def test_search_methods_host_loop(monkeypatch):
     gen9 = model.GeneratorWithBeamSearch(eos_index=eos, max_steps=9, beam_size=4, per_node_beam_size=2, length_penalty=0.6)
     decoded, lps = gen9.search(torch.tensor([[5], [6]]), step_eos_at_4, _engine_factory=factory)
     assert max(t for _, t in seen) == 3 and decoded.shape == (2, 9)
-    with pytest.raises(NotImplementedError):
-        gen.search(torch.tensor([[5]]), step_never_eos, num_keep_best=2, _engine_factory=factory)
+    # num_return_sequences (decoder.py:1093-1097): the seam sees every sentence r times, r * beam_size rows per start row
+    model._SEARCH_ENGINES.clear()
+    seen.clear()
+    decoded, lps = gen.search(torch.tensor([[5], [7]]), step_never_eos, num_return_sequences=3, _engine_factory=factory)
+    assert made[-1].B == 6 and seen[0] == (24, 1) and decoded.shape == (6, 6) and lps.shape == (6, 1)
+    assert decoded[:, 0].tolist() == [5, 5, 5, 7, 7, 7]
     with pytest.raises(NotImplementedError):
         dec.search(start, step_never_eos, do_sample=True, _engine_factory=factory)
     model._SEARCH_ENGINES.clear()
