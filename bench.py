@@ -98,6 +98,18 @@ def cpu_baseline(sample_batch: int, max_steps: int, threads: int = 0, repeats: i
            "sample": f"GIT_BASE fp32 bs={sample_batch} greedy {med['steps']} decode steps, full recompute per step "
                      f"(reference semantics): median of {len(runs)} passes after one warm-up, {med['wall_s']:.1f}s each on "
                      f"{threads} threads"}
+    # how representative the port is: measured once where /root/reference is importable (oracle/time_port_vs_reference.py,
+    # same weights / images / threads / batch: the unmodified reference modules against the port, ids equal)
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "port_vs_reference.json")) as f:
+            pr = json.load(f)
+        out["port_vs_reference_ratio"] = pr["port_vs_reference_ratio"]
+        out["reference_estimate"] = round(out["value"] / pr["port_vs_reference_ratio"], 4)
+        out["sample"] += (f"; the port runs at {pr['port_vs_reference_ratio']:.2f} x the speed of the reference's own modules "
+                          f"(bs={pr['batch']}, {pr['threads']} threads, measured where /root/reference exists: "
+                          f"{pr['port_s']} s vs {pr['reference_s']} s)")
+    except (OSError, KeyError, ValueError):
+        pass
     if big_batch and big_batch != sample_batch:
         big = _cpu_run(big_batch, max_steps, threads)
         out["bs%d" % big_batch] = {"value": round(big["captions_per_s"], 4), "vit_s": round(big["vit_s"], 2),
@@ -189,7 +201,7 @@ def bench_parity(eng, tokens, info, args):
     name, _ = parity_golden(args)
     if name is None:
         return None
-    from generativeimage2text_amd.parity import F16_SCALE, IDENTICAL_FLOORS, IDENTICAL_FLOORS_F16, bf16_bounds, ids_parity
+    from generativeimage2text_amd.parity import IDENTICAL_FLOORS, IDENTICAL_FLOORS_F16, ids_parity, margin_threshold
     g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
     chained = args.search != "greedy"
     seq_len = int(info.tolist()[0])
@@ -197,12 +209,13 @@ def bench_parity(eng, tokens, info, args):
     lg = eng.step_logits(torch.from_numpy(g["tf_tokens"]))[:4, ::3].float().cpu().numpy()
     lerr = float(np.abs(lg - g["tf_logits"]).max())
     span = float(g["tf_logits"].max() - g["tf_logits"].min())
-    bnd = bf16_bounds(model_family(args.model))
     f32, f16 = args.precision == "f32", args.precision == "f16"
     from generativeimage2text_amd.parity import lerr_frac_bound
-    thr = 1e-6 if f32 else bnd["thr"] * (2 if chained else 1) * (F16_SCALE["thr"] if f16 else 1.0)
     floor = got.shape[0] if f32 else (IDENTICAL_FLOORS_F16 if f16 else IDENTICAL_FLOORS).get(name)
     lbound = 1e-4 if f32 else lerr_frac_bound(name, model_family(args.model), args.precision) * span
+    # a one-beam row sees the reference's own tokens until its first divergence: within the logit bound, only a decision
+    # whose fp32 margin is below 2 x bound can flip (parity.margin_threshold)
+    thr = 1e-6 if f32 else margin_threshold(model_family(args.model), lbound, chained, args.precision)
     try:
         st = ids_parity(got, g["predictions"], g["step_margin"], thr, chained=chained, min_identical=floor)
         st["ok"] = bool(lerr < lbound)
@@ -212,10 +225,45 @@ def bench_parity(eng, tokens, info, args):
         st = {"ok": False, "violation": str(exc)[:200]}
     st["logit_err"] = round(lerr, 5)
     st["logit_span"] = round(span, 3)
+    st["logit_err_frac_of_span"] = round(lerr / span, 6)       # north_star's "logits within 1e-3 bf16", read relative to the span
     st["logit_err_bound"] = round(lbound, 5)
     st["identical_floor"] = floor
     st["reference"] = f"tests/golden/{name}.npz"
     return st
+
+
+def bench_wide_margin(args, cfg, device):
+    """north_star: "greedy outputs bit-identical to reference token IDs".  On the benchmark's own random-init weights every
+    row has a top-1 / top-2 near-tie somewhere in its 19 steps, so that clause is undecidable for a 16-bit pipeline (`parity`
+    above reports the count and the floor).  tests/golden/full_wide_b64_*.npz is the same geometry in the regime where it IS
+    decidable (the benchmark's weight family + a successor structure, 64 images on which every greedy decision of the fp32
+    reference has a margin >= 0.2; frozen from the unmodified reference by oracle/make_golden.py): the engine must return
+    the reference's ids on EVERY row.  One solo pass in this run's precision and search, outside the timed region."""
+    import numpy as np
+    if model_family(args.model) != "GIT_BASE" or args.frames != 1 or args.batch != 64 or args.max_steps != 20:
+        return None
+    name = "full_wide_b64_greedy" if args.search == "greedy" else "full_wide_b64_beam4"
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    if not os.path.exists(path):
+        return None
+    from generativeimage2text_amd.engine import Engine
+    from generativeimage2text_amd.synthetic import random_state_dict, seeded_images
+    g = np.load(path)
+    wsrc = eval(str(g["weights"]), {"__builtins__": {}}, {})              # ("wide", seed, eos_bias, successor[, images of])
+    beams = 1 if args.search == "greedy" else 4
+    eng = Engine(cfg, precision=args.precision, max_batch=64, max_beams=beams, max_frames=1, max_text_len=20)
+    try:
+        eng.load_state_dict(random_state_dict(cfg, seed=wsrc[1], eos_bias=wsrc[2], successor=wsrc[3]))
+        search = Engine.make_search("greedy", 20, 1, 1) if beams == 1 else Engine.make_search("beam", 20, 4, 2, 0.6)
+        tokens, _, info = eng.generate(seeded_images(cfg, g["image_seeds"].tolist(), device=device), search, sync=True)
+    finally:
+        eng.close()
+    got = (tokens if beams > 1 else tokens[:, :int(info.tolist()[0])]).cpu().numpy()
+    ref = g["predictions"]
+    same = int(sum(1 for r in range(ref.shape[0]) if got.shape == ref.shape and (got[r] == ref[r]).all()))
+    return {"reference": f"tests/golden/{name}.npz", "rows": int(ref.shape[0]), "identical": same,
+            "required": int(ref.shape[0]), "ok": same == int(ref.shape[0]),
+            "min_reference_margin_greedy": round(float(np.load(os.path.join(ROOT, "tests", "golden", "full_wide_b64_greedy.npz"))["step_margin"].min()), 4)}
 
 
 class _HostDev:
@@ -425,6 +473,8 @@ def main(argv=None, engine_factory=None):
         search = Engine.make_search("beam", args.max_steps, 4, 2, 0.6)
 
     lat_events = []
+    gather_events = []          # N > 1: events around the batch's ONE collective on its stream
+    last_lp = [None]
 
     def step(record_latency=False):
         i = counter[0] % len(ctxs)
@@ -434,8 +484,15 @@ def main(argv=None, engine_factory=None):
                 e0, e1 = dev.Event(enable_timing=True), dev.Event(enable_timing=True)
                 e0.record()
             tokens, logprobs, info = ctxs[i].generate(frames, search, sync=False)
+            last_lp[0] = logprobs
             if world > 1:
+                if record_latency:
+                    g0, g1 = dev.Event(enable_timing=True), dev.Event(enable_timing=True)
+                    g0.record()
                 gather_results(tokens, logprobs)
+                if record_latency:
+                    g1.record()
+                    gather_events.append((g0, g1))
             if record_latency:
                 e1.record()
                 lat_events.append((e0, e1))
@@ -562,6 +619,26 @@ def main(argv=None, engine_factory=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N > 1: what the one collective of the path costs ("report the gather latency separately") -- in the timed
+    # schedule (device time between the events around it on the batch's stream: it queues behind the batch's decode chain
+    # and waits for the slowest rank) and alone (one gather + stream synchronisation at a time, after the timed region)
+    gather_stats = None
+    if world > 1 and tokens is not None:
+        g_in = sorted(a.elapsed_time(b) for a, b in gather_events)
+        alone = []
+        lp_probe = last_lp[0] if last_lp[0] is not None and last_lp[0].shape[0] == tokens.shape[0] else \
+            torch.zeros(tokens.shape[0], device=tokens.device)
+        for _ in range(20):
+            t_g = time.perf_counter()
+            gather_results(tokens, lp_probe)
+            dev.synchronize()
+            alone.append(1e3 * (time.perf_counter() - t_g))
+        alone.sort()
+        gather_stats = {"in_schedule_ms": {"median": round(g_in[len(g_in) // 2], 4), "max": round(g_in[-1], 4)} if g_in else None,
+                        "alone_ms": {"median": round(alone[len(alone) // 2], 4), "max": round(alone[-1], 4)},
+                        "bytes_per_rank": int(tokens.shape[0] * (tokens.shape[1] + 1) * 8),
+                        "what": "ONE gather of int64 [B, max_len + 1] (ids + bit-cast log-probs) to rank 0 per batch"}
+
     # fixed-work check: no caption ended early (every caption ran max_steps-1 decode steps)
     info_h = info.tolist()
     steps_run = info_h[2]
@@ -593,6 +670,8 @@ def main(argv=None, engine_factory=None):
             # a batch's own latency (submit -> ids ready) while `contexts_in_flight` batches share the GPU
             "batch_latency_ms": {"median": round(lat[len(lat) // 2], 3), "max": round(lat[-1], 3)},
         }
+        if gather_stats is not None:
+            result["gather"] = gather_stats
 
     # ---- roofline passes (rank 0 of N=1 only) ---------------------------------------------------------------
     if rank == 0 and world == 1 and not standin:
@@ -702,6 +781,8 @@ def main(argv=None, engine_factory=None):
         result["phases_ms"]["graph_encode_prefill_ms"] = round(gprof["vit_ms"], 3)
         result["phases_ms"]["graph_decode_ms"] = round(gprof["decode_ms"], 3)
         result["parity"] = bench_parity(eng, tokens_solo, info_solo, args)
+        if result["parity"] is not None:
+            result["parity"]["wide_margin"] = bench_wide_margin(args, cfg, frames[0].device)
         # the ids of the timed schedule's last batch are the ids of the solo pass (same images, same weights)
         result["timed_ids_equal_solo"] = bool(torch.equal(tokens.cpu(), tokens_solo.cpu()))
         if not args.no_cpu_baseline:

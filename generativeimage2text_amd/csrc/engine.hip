@@ -1295,26 +1295,33 @@ extern "C" int gitmi_set_trie(gitmi_engine* e, int n_nodes, const int32_t* child
     RCK(check_ready(e));
     HIPCK(hipDeviceSynchronize());
     destroy_graph(e);                                       // captured launches hold the old pointers
-    if (e->trie_off) { hipFree(e->trie_off); hipFree(e->trie_tok); hipFree(e->trie_child); }
-    e->trie_off = e->trie_tok = e->trie_child = nullptr;
-    e->trie_nodes = 0;
-    if (n_nodes <= 0) return 0;
-    if (!child_off || child_off[0] != 0) return fail("set_trie: child_off must start at 0");
-    const int n_edges = child_off[n_nodes];
-    for (int n = 0; n < n_nodes; ++n)
-        if (child_off[n + 1] < child_off[n]) return fail("set_trie: child_off must be non-decreasing");
-    if (n_edges > 0 && (!child_tok || !child_node)) return fail("set_trie: null edge arrays");
-    for (int i = 0; i < n_edges; ++i)
-        if (child_node[i] < 0 || child_node[i] >= n_nodes) return fail("set_trie: edge %d leads to node %d of %d", i, child_node[i], n_nodes);
-    HIPCK(hipMalloc((void**)&e->trie_off, (size_t)(n_nodes + 1) * sizeof(int)));
-    HIPCK(hipMalloc((void**)&e->trie_tok, (size_t)std::max(n_edges, 1) * sizeof(int)));
-    HIPCK(hipMalloc((void**)&e->trie_child, (size_t)std::max(n_edges, 1) * sizeof(int)));
-    HIPCK(hipMemcpy(e->trie_off, child_off, (size_t)(n_nodes + 1) * sizeof(int), hipMemcpyHostToDevice));
-    if (n_edges > 0) {
-        HIPCK(hipMemcpy(e->trie_tok, child_tok, (size_t)n_edges * sizeof(int), hipMemcpyHostToDevice));
-        HIPCK(hipMemcpy(e->trie_child, child_node, (size_t)n_edges * sizeof(int), hipMemcpyHostToDevice));
+    // the new arrays are built completely before the old ones go: a failed allocation or copy leaves the engine with the
+    // trie it had (all three arrays or none), never with offsets that point into freed edge arrays
+    int *n_off = nullptr, *n_tok = nullptr, *n_child = nullptr;
+    if (n_nodes > 0) {
+        if (!child_off || child_off[0] != 0) return fail("set_trie: child_off must start at 0");
+        const int n_edges = child_off[n_nodes];
+        for (int n = 0; n < n_nodes; ++n)
+            if (child_off[n + 1] < child_off[n]) return fail("set_trie: child_off must be non-decreasing");
+        if (n_edges > 0 && (!child_tok || !child_node)) return fail("set_trie: null edge arrays");
+        for (int i = 0; i < n_edges; ++i)
+            if (child_node[i] < 0 || child_node[i] >= n_nodes) return fail("set_trie: edge %d leads to node %d of %d", i, child_node[i], n_nodes);
+        hipError_t err = hipMalloc((void**)&n_off, (size_t)(n_nodes + 1) * sizeof(int));
+        if (err == hipSuccess) err = hipMalloc((void**)&n_tok, (size_t)std::max(n_edges, 1) * sizeof(int));
+        if (err == hipSuccess) err = hipMalloc((void**)&n_child, (size_t)std::max(n_edges, 1) * sizeof(int));
+        if (err == hipSuccess) err = hipMemcpy(n_off, child_off, (size_t)(n_nodes + 1) * sizeof(int), hipMemcpyHostToDevice);
+        if (err == hipSuccess && n_edges > 0) err = hipMemcpy(n_tok, child_tok, (size_t)n_edges * sizeof(int), hipMemcpyHostToDevice);
+        if (err == hipSuccess && n_edges > 0) err = hipMemcpy(n_child, child_node, (size_t)n_edges * sizeof(int), hipMemcpyHostToDevice);
+        if (err != hipSuccess) {
+            if (n_off) hipFree(n_off);
+            if (n_tok) hipFree(n_tok);
+            if (n_child) hipFree(n_child);
+            return fail("set_trie: %s (the previous trie is kept)", hipGetErrorString(err));
+        }
     }
-    e->trie_nodes = n_nodes;
+    if (e->trie_off) { hipFree(e->trie_off); hipFree(e->trie_tok); hipFree(e->trie_child); }
+    e->trie_off = n_off; e->trie_tok = n_tok; e->trie_child = n_child;
+    e->trie_nodes = n_nodes > 0 ? n_nodes : 0;
     return 0;
 }
 
@@ -1698,7 +1705,9 @@ GITMI_EXP_EXPORT int gitmi_group_decode(gitmi_engine* e, int F, int B, const int
     RCK(check_generate_args(e, F, B, prefix, &P, sp));
     const int F_in = e->cfg.num_frames > 0 ? std::min(F, e->cfg.num_frames) : F;
     hipStream_t s = (hipStream_t)stream;
-    // images [0, B) must be covered by members that have published a request of the same geometry
+    // images [0, B) must be covered by members that have published a request of the same geometry.  A published request
+    // stays in the cache until its member publishes the next one: decoding it AGAIN (bench.py's solo decode-step probe) is
+    // allowed and returns the same rows; what is refused is a member that never published (cur_B == 0) or a changed geometry
     std::vector<char> have((size_t)B, 0);
     for (gitmi_engine* m : e->kv_members) {
         if (m->kv_image_off >= B) continue;

@@ -925,7 +925,7 @@ hipError_t launch_trie_select(const float* logits, int ldl, int V, const int* id
                               int eos, const TrieArgs& tr, int B, float* part_val, int* part_idx, float2* part_lse,
                               hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if (!tr.child_off || !tr.cursor || V < 2) return hipErrorInvalidValue;
+    if (!tr.child_off || !tr.child_tok || !tr.child_node || !tr.cursor || V < 2) return hipErrorInvalidValue;
     hipLaunchKernelGGL(trie_select_kernel, dim3(B), dim3(TRIE_NT), 0, s, logits, ldl, V, ids, ld_ids, cur_len, plen, eos, tr,
                        part_val, part_idx, part_lse);
     return hipGetLastError();

@@ -18,8 +18,9 @@ import numpy as np
 # None of these is derived from the engine under test (round-2 review: a threshold of "4 x the measured error" widens its
 # own acceptance band when a kernel regresses).  They were set ONCE from the measurements of profiles/r03_a_parity_measured.jsonl
 # (MI355X, both residual-stream storage types):
-#   thr        a row may leave the reference's ids only at a search decision whose fp32 margin is below thr (x 2 for
-#              beam search: summed log-probs).  Largest margin at which a row actually diverged: 0.0078 (greedy), 0.027 (beam)
+#   thr        cap on the margin below which a row may leave the reference's ids (x 2 for beam search: summed log-probs); for
+#              one-beam searches the threshold actually applied is min(thr, 2 x the logit-error bound): margin_threshold().
+#              Largest margin at which a row actually diverged: 0.0078 (greedy), 0.027 (beam)
 #   ferr       bound on the visual-feature error (unit-variance LayerNorm outputs; measured 0.015 - 0.023)
 #   lerr_frac  bound on the teacher-forced logit error as a fraction of the logit span: 1.5 x the measured value of every
 #              golden case (LERR_FRAC; the benchmark's identity-LayerNorm weights measure 0.9e-3, the oracle's weights with
@@ -45,15 +46,21 @@ LERR_FRAC = {
     "full_base_b64_greedy": 0.0072, "full_base_b64_beam4": 0.0053, "full_large_b32_greedy": 0.0016,
     "full_vatex_b16_greedy": 0.0017,
 }
-# floors on rows whose ids equal the reference's token for token, per full-batch golden, 1-2 rows below the lowest count
-# measured (any re-ordering of fp32 partial sums moves a near-tie row or two: the wide LayerNorm kernel took VATEX from
-# 13 to 12 of 16 and the benchmark rows from 49 to 50 of 64) (full_base_b64_greedy uses the
-# oracle's perturbed-LayerNorm weights: 5x the logit error of the benchmark's weights, hence fewer identical rows); a kernel regression that loses rows fails here even when every lost row has a near-tie
-# somewhere in its 19 steps
-IDENTICAL_FLOORS = {       # measured over the kernel variants of round 3: 49-52, 42, 56, 60-61, 26-27, 12-14
+# floors on rows whose ids equal the reference's token for token, per full-batch golden: a regression guard, 1-2 rows below
+# the LOWEST count measured over the kernel variants of rounds 3-4 (any re-ordering of fp32 partial sums moves a near-tie row
+# or two: the wide LayerNorm kernel took VATEX from 13 to 12 of 16 and the benchmark rows from 49 to 50 of 64;
+# full_base_b64_greedy uses the oracle's perturbed-LayerNorm weights: 5x the logit error of the benchmark's weights, hence
+# fewer identical rows).  A kernel regression that loses rows fails here even when every lost row has a near-tie somewhere in
+# its 19 steps.  With random-init weights every row of these cases has such a near-tie (median row-minimum margin 0.006), so
+# the floor is the only bound with teeth there; the case on which identity IS decidable -- reference margins >= 0.1 on every
+# decision of every row -- is full_wide_b64_greedy, where the bf16 engine must return 64 of 64 rows (IDENTICAL_REQUIRED).
+IDENTICAL_FLOORS = {       # measured over the kernel variants of rounds 3-4: 49-52, 42-46, 56-60, 59-61, 26-28, 12-14
     "full_bench_b64_greedy": 47, "full_base_b64_greedy": 40, "full_base_b64_beam4": 52, "full_bench_b64_beam4": 58,
-    "full_large_b32_greedy": 24, "full_vatex_b16_greedy": 12,
+    "full_large_b32_greedy": 24, "full_vatex_b16_greedy": 11,
 }
+# goldens whose reference margins are wide on every decision (oracle/make_golden.py asserts >= 0.1 when it freezes them): every
+# row must equal the reference's ids in EVERY precision -- north_star's identity clause in the regime where it is decidable
+IDENTICAL_REQUIRED = ("full_wide_b64_greedy", "full_wide_b64_beam4")
 
 
 # fp16-operand build (libgitmi_f16.so, precision "f16"): the same kernels with 3 more mantissa bits per operand.  Bounds =
@@ -64,6 +71,21 @@ IDENTICAL_FLOORS_F16 = {                                   # measured (profiles/
     "full_bench_b64_greedy": 58, "full_base_b64_greedy": 56, "full_base_b64_beam4": 58, "full_bench_b64_beam4": 61,
     "full_large_b32_greedy": 29, "full_vatex_b16_greedy": 14,
 }
+
+
+def margin_threshold(config_name: str, logit_err_bound: float, chained: bool, precision: str = "bf16") -> float:
+    """Margin below which a row may leave the reference's ids.
+    One beam (not chained): until its first divergence a row is fed exactly the reference's tokens, so its logits are the
+    teacher-forced logits, asserted elsewhere to lie within `logit_err_bound` (absolute) of the reference's; log-softmax shifts
+    all logits of a row alike, so a decision can flip only if its fp32 margin is below 2 x logit_err_bound.  The threshold is
+    that bound, capped by the fixed per-geometry constant (which is tighter on the wide-span oracle weights) -- it follows
+    from the logit bound instead of being calibrated on observed divergences.
+    Beam search (chained): candidates are SUMS of up to T log-probs, for which 2 x err x T is far too loose to be a test; the
+    fixed constant x 2 stays (largest margin at which a beam row was ever observed to diverge: 0.027)."""
+    thr = bf16_bounds(config_name)["thr"] * (F16_SCALE["thr"] if precision == "f16" else 1.0)
+    if chained:
+        return 2.0 * thr
+    return min(thr, 2.0 * float(logit_err_bound))
 
 
 def lerr_frac_bound(case: str, config_name: str, precision: str = "bf16") -> float:

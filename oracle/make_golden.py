@@ -205,6 +205,11 @@ FULL_CASES = {
     # family with a successor structure (synthetic.random_state_dict(successor=...)) and 64 images on which EVERY greedy
     # decision of the fp32 reference has a margin >= WIDE_MARGIN -- the bf16 / fp16 engines must return 64 of 64 rows
     "full_wide_b64_greedy": ("GIT_BASE", ("wide", 1250, -5.0, 1.0), 64, 1, O.GREEDY),
+    # the same weights and the same 64 images under the shipped search class (cfg3: beam 4).  The greedy margins certify
+    # the TOP-1 path of every row; the 2k = 8 candidates a beam step keeps include runner-ups that are Gaussian-close for
+    # any weights, so no margin certificate exists for beam search -- but those near-ties sit in the tail of the beam and
+    # the best hypothesis is carried by the wide top-1 decisions: the engines are REQUIRED to return 64 of 64 rows here too
+    "full_wide_b64_beam4": ("GIT_BASE", ("wide", 1250, -5.0, 1.0, "full_wide_b64_greedy"), 64, 1, O.BEAM4),
 }
 WIDE_MARGIN = 0.2        # selection bound on every decision margin of a kept image (the tests demand >= 0.1)
 
@@ -244,7 +249,7 @@ def full_case_inputs(name: str, image_seeds=None):
         from generativeimage2text_amd.synthetic import random_state_dict, seeded_images
         mc = config_for_model(cfg_name)
         w = {k: v.float() for k, v in random_state_dict(mc, seed=wsrc[1], eos_bias=wsrc[2], successor=wsrc[3]).items()}
-        path = os.path.join(GOLD, name + ".npz")
+        path = os.path.join(GOLD, (wsrc[4] if len(wsrc) > 4 else name) + ".npz")      # wsrc[4]: the case whose images are reused
         if image_seeds is None:
             image_seeds = np.load(path)["image_seeds"].tolist() if os.path.exists(path) else select_wide_images(cfg, w, B, search)
         frames = seeded_images(mc, image_seeds, device="cpu")
@@ -269,7 +274,10 @@ def run_full_case(name: str):
     The full-recompute reference costs minutes per case here (B=64 greedy ~3 min, beam-4 ~10 min on 8 vCPUs)."""
     wide = FULL_CASES[name][1][0] == "wide" if isinstance(FULL_CASES[name][1], tuple) else False
     image_seeds = None
-    if wide:          # the images are part of the fixture: re-select them (deterministic) rather than trust an old file
+    reuse = wide and len(FULL_CASES[name][1]) > 4          # images of another wide case (its golden names them)
+    if reuse:
+        image_seeds = np.load(os.path.join(GOLD, FULL_CASES[name][1][4] + ".npz"))["image_seeds"].tolist()
+    elif wide:        # the images are part of the fixture: re-select them (deterministic) rather than trust an old file
         cfg0, w0, _, search0, _ = full_case_inputs(name, image_seeds=[0])
         image_seeds = select_wide_images(cfg0, w0, FULL_CASES[name][2], search0)
     cfg, w, frames, search, tie = full_case_inputs(name, image_seeds=image_seeds)
@@ -309,7 +317,7 @@ def run_full_case(name: str):
         tf_top2_margin=(ora_tf.topk(2).values[:, 0] - ora_tf.topk(2).values[:, 1]).numpy(),
         **({"image_seeds": np.array(image_seeds, dtype=np.int64)} if wide else {}),
     )
-    if wide:
+    if wide and not reuse:
         assert float(margins.min()) >= WIDE_MARGIN, margins.min()
 
 

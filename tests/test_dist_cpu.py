@@ -170,10 +170,15 @@ def _bench_main_worker(rank, world, port, tmpdir):
                       "--no-cpu-baseline"],
                      engine_factory=lambda args, r: (_StandInEngine(r, args.batch, args.max_steps), [torch.zeros(1)]))
     if rank == 0:
-        assert res["n_gpus"] == world and res["config"]["global_batch"] == world * 3 and res["config"]["parallelism"] == "dp2"
+        assert res["n_gpus"] == world and res["config"]["global_batch"] == world * 3 and res["config"]["parallelism"] == f"dp{world}"
         assert res["value"] > 0 and res["steps"] == 4
-        t, l = gathered[-1]                                   # rank 0 received the rows of BOTH ranks, in rank order
-        assert t.shape == (world * 3, 20) and t[:3].eq(1000).all() and t[3:].eq(1001).all() and l.tolist() == [0.0] * 3 + [-1.0] * 3
+        t, l = gathered[-1]                                   # rank 0 received the rows of EVERY rank, in rank order
+        assert t.shape == (world * 3, 20)
+        for r in range(world):
+            assert t[3 * r:3 * r + 3].eq(1000 + r).all() and l[3 * r:3 * r + 3].tolist() == [-float(r)] * 3
+        # the path's one collective is reported on its own: in the schedule and alone
+        g = res["gather"]
+        assert g["bytes_per_rank"] == 3 * 21 * 8 and g["alone_ms"]["median"] > 0 and g["in_schedule_ms"]["median"] >= 0
         open(os.path.join(tmpdir, "ok"), "w").write(json.dumps(res))
     else:
         assert res is None and gathered[-1] == (None, None)
@@ -218,6 +223,15 @@ def test_two_rank_bench_main_with_standin_engine(tmp_path):
     with n_gpus == --gpus == WORLD_SIZE, the gather delivers every rank's rows to rank 0."""
     mp.spawn(_bench_main_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert json.loads((tmp_path / "ok").read_text())["n_gpus"] == 2
+
+
+def test_eight_rank_bench_main_with_standin_engine(tmp_path):
+    """The same at the node's size: 8 ranks (BASELINE.json configs[3]: DP across 8 GPUs).  Every rank times its steps, the
+    elapsed time is the MAX over ranks, rank 0 receives 8 x B rows in rank order and prints ONE line with n_gpus = 8,
+    global_batch = 8 B, parallelism dp8 and the gather figures."""
+    mp.spawn(_bench_main_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    res = json.loads((tmp_path / "ok").read_text())
+    assert res["n_gpus"] == 8 and res["config"]["global_batch"] == 24 and res["scaling"] == "weak"
 
 
 def test_bench_decode_group_schedule_with_standin_engine():

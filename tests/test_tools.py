@@ -166,7 +166,7 @@ def _run_bench_with_fakes(monkeypatch, capsys, argv):
     monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
     monkeypatch.setattr(torch.cuda, "synchronize", lambda: None)
     monkeypatch.setattr(E, "Engine", FakeEngine)
-    monkeypatch.setattr(synthetic, "random_state_dict", lambda cfg, seed=0: {})
+    monkeypatch.setattr(synthetic, "random_state_dict", lambda cfg, seed=0, **kw: {})
     monkeypatch.setattr(synthetic, "random_frames", lambda cfg, B, F, seed=0: [torch.zeros(B, 3, 8, 8) for _ in range(F)])
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BENCH_GEMM_IMPL"):
         monkeypatch.delenv(k, raising=False)
