@@ -151,6 +151,7 @@ struct gitmi_engine {
     int attn_pw = 0;                    // (sentence, head) pairs per workgroup of the decode attention (GITMI_ATTN_PW; 0 = by policy)
     int attn_nh = 0;                    // waves per (sentence, head) pair of the decode attention (GITMI_ATTN_NH: 1 / 2)
     int attn_ppw = 0;                   // pairs a wave of the packed one-wave decode attention serves one after the other (0 = by policy)
+    int attn_stream = -1;               // workgroups of the streaming decode attention (0 = register kernels; -1 = by policy)
     bool shared_device = false;         // gitmi_set_shared_device: other contexts run beside this one
     int dgemm_no_row_walk = -1;         // A/B (GITMI_DGEMM_NO_ROW_WALK=0|1; -1 = by policy)
     int dgemm_strips = -1;              // 16-column strips per workgroup of the wide chain GEMMs at <= 64 rows (1, 2, 4, 6; -1 = by policy)
@@ -352,6 +353,7 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     if (const char* env = getenv("GITMI_ATTN_PW")) e->attn_pw = atoi(env);
     if (const char* env = getenv("GITMI_ATTN_NH")) e->attn_nh = atoi(env);
     if (const char* env = getenv("GITMI_ATTN_PPW")) e->attn_ppw = atoi(env);
+    if (const char* env = getenv("GITMI_ATTN_STREAM")) e->attn_stream = atoi(env);
     if (const char* env = getenv("GITMI_DECODE_SKIP")) e->decode_skip = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_ROWS")) e->dgemm_rows = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_STRIPS")) e->dgemm_strips = atoi(env);
@@ -813,7 +815,7 @@ static int clone_impl(gitmi_engine* src, int max_batch, gitmi_engine** out) {
     e->N_nat = e->N = src->N_nat; e->g_nat = e->gh = e->gw = src->g_nat; e->H = e->W = src->cfg.image_size;
     e->Nmax = src->Nmax; e->max_pixels = src->max_pixels;
     e->use_graph = src->use_graph; e->skinny = src->skinny; e->use_temb = src->use_temb;
-    e->attn_dbg = src->attn_dbg; e->dgemm_dbg = src->dgemm_dbg; e->attn_pw = src->attn_pw; e->attn_nh = src->attn_nh; e->attn_ppw = src->attn_ppw; e->decode_skip = src->decode_skip;
+    e->attn_dbg = src->attn_dbg; e->dgemm_dbg = src->dgemm_dbg; e->attn_pw = src->attn_pw; e->attn_nh = src->attn_nh; e->attn_ppw = src->attn_ppw; e->attn_stream = src->attn_stream; e->decode_skip = src->decode_skip;
     e->shared_device = src->shared_device; e->dgemm_rows = src->dgemm_rows; e->dgemm_strips = src->dgemm_strips; e->vocab_wgs = src->vocab_wgs; e->dgemm_no_row_walk = src->dgemm_no_row_walk;
     e->parent = src->parent ? src->parent : src;
     e->conv_w = src->conv_w; e->cls = src->cls; e->pos = src->pos; e->pos_cur = src->pos;
@@ -1044,6 +1046,7 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
         a.waves_per_pair = e->attn_nh;
         a.pairs_per_wg = e->attn_pw > 0 ? e->attn_pw : e->shared_device ? 8 : 4;
         a.pairs_per_wave = e->attn_ppw > 0 ? e->attn_ppw : 1;
+        a.stream_wgs = e->attn_stream >= 0 ? e->attn_stream : 0;
         if (e->f32) HIPCK(launch_attn_decode(a, B, c.dec_heads, true, s));
         else if (!GITMI_SKIPPED(e, 1)) HIPCK(launch_attn_decode_mfma(a, B, c.dec_heads, s));
         if (chain) {
@@ -2034,7 +2037,9 @@ extern "C" int gitmi_op_attn_decode(const void* qkv, const void* img_k, const vo
     AttnDecodeArgs a{};
     a.qkv = qkv; a.img_k = img_k; a.img_v = img_v; a.txt_k = txt_k; a.txt_v = txt_v; a.out = out;
     a.kv_src = kv_src; a.ld_src = T_max; a.d = H * 64; a.N_img = N_img; a.T_max = T_max; a.pos = pos; a.beams = beams;
-    a.scale = 0.125f; a.dbg = dbg;
+    // dbg: bits 0..15 timing experiments of the kernels (measurement builds), bits 16..17 waves per pair (0 = by geometry,
+    // 1, 2), bits 18.. workgroups of the streaming kernel (0 = register kernels)
+    a.scale = 0.125f; a.dbg = dbg & 0xffff; a.waves_per_pair = (dbg >> 16) & 3; a.stream_wgs = dbg >> 18;
     if (dtype == GITMI_DTYPE_F32) {
         HIPCK(launch_attn_decode(a, B, H, true, (hipStream_t)stream));
         return 0;

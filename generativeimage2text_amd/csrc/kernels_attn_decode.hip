@@ -20,6 +20,7 @@
 // 8-lanes-per-key scalar path and are folded into the wave's partial before the two halves are combined.
 #include "gitmi_common.h"
 #include "launchers.h"
+#include <algorithm>
 
 namespace gitmi {
 
@@ -407,6 +408,365 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
   }
 }
 
+// ---- streaming form of the one-wave kernel -----------------------------------------------------------------------
+// The kernels above keep a pair's K/V chunk in REGISTERS (128 of a wave's 215): a wave can only ask for its next chunk when
+// the registers are free, so every pair costs two exposed memory round trips and a CU never has more than its resident
+// waves' chunks in flight -- 24 GB/s per CU, 96 CUs for 17.8 us per launch, while every one of those CUs is closed to the
+// image encoder's GEMM workgroups.  Here the K/V of a wave's pairs STREAM through an LDS ring: 4-KiB slots (the K or the
+// V^T of one 32-key step -- contiguous in the cache layouts above) are fetched by LDS-DMA (global_load_lds, lane-linear:
+// the fragment-major layout lands so that lane l's operand of fragment f is the 16 bytes at f * 1 KiB + l * 16) in exactly
+// the order the wave consumes them,
+//        pair 0: K0 K1 K2 K3 | V0 V1 V2 V3 | K4 K5 K6 | V4 V5 V6      pair 1: ...
+// RING slots ahead of the consumer, across chunk AND pair boundaries: the stream never drains between pairs, text keys,
+// merge and output of one pair are worked off while the next pair's slots land.  A wave holds ~100 registers instead of
+// 215, a workgroup is 4 waves x RING x 4 KiB of LDS = one per CU.
+// The arithmetic is the one-wave kernel's, operation for operation (same chunks of ACS key steps, same max / rescale
+// order): results are bit-identical to attn_decode_mfma_kernel<KB, TI, *, 1>.
+// Ordering rules (MI355X_MICROARCH.md, LDS-DMA): a ds_read sees a DMA's bytes only after the issuing wave's counted vmcnt
+// -- loads complete in order, so `vmcnt(4 * slots issued after this one)` retires the slot (other vector-memory operations
+// issued in between only make that wait stricter); a slot is refilled only after the ds_reads that emptied it have
+// returned (lgkmcnt(0)).  Rings are private to a wave: no workgroup barrier anywhere.
+typedef __attribute__((address_space(3))) void attn_lds_void_t;
+
+template <int N> __device__ __forceinline__ void attn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// younger slots still in flight are allowed to stay in flight: 4 LDS-DMA instructions per slot
+__device__ __forceinline__ void attn_wait_slots_ahead(int ahead) {
+    switch (ahead) {
+        case 0: attn_wait_vm<0>(); break;
+        case 1: attn_wait_vm<4>(); break;
+        case 2: attn_wait_vm<8>(); break;
+        case 3: attn_wait_vm<12>(); break;
+        case 4: attn_wait_vm<16>(); break;
+        case 5: attn_wait_vm<20>(); break;
+        case 6: attn_wait_vm<24>(); break;
+        case 7: attn_wait_vm<28>(); break;
+        case 8: attn_wait_vm<32>(); break;
+        case 9: attn_wait_vm<36>(); break;
+        case 10: attn_wait_vm<40>(); break;
+        default: attn_wait_vm<44>(); break;       // ahead >= 11: waiting for fewer outstanding operations is always safe
+    }
+}
+
+constexpr int AS_WAVES = 4;                    // waves (independent streams) per workgroup
+constexpr int AS_SLOT = 4096;                  // bytes: K or V^T of one 32-key step of one (image, head)
+
+template <int KB, int TI, int RING>
+__global__ __launch_bounds__(64 * AS_WAVES) void attn_decode_stream_kernel(AttnDecodeArgs a) {
+    static_assert(RING >= 2 && RING <= 12, "ring depth");
+    __shared__ __attribute__((aligned(16))) unsigned char ring_mem[AS_WAVES][RING * AS_SLOT];
+    __shared__ float part[AS_WAVES][KB][HD + 2];   // [wave][beam]: o[64], m, l
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int H = a.d / HD;
+    const int k = a.beams;
+    const bf16_t* QKV = reinterpret_cast<const bf16_t*>(a.qkv);
+    bf16_t* TK = reinterpret_cast<bf16_t*>(a.txt_k);
+    bf16_t* TV = reinterpret_cast<bf16_t*>(a.txt_v);
+    bf16_t* O = reinterpret_cast<bf16_t*>(a.out);
+    const int ld3 = 3 * a.d;
+    const int Np = a.N_pad, nsteps = Np >> 5;
+    unsigned char* ring = ring_mem[wave];
+
+    // pairs of this wave: w, w + W, w + 2W, ...  (W = waves of the launch)
+    const int W = (int)gridDim.x * AS_WAVES, w0 = (int)blockIdx.x * AS_WAVES + wave;
+    const int npw = w0 < a.n_pairs ? (a.n_pairs - 1 - w0) / W + 1 : 0;
+    const int slots_per_pair = 2 * nsteps;
+    const int total_slots = npw * slots_per_pair;
+
+    // ---- producer: the next slot of the stream -> ring position issued % RING.  All state is wave-uniform.
+    int issued = 0;                      // slots requested so far
+    int p_ord = 0, p_s0 = 0, p_v = 0, p_c = 0;     // pair ordinal, chunk start step, 0 = K / 1 = V^T, step within the chunk
+    const bf16_t* p_K = nullptr; const bf16_t* p_V = nullptr;
+    auto producer_pair = [&]() {
+        const int pair = w0 + p_ord * W;
+        const int h = pair % H, b = pair / H;
+        const int bi = a.img_of ? a.img_of[b] : b;
+        p_K = reinterpret_cast<const bf16_t*>(a.img_k) + ((size_t)bi * H + h) * Np * HD;
+        p_V = reinterpret_cast<const bf16_t*>(a.img_v) + ((size_t)bi * H + h) * Np * HD;
+    };
+    if (npw > 0) producer_pair();
+    auto issue_slot = [&]() {
+        if (issued >= total_slots) return;
+        const bf16_t* src = (p_v ? p_V : p_K) + (size_t)(p_s0 + p_c) * (AS_SLOT / 2) + lane * 8;
+        unsigned char* dst = ring + (issued % RING) * AS_SLOT;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            __builtin_amdgcn_global_load_lds((const void*)(src + f * 512), (attn_lds_void_t*)(dst + f * 1024), 16, 0, 2);   // aux 2 = nt
+        ++issued;
+        const int nsc = min(ACS, nsteps - p_s0);
+        if (++p_c == nsc) {
+            p_c = 0;
+            if (p_v == 0) p_v = 1;
+            else {
+                p_v = 0; p_s0 += ACS;
+                if (p_s0 >= nsteps) { p_s0 = 0; ++p_ord; if (p_ord < npw) producer_pair(); }
+            }
+        }
+    };
+    for (int i = 0; i < RING; ++i) issue_slot();
+
+    int consumed = 0;                    // slots read out of the ring so far
+    // wait for the oldest unread slot, return its ring address
+    auto slot_ready = [&]() -> const unsigned char* {
+        const int ahead = issued - consumed - 1;
+        if (ahead == RING - 1) attn_wait_vm<4 * (RING - 1)>();        // steady state
+        else attn_wait_slots_ahead(ahead);
+        return ring + (consumed % RING) * AS_SLOT;
+    };
+    // the slot's fragments are in registers (the caller has used them): free it and keep the stream RING slots ahead
+    auto slot_done = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ++consumed;
+        issue_slot();
+    };
+
+    for (int ord = 0; ord < npw; ++ord) {
+        const int pair = w0 + ord * W;
+        const int h = pair % H, b = pair / H;
+        const int row0 = b * k;
+
+        // ---- text items: the 8 eight-lane groups of the wave share them -------------------------------------------
+        const int grp = lane >> 3, sub = lane & 7;
+        const int nt = a.pos + 1;
+        int t_j[TI], t_s[TI];
+        u32x4_t tkr[TI], tvr[TI];
+#pragma unroll
+        for (int u = 0; u < TI; ++u) {
+            const int it = grp + 8 * u;
+            t_j[u] = it < k * nt ? it / nt : -1;
+            t_s[u] = it < k * nt ? it % nt : 0;
+            tkr[u] = u32x4_t{0u, 0u, 0u, 0u};
+            tvr[u] = tkr[u];
+            if (t_j[u] >= 0) {
+                if (t_s[u] == a.pos) {
+                    const bf16_t* src = QKV + (size_t)(row0 + t_j[u]) * ld3 + a.d + h * HD + sub * 8;
+                    tkr[u] = *reinterpret_cast<const u32x4_t*>(src);
+                    tvr[u] = *reinterpret_cast<const u32x4_t*>(src + a.d);
+                } else {
+                    const int srow = KB == 1 ? row0 : a.kv_src[(size_t)(row0 + t_j[u]) * a.ld_src + t_s[u]];
+                    const size_t off = ((size_t)srow * a.T_max + t_s[u]) * a.d + h * HD + sub * 8;
+                    tkr[u] = *reinterpret_cast<const u32x4_t*>(TK + off);
+                    tvr[u] = *reinterpret_cast<const u32x4_t*>(TV + off);
+                }
+            }
+        }
+        // append this position's K/V of every beam to the text cache
+        if (lane < k * 8) {
+            const int j = lane >> 3;
+            const bf16_t* src = QKV + (size_t)(row0 + j) * ld3 + a.d + h * HD + sub * 8;
+            const size_t dst = ((size_t)(row0 + j) * a.T_max + a.pos) * a.d + h * HD + sub * 8;
+            *reinterpret_cast<u32x4_t*>(TK + dst) = *reinterpret_cast<const u32x4_t*>(src);
+            *reinterpret_cast<u32x4_t*>(TV + dst) = *reinterpret_cast<const u32x4_t*>(src + a.d);
+        }
+
+        // ---- image part on the matrix cores: operands from the ring ------------------------------------------------
+        bf16x8_t qf[2];
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) {
+            float qv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (l15 < k) ld8bf(QKV + (size_t)(row0 + l15) * ld3 + h * HD + ds * 32 + lg * 8, qv);
+            u32x4_t t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = pack2bf(qv[2 * e] * a.scale, qv[2 * e + 1] * a.scale);
+            qf[ds] = __builtin_bit_cast(bf16x8_t, t);
+        }
+        float m_i = -INFINITY, l_i = 0.f;
+        f32x4_t oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        for (int s0 = 0; s0 < nsteps; s0 += ACS) {
+            f32x4_t sc[ACS][2];
+            float cm = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < ACS; ++c) {
+                const int s = s0 + c;
+                if (s < nsteps) {                                              // wave-uniform
+                    const unsigned char* sl = slot_ready();
+                    bf16x8_t kq[2][2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int ds = 0; ds < 2; ++ds)
+                            kq[t][ds] = *reinterpret_cast<const bf16x8_t*>(sl + (t * 2 + ds) * 1024 + lane * 16);
+                    __builtin_amdgcn_sched_barrier(0);       // all four ds_reads in flight before the first MFMA waits for one
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        sc[c][t] = mfma16(kq[t][0], qf[0], f32x4_t{0.f, 0.f, 0.f, 0.f});
+                        sc[c][t] = mfma16(kq[t][1], qf[1], sc[c][t]);
+                    }
+                    slot_done();
+                } else {
+                    sc[c][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    sc[c][1] = sc[c][0];
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (s * 32 + t * 16 + lg * 4 + r >= a.N_img || s >= nsteps) sc[c][t][r] = -INFINITY;   // padded keys / steps
+                        cm = fmaxf(cm, sc[c][t][r]);
+                    }
+            }
+            cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+            cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+            const float mn = fmaxf(m_i, cm);
+            if (s0 != 0) {
+                const float al = fast_exp(m_i - mn);
+                l_i *= al;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { oacc[dt][0] *= al; oacc[dt][1] *= al; oacc[dt][2] *= al; oacc[dt][3] *= al; }
+            }
+            m_i = mn;
+#pragma unroll
+            for (int c = 0; c < ACS; ++c) {
+                float p[8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        p[t * 4 + r] = fast_exp(sc[c][t][r] - mn);    // exp(-inf) = 0 for padded keys
+                        l_i += p[t * 4 + r];
+                    }
+                u32x4_t pp;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pp[e] = pack2bf(p[2 * e], p[2 * e + 1]);
+                const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pp);
+                if (s0 + c < nsteps) {
+                    const unsigned char* sl = slot_ready();
+                    bf16x8_t vq[4];
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) vq[dt] = *reinterpret_cast<const bf16x8_t*>(sl + dt * 1024 + lane * 16);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) oacc[dt] = mfma16(vq[dt], pf, oacc[dt]);
+                    slot_done();
+                } else {
+                    // the register kernels multiply an all-zero V^T step by P = 0 here: adds +0 to every accumulator
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) oacc[dt] = mfma16(bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0}, pf, oacc[dt]);
+                }
+            }
+        }
+        l_i += __shfl_xor(l_i, 16, 64);
+        l_i += __shfl_xor(l_i, 32, 64);
+        // ---- text keys (beam-specific): 8 lanes per key, online update ---------------------------------------------
+        float q[KB][8], m[KB], l[KB], o[KB][8];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            m[j] = -INFINITY;
+            l[j] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { q[j][e] = 0.f; o[j][e] = 0.f; }
+            if (j < k) {
+                ld8bf(QKV + (size_t)(row0 + j) * ld3 + h * HD + sub * 8, q[j]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[j][e] *= a.scale;
+            }
+        }
+        auto dot8 = [&](const float (&x)[8], const float (&y)[8]) {
+            float p = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) p += x[e] * y[e];
+            p += __shfl_xor(p, 1, 64);
+            p += __shfl_xor(p, 2, 64);
+            p += __shfl_xor(p, 4, 64);
+            return p;
+        };
+        auto text_item = [&](int jj, const float (&kv)[8], const float (&vv)[8]) {
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                if (j == jj) {
+                    const float sv = dot8(q[j], kv);
+                    const float mn = fmaxf(m[j], sv);
+                    const float al = fast_exp(m[j] - mn);
+                    const float p = fast_exp(sv - mn);
+                    l[j] = l[j] * al + p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[j][e] = o[j][e] * al + p * vv[e];
+                    m[j] = mn;
+                }
+            }
+        };
+        auto unpack = [&](const u32x4_t& r, float (&v)[8]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) unpack2op(r[i], v[2 * i], v[2 * i + 1]);
+        };
+#pragma unroll
+        for (int u = 0; u < TI; ++u) {
+            if (t_j[u] >= 0) {
+                float kv[8], vv[8];
+                unpack(tkr[u], kv);
+                unpack(tvr[u], vv);
+                text_item(t_j[u], kv, vv);
+            }
+        }
+        for (int it = grp + 8 * TI; it < k * nt; it += 8) {                  // long texts: dependent-load path
+            const int j = it / nt, sidx = it % nt;
+            float kv[8], vv[8];
+            if (sidx == a.pos) {
+                ld8bf(QKV + (size_t)(row0 + j) * ld3 + a.d + h * HD + sub * 8, kv);
+                ld8bf(QKV + (size_t)(row0 + j) * ld3 + 2 * a.d + h * HD + sub * 8, vv);
+            } else {
+                const int srow = KB == 1 ? row0 : a.kv_src[(size_t)(row0 + j) * a.ld_src + sidx];
+                ld8bf(TK + ((size_t)srow * a.T_max + sidx) * a.d + h * HD + sub * 8, kv);
+                ld8bf(TV + ((size_t)srow * a.T_max + sidx) * a.d + h * HD + sub * 8, vv);
+            }
+            text_item(j, kv, vv);
+        }
+        // merge the 8 groups of the wave (lanes with equal `sub`): lanes 0..7 end up with the wave's text partial
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {
+                const float m2 = __shfl_xor(m[j], off, 64);
+                const float l2 = __shfl_xor(l[j], off, 64);
+                const float mn = fmaxf(m[j], m2);
+                const float a1 = m[j] == -INFINITY ? 0.f : fast_exp(m[j] - mn);
+                const float a2 = m2 == -INFINITY ? 0.f : fast_exp(m2 - mn);
+                l[j] = l[j] * a1 + l2 * a2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float o2 = __shfl_xor(o[j][e], off, 64);
+                    o[j][e] = o[j][e] * a1 + o2 * a2;
+                }
+                m[j] = mn;
+            }
+        }
+        // ---- the wave's partial per beam row = image keys + text items, through its own LDS slot -------------------
+        if (l15 < k) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[wave][l15][dt * 16 + lg * 4 + r] = oacc[dt][r];
+            if (lg == 0) { part[wave][l15][HD] = m_i; part[wave][l15][HD + 1] = l_i; }
+        }
+        __builtin_amdgcn_wave_barrier();       // a wave reads back only what it wrote itself (its LDS operations complete in order)
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            if (lane < 8 && j < k) {
+                const float mi = part[wave][j][HD], li = part[wave][j][HD + 1];
+                const float mn = fmaxf(mi, m[j]);
+                const float a1 = mi == -INFINITY ? 0.f : fast_exp(mi - mn);
+                const float a2 = m[j] == -INFINITY ? 0.f : fast_exp(m[j] - mn);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part[wave][j][sub * 8 + e] = part[wave][j][sub * 8 + e] * a1 + o[j][e] * a2;
+                if (sub == 0) { part[wave][j][HD] = mn; part[wave][j][HD + 1] = li * a1 + l[j] * a2; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < k * HD; i += 64) {
+            const int j = i / HD, dd = i % HD;
+            const float r1 = part[wave][j][dd] / part[wave][j][HD + 1];
+            if (a.out_frag) O[frag_offset(row0 + j, h * HD + dd, a.d >> 5)] = f2bf(r1);
+            else O[(size_t)(row0 + j) * a.d + h * HD + dd] = f2bf(r1);
+        }
+        __builtin_amdgcn_wave_barrier();       // the next pair reuses this wave's LDS slot
+    }
+}
+
 // ---- host launchers ------------------------------------------------------------------
 hipError_t launch_kv_repack_frag(const void* qkv, void* kf, void* vt, int B, int N, int N_pad, int H, int d, hipStream_t s) {
     if (B <= 0 || N <= 0) return hipSuccess;
@@ -430,6 +790,15 @@ hipError_t launch_attn_decode_mfma(const AttnDecodeArgs& a, int B, int H, hipStr
     //  * TWO waves per pair for long key sequences (6 video frames, a 480 x 640 VQA image: 37 steps would be 10 round trips
     //    in one wave, 5 in two; GIT_BASE_VATEX bs = 16: 1.78k captions/s with one wave, 1.90k with two).
     // waves_per_pair 1 / 2 (GITMI_ATTN_NH) force one of them for A/B.
+    if (a.stream_wgs > 0) {
+        // streaming kernel: bit-identical to the one-wave register kernel; workgroups = min(stream_wgs, pairs / 4)
+        const int nwg = std::max(1, std::min(a.stream_wgs, (p.n_pairs + AS_WAVES - 1) / AS_WAVES));
+        if (a.beams <= 1) hipLaunchKernelGGL((attn_decode_stream_kernel<1, 3, 9>), dim3(nwg), dim3(64 * AS_WAVES), 0, s, p);
+        else if (a.beams <= 2) hipLaunchKernelGGL((attn_decode_stream_kernel<2, 3, 9>), dim3(nwg), dim3(64 * AS_WAVES), 0, s, p);
+        else if (a.beams <= 4) hipLaunchKernelGGL((attn_decode_stream_kernel<4, 3, 9>), dim3(nwg), dim3(64 * AS_WAVES), 0, s, p);
+        else hipLaunchKernelGGL((attn_decode_stream_kernel<8, 3, 8>), dim3(nwg), dim3(64 * AS_WAVES), 0, s, p);
+        return hipGetLastError();
+    }
     const bool one_wave = a.waves_per_pair == 1 || (a.waves_per_pair != 2 && a.N_pad <= 8 * 32);
     if (!one_wave) {
         const dim3 grid(H, B);

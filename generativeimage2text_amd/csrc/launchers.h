@@ -104,6 +104,8 @@ struct AttnDecodeArgs {
     int pairs_per_wg;    // MFMA kernel: (sentence, head) pairs per workgroup (1, 2, 4, 8); > 1 packs the launch onto fewer CUs
     int pairs_per_wave;  // one-wave MFMA kernel: pairs a wave serves one after the other (the next pair's first K/V chunk is
                          // requested while the current pair's text keys / output are worked off); 0 / 1 = one
+    int stream_wgs;      // > 0: the streaming kernel (K/V through an LDS ring, 4 independent waves per workgroup) on at most this
+                         // many workgroups -- each wave walks its share of the pairs; 0: the register kernels above
     int n_pairs;         // set by the launcher
     int waves_per_pair;  // MFMA kernel: 0 / 1 = one wave walks all key steps of a pair (default); 2 = two waves split them (A/B)
 };

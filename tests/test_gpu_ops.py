@@ -327,6 +327,18 @@ def test_attention_decode(B, H, N_img, pos, beams, dtype):
             ref[r, h * 64:(h + 1) * 64] = p @ Vc
     tol = 3e-5 if dtype == torch.float32 else 3e-2
     assert (out - ref).abs().max().item() < tol
+    if dtype == torch.bfloat16:
+        # the kernel forms of the bf16 path (gitmi_op_attn_decode `dbg` bits 16..): one wave per pair with the K/V chunk in
+        # registers, and the streaming kernel (K/V through an LDS ring; each wave walks several pairs) on 1, 2 and 96
+        # workgroups -- the streaming kernel repeats the one-wave arithmetic operation for operation: bitwise equal
+        def run(form):
+            return E.op_attn_decode(qkv.cuda(), ik.cuda(), iv.cuda(), tk.cuda().clone(), tv.cuda().clone(), src.cuda(), B, H, N_img,
+                                    T, pos, beams, dbg=form).cpu()
+        one = run(1 << 16)
+        assert (one.double() - ref).abs().max().item() < tol
+        for wgs in (1, 2, 96):
+            st = run(wgs << 18)
+            assert torch.equal(st, one), (wgs, (st.double() - one.double()).abs().max().item())
 
 
 # ---- sampling branch (decoder.py:1146-1166, 1343-1375) -------------------------------------------------------------
