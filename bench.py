@@ -435,7 +435,7 @@ def main(argv=None, engine_factory=None):
         frames = random_frames(cfg, args.batch, args.frames, seed=rank)
     if args.no_graph:
         eng.set_graph(False)
-    if os.environ.get("BENCH_GEMM_IMPL"):       # experiment knob (A/B of GEMM variants in situ, tools/gpu_epi.sh)
+    if os.environ.get("BENCH_GEMM_IMPL"):       # measurement build: A/B of GEMM variants in situ (tools/gpu_ab.sh)
         from generativeimage2text_amd.engine import set_gemm_impl
         set_gemm_impl(int(os.environ["BENCH_GEMM_IMPL"]))
     # several batches in flight: context i%C runs on its own stream, so the latency-bound decode steps of
