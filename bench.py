@@ -240,9 +240,12 @@ def bench_wide_margin(args, cfg, device):
     reference has a margin >= 0.2; frozen from the unmodified reference by oracle/make_golden.py): the engine must return
     the reference's ids on EVERY row.  One solo pass in this run's precision and search, outside the timed region."""
     import numpy as np
-    if model_family(args.model) != "GIT_BASE" or args.frames != 1 or args.batch != 64 or args.max_steps != 20:
+    name = {("GIT_BASE", 64, 1, "greedy"): "full_wide_b64_greedy", ("GIT_BASE", 64, 1, "beam"): "full_wide_b64_beam4",
+            ("GIT_LARGE", 32, 1, "greedy"): "full_wide_large_b32_greedy",
+            ("GIT_BASE_VATEX", 16, 6, "greedy"): "full_wide_vatex_b16_greedy"}.get(
+        (model_family(args.model), args.batch, max(1, args.frames), args.search))
+    if name is None or args.max_steps != 20:
         return None
-    name = "full_wide_b64_greedy" if args.search == "greedy" else "full_wide_b64_beam4"
     path = os.path.join(ROOT, "tests", "golden", name + ".npz")
     if not os.path.exists(path):
         return None
@@ -251,11 +254,12 @@ def bench_wide_margin(args, cfg, device):
     g = np.load(path)
     wsrc = eval(str(g["weights"]), {"__builtins__": {}}, {})              # ("wide", seed, eos_bias, successor[, images of])
     beams = 1 if args.search == "greedy" else 4
-    eng = Engine(cfg, precision=args.precision, max_batch=64, max_beams=beams, max_frames=1, max_text_len=20)
+    F = max(1, args.frames)
+    eng = Engine(cfg, precision=args.precision, max_batch=args.batch, max_beams=beams, max_frames=F, max_text_len=20)
     try:
         eng.load_state_dict(random_state_dict(cfg, seed=wsrc[1], eos_bias=wsrc[2], successor=wsrc[3]))
         search = Engine.make_search("greedy", 20, 1, 1) if beams == 1 else Engine.make_search("beam", 20, 4, 2, 0.6)
-        tokens, _, info = eng.generate(seeded_images(cfg, g["image_seeds"].tolist(), device=device), search, sync=True)
+        tokens, _, info = eng.generate(seeded_images(cfg, g["image_seeds"].tolist(), device=device, frames=F), search, sync=True)
     finally:
         eng.close()
     got = (tokens if beams > 1 else tokens[:, :int(info.tolist()[0])]).cpu().numpy()
@@ -265,7 +269,7 @@ def bench_wide_margin(args, cfg, device):
     need = int(ref.shape[0]) if (beams == 1 or args.precision == "f32") else WIDE_BEAM_FLOOR      # beam search: no margin certificate
     return {"reference": f"tests/golden/{name}.npz", "rows": int(ref.shape[0]), "identical": same,
             "required": need, "ok": same >= need,
-            "min_reference_margin_greedy": round(float(np.load(os.path.join(ROOT, "tests", "golden", "full_wide_b64_greedy.npz"))["step_margin"].min()), 4)}
+            "min_reference_margin": round(float(g["step_margin"].min()), 4) if beams == 1 else None}
 
 
 class _HostDev:

@@ -60,7 +60,7 @@ IDENTICAL_FLOORS = {       # measured over the kernel variants of rounds 3-4: 49
 }
 # goldens whose reference margins are wide on every decision (oracle/make_golden.py asserts >= 0.2 when it freezes them): every
 # row must equal the reference's ids in EVERY precision -- north_star's identity clause in the regime where it is decidable
-IDENTICAL_REQUIRED = ("full_wide_b64_greedy",)
+IDENTICAL_REQUIRED = ("full_wide_b64_greedy", "full_wide_large_b32_greedy", "full_wide_vatex_b16_greedy")     # cfg2, cfg4, cfg5
 # the same weights and images under beam 4 (full_wide_b64_beam4): a beam step keeps 2k = 8 candidates whose runner-ups are
 # Gaussian-close for any weights (median adjacent gap 0.01), so no margin certificate exists; measured 62 of 64 rows in
 # bf16 and 63 in f16, solo and serving shapes alike (profiles/r04_f_parity_measured.jsonl), f32 mode 64 of 64

@@ -98,11 +98,13 @@ def random_frames(cfg: GitModelConfig, batch: int, frames: int = 1, seed: int = 
     return [torch.randn(batch, 3, cfg.image_size, cfg.image_size, generator=g).to(device) for _ in range(frames)]
 
 
-def seeded_images(cfg: GitModelConfig, image_seeds, device="cuda") -> List[torch.Tensor]:
-    """One single-frame batch whose image i is drawn from its OWN generator (seed image_seeds[i]): a fixture can name
-    the images it kept (tests/golden/full_wide_*.npz `image_seeds`) without storing them."""
-    imgs = []
+def seeded_images(cfg: GitModelConfig, image_seeds, device="cuda", frames: int = 1) -> List[torch.Tensor]:
+    """`frames` batches whose image i is drawn from its OWN generator (seed image_seeds[i]; the frames of a clip one after
+    the other from it): a fixture can name the images it kept (tests/golden/full_wide_*.npz `image_seeds`) without storing
+    them."""
+    per_frame = [[] for _ in range(frames)]
     for sd in image_seeds:
         g = torch.Generator().manual_seed(7_000_000 + int(sd))
-        imgs.append(torch.randn(3, cfg.image_size, cfg.image_size, generator=g))
-    return [torch.stack(imgs).to(device)]
+        for f in range(frames):
+            per_frame[f].append(torch.randn(3, cfg.image_size, cfg.image_size, generator=g))
+    return [torch.stack(imgs).to(device) for imgs in per_frame]

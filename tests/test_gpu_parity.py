@@ -250,7 +250,8 @@ def test_full_batch_ids_against_reference(name, serving):
 
 @pytest.mark.parametrize("serving", [False, True], ids=["solo", "serving"])
 @pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
-def test_wide_margin_batch_ids_identical_to_reference(prec, serving):
+@pytest.mark.parametrize("name", ["full_wide_b64_greedy", "full_wide_large_b32_greedy", "full_wide_vatex_b16_greedy"])
+def test_wide_margin_batch_ids_identical_to_reference(name, prec, serving):
     """north_star: "greedy outputs bit-identical to reference token IDs".  With plain random-init weights that clause is
     undecidable for ANY 16-bit pipeline: Gaussian logits over 30522 tokens put a top-1 / top-2 gap below the pipeline's own
     logit error somewhere in almost every 19-step row (on the benchmark's golden every one of the 64 rows has such a
@@ -258,14 +259,14 @@ def test_wide_margin_batch_ids_identical_to_reference(prec, serving):
     where it IS decidable -- the benchmark's weight family with a successor structure on the output matrix
     (synthetic.random_state_dict(successor=1.0)) and 64 images on which EVERY decision of the fp32 reference has a margin
     >= 0.2 (oracle/make_golden.py: select_wide_images; first tokens differ with the image, 20 distinct ids per row) -- and
-    there every precision of the engine must return the reference's ids on 64 of 64 rows."""
+    there every precision of the engine must return the reference's ids on 64 of 64 rows.  The same construction for the
+    other two greedy BASELINE configurations: cfg4 GIT_LARGE B = 32 (32 of 32) and cfg5 VATEX 6 frames B = 16 (16 of 16)."""
     from generativeimage2text_amd.parity import ids_parity
-    name = "full_wide_b64_greedy"
     g = load_golden(name)
     cfg, w, frames, search, _ = MG.full_case_inputs(name)
-    B = frames[0].shape[0]
-    assert float(g["step_margin"].min()) >= 0.1 and B == 64
-    eng = make_engine(cfg, w, prec, B, search, serving=serving)
+    B, F = frames[0].shape[0], len(frames)
+    assert float(g["step_margin"].min()) >= 0.1 and B == MG.FULL_CASES[name][2]
+    eng = make_engine(cfg, w, prec, B, search, frames=F, serving=serving)
     tokens, logprobs, info = eng.generate([f.cuda() for f in frames], search_struct(search))
     preds, lps = format_like_reference(search, tokens, logprobs, info, None)
     logits = eng.step_logits(torch.from_numpy(g["tf_tokens"]))[:4, ::3].cpu().numpy()
@@ -277,7 +278,8 @@ def test_wide_margin_batch_ids_identical_to_reference(prec, serving):
                        lerr_frac=round(lerr / span, 6), min_margin=round(float(g["step_margin"].min()), 4), **stats)
     assert stats["identical"] == B and stats["safe_rows"] == B, stats
     assert np.allclose(lps.numpy(), g["logprobs"], atol=1e-4 if prec == "f32" else 0.05), np.abs(lps.numpy() - g["logprobs"]).max()
-    assert len({tuple(r) for r in preds.numpy().tolist()}) >= 8        # the rows are not copies of each other
+    # the rows are not copies of each other (the VATEX model's first token is all but image-independent: one caption)
+    assert len({tuple(r) for r in preds.numpy().tolist()}) >= {64: 8, 32: 4}.get(B, 1)
 
 
 @pytest.mark.parametrize("serving", [False, True], ids=["solo", "serving"])
