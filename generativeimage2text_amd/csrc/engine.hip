@@ -1008,7 +1008,13 @@ static int dgemm(gitmi_engine* e, hipStream_t s, const DGemmArgs& g_in) {
     // profiles/r03_zzz_ab_bench_lines.txt); alone, one workgroup per (strip, row block) is 3.5 us faster per launch
     g.no_row_walk = e->dgemm_no_row_walk >= 0 ? e->dgemm_no_row_walk : e->shared_device ? 0 : 1;
     g.strips_per_wg = e->dgemm_strips >= 0 ? e->dgemm_strips : e->shared_device ? 2 : 1;
-    g.rows_per_wg = e->dgemm_rows > 0 ? e->dgemm_rows : (e->shared_device || g.M > 64) ? 64 : 16;
+    // rows per workgroup of the N = 768 chain GEMMs: 16 alone (48 strips x R/16 workgroups, shortest launch); next to other
+    // contexts 32 -- half the workgroups for +1 us per launch.  Round 3 took 64 there (a quarter of the workgroups, +5 us:
+    // +1.5 % captions/s with the kernels of the time); with the walking vocabulary head and the two-strip wide GEMMs in place
+    // 32 gives the same throughput and a 7 % shorter decode step (profiles/r04_k_policy_components_bench_lines.txt:
+    // 16 / 32 / 64 rows = 11.18k / 11.24k / 11.20k captions/s at 0.297 / 0.310 / 0.333 ms per step).  > 64 rows (beam
+    // batches): 64, faster alone too.
+    g.rows_per_wg = e->dgemm_rows > 0 ? e->dgemm_rows : g.M > 64 ? 64 : e->shared_device ? 32 : 16;
     SpanGuard sp(e, s, TAG_GEMM_OTHER, 2.0 * (double)g.M * (double)g.N * (double)g.K);
     HIPCK(launch_dgemm(g, s));
     return 0;

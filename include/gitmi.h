@@ -156,13 +156,14 @@ int  gitmi_clone(gitmi_engine* src, gitmi_engine** out);
  * context waits for it either).  Destroying either context of a link removes the link. */
 int  gitmi_set_encode_after(gitmi_engine* e, gitmi_engine* after);
 
-/* serving policy (ABI 6): tell a context that other contexts keep the device busy beside it.  Kernel shapes are then chosen
+/* serving policy: tell a context that other contexts keep the device busy beside it.  Kernel shapes are then chosen
  * for what a launch costs the device as a whole, not for its own duration: the image-encoder GEMMs always take the
  * 256x256 tile (a partial round's idle CUs are filled by the other contexts; measured +2.2 % captions/s in the mixed
- * schedule, -3 % for a context alone), the N = 768 GEMMs of the decode chain take 64 rows per workgroup (a quarter of the
- * workgroups; +1.5 %, beam-4 +4.5 %), the decode attention packs 8 instead of 4 (sentence, head) pairs per workgroup (+0.8 %), the wide
+ * schedule, -3 % for a context alone), the N = 768 GEMMs of the decode chain take 32 rows per workgroup (64 for beam
+ * batches: beam-4 +4.5 %), the decode attention packs 8 instead of 4 (sentence, head) pairs per workgroup (+0.8 %), the wide
  * chain GEMMs take two 16-column strips per workgroup one after the other (+1.3 %) and, for beam batches, walk their row
- * blocks in one workgroup per weight strip (beam-4 +1.7 %).
+ * blocks in one workgroup per weight strip (beam-4 +1.7 %), the vocabulary head runs on ~60 workgroups that each walk four
+ * column blocks (+1 %).
  * Results are bit-identical either way.  Clones inherit the setting of their source at clone time. */
 int  gitmi_set_shared_device(gitmi_engine* e, int on);
 
