@@ -18,6 +18,13 @@ SHAPES = [  # (name, M, N, K, out dtype, act, residual)
 ]
 
 
+# GEMM_BENCH_EXTRA="name:M:N:K[:f32res]" (comma-separated): extra shapes, e.g. the two K halves of a split-K launch stacked as rows
+for _spec in filter(None, os.environ.get("GEMM_BENCH_EXTRA", "").split(",")):
+    _f = _spec.split(":")
+    _res = len(_f) > 4 and _f[4] == "f32res"
+    SHAPES.append((_f[0], int(_f[1]), int(_f[2]), int(_f[3]), torch.float32 if _res else torch.bfloat16, 0, _res))
+
+
 def bench(fn, reps=20):
     for _ in range(3):
         fn()
