@@ -715,3 +715,29 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), lib, "-Wl,-rpath," + os.path.dirname(lib),
                         "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr          # every symbol the header declares resolves in the library
+
+
+def test_margin_threshold_follows_the_logit_bound():
+    """parity.margin_threshold: for one-beam searches the margin below which a row may leave the reference's ids is
+    2 x the (fixed) logit-error bound, capped by the per-geometry constant; beam search keeps 2 x the constant; the f16 build
+    scales the constant.  ids_parity with it: a divergence at a wide margin fails, at a narrow one passes, the floor on
+    identical rows is enforced."""
+    from generativeimage2text_amd import parity as P
+    cap = P.bf16_bounds("GIT_BASE")["thr"]
+    assert P.margin_threshold("GIT_BASE", 0.0179, False) == pytest.approx(0.0358)            # the benchmark workload's bound
+    assert P.margin_threshold("GIT_BASE", 0.35, False) == cap                                # wide-span oracle weights: the cap
+    assert P.margin_threshold("GIT_BASE", 0.0179, True) == pytest.approx(2 * cap)            # beam: fixed
+    assert P.margin_threshold("GIT_BASE", 1.0, False, "f16") == pytest.approx(cap * P.F16_SCALE["thr"])
+    ref = np.array([[101, 5, 6, 7], [101, 8, 9, 10]])
+    margin = np.array([[0.5, 0.01, 0.5], [0.5, 0.5, 0.5]], dtype=np.float32)
+    got = ref.copy()
+    got[0, 2:] = [60, 70]                                    # row 0 diverges at decision 1 (margin 0.01): allowed
+    st = P.ids_parity(got, ref, margin, 0.0358, chained=False)
+    assert st["identical"] == 1 and st["safe_rows"] == 1 and st["first_divergence_margin_max"] == pytest.approx(0.01)
+    with pytest.raises(AssertionError, match="floor"):
+        P.ids_parity(got, ref, margin, 0.0358, chained=False, min_identical=2)
+    bad = ref.copy()
+    bad[1, 1] = 99                                           # row 1 has no narrow decision: any divergence is a failure
+    with pytest.raises(AssertionError):
+        P.ids_parity(bad, ref, margin, 0.0358, chained=False)
+    assert set(P.IDENTICAL_REQUIRED) == {"full_wide_b64_greedy", "full_wide_large_b32_greedy", "full_wide_vatex_b16_greedy"}
