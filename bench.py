@@ -110,6 +110,8 @@ def cpu_baseline(sample_batch: int, max_steps: int, threads: int = 0, repeats: i
                           f"{pr['port_s']} s vs {pr['reference_s']} s)")
     except (OSError, KeyError, ValueError):
         pass
+    out["bs64_note"] = ("the GPU workload's own batch (bs = 64) is behind --cpu-big-batch 64 (one pass = 75 s): 0.85 captions/s on a host of "
+                        "this class (profiles/r03_a_bench.json); the reference's modules at bs = 64 here: 59.4 s against the port's 61.8 s")
     if big_batch and big_batch != sample_batch:
         big = _cpu_run(big_batch, max_steps, threads)
         out["bs%d" % big_batch] = {"value": round(big["captions_per_s"], 4), "vit_s": round(big["vit_s"], 2),
