@@ -1052,12 +1052,14 @@ static int decode_layers_impl(gitmi_engine* e, const int* kv_src, int ld_ids, in
         a.waves_per_pair = e->attn_nh;
         a.pairs_per_wg = e->attn_pw > 0 ? e->attn_pw : e->shared_device ? 8 : 4;
         a.pairs_per_wave = e->attn_ppw > 0 ? e->attn_ppw : 1;
-        // streaming kernel (kernels_attn_decode.hip: K/V through per-wave LDS rings): measurement builds only
-        // (GITMI_ATTN_STREAM).  On 192 workgroups it is 4 us faster per launch than the register kernel for a context that has
-        // the device to itself, but its fp32 partials differ from the register kernel's in the last bit (the compiler fuses
-        // the a*b + c*d updates of the text path differently in the two kernels): adopting it for one policy only would end
-        // the bitwise neutrality of gitmi_set_shared_device, and in the mixed schedule it does not gain (profiles/r04_f_*)
-        a.stream_wgs = e->attn_stream >= 0 ? e->attn_stream : 0;
+        // a context that has the device to itself streams the image K/V through LDS rings (kernels_attn_decode.hip: all of a
+        // pair's first 36 KiB requested at once, no second memory round trip): 11.7 instead of 15.6 us per launch on 192
+        // workgroups.  Same arithmetic as the one-wave register kernel, every fused multiply-add written out in both, so the
+        // two agree bit for bit and gitmi_set_shared_device stays bitwise neutral.  Next to other contexts the register kernel
+        // packed 8 pairs per workgroup stays: a CU streams ~24 GB/s from HBM whatever the kernel form, and fewer workgroups
+        // of the streaming kernel only stretch the launch (profiles/r04_f_*)
+        const bool stream_ok = !e->shared_device && a.N_pad <= 8 * 32 && B * c.dec_heads >= 384 && e->attn_nh != 2;
+        a.stream_wgs = e->attn_stream >= 0 ? e->attn_stream : stream_ok ? 192 : 0;
         if (e->f32) HIPCK(launch_attn_decode(a, B, c.dec_heads, true, s));
         else if (!GITMI_SKIPPED(e, 1)) HIPCK(launch_attn_decode_mfma(a, B, c.dec_heads, s));
         if (chain) {

@@ -85,6 +85,9 @@ constexpr int ACS = 4;          // key steps per chunk and wave
 // K/V registers cost the 512-thread form a few spilled registers, which the single-pair form must not pay.
 template <int KB, int TI = 3, int PW = 1, int NH = 2, bool LOOP = false>
 __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDecodeArgs a) {
+    // every fused multiply-add of the softmax bookkeeping is written out (fmaf): with contraction left to the compiler the
+    // a*b + c*d updates fuse differently per instantiation, and results must not depend on the packing or the kernel form
+#pragma clang fp contract(off)
     __shared__ float part[PW][NH][KB][HD + 2];    // [pair][half][beam]: o[64], m, l
     constexpr int PT = 64 * NH;                   // threads of a pair
 
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
     auto dot8 = [&](const float (&x)[8], const float (&y)[8]) {
         float p = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) p += x[e] * y[e];
+        for (int e = 0; e < 8; ++e) p = fmaf(x[e], y[e], p);
         p += __shfl_xor(p, 1, 64);
         p += __shfl_xor(p, 2, 64);
         p += __shfl_xor(p, 4, 64);
@@ -294,9 +297,9 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
                 const float mn = fmaxf(m[j], sv);
                 const float al = fast_exp(m[j] - mn);
                 const float p = fast_exp(sv - mn);
-                l[j] = l[j] * al + p;
+                l[j] = fmaf(l[j], al, p);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[j][e] = o[j][e] * al + p * vv[e];
+                for (int e = 0; e < 8; ++e) o[j][e] = fmaf(o[j][e], al, p * vv[e]);
                 m[j] = mn;
             }
         }
@@ -349,11 +352,11 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
             const float mn = fmaxf(m[j], m2);
             const float a1 = m[j] == -INFINITY ? 0.f : fast_exp(m[j] - mn);
             const float a2 = m2 == -INFINITY ? 0.f : fast_exp(m2 - mn);
-            l[j] = l[j] * a1 + l2 * a2;
+            l[j] = fmaf(l[j], a1, l2 * a2);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float o2 = __shfl_xor(o[j][e], off, 64);
-                o[j][e] = o[j][e] * a1 + o2 * a2;
+                o[j][e] = fmaf(o[j][e], a1, o2 * a2);
             }
             m[j] = mn;
         }
@@ -379,8 +382,8 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
             const float a1 = mi == -INFINITY ? 0.f : fast_exp(mi - mn);
             const float a2 = m[j] == -INFINITY ? 0.f : fast_exp(m[j] - mn);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) part[hp][half][j][sub * 8 + e] = part[hp][half][j][sub * 8 + e] * a1 + o[j][e] * a2;
-            if (sub == 0) { part[hp][half][j][HD] = mn; part[hp][half][j][HD + 1] = li * a1 + l[j] * a2; }
+            for (int e = 0; e < 8; ++e) part[hp][half][j][sub * 8 + e] = fmaf(part[hp][half][j][sub * 8 + e], a1, o[j][e] * a2);
+            if (sub == 0) { part[hp][half][j][HD] = mn; part[hp][half][j][HD + 1] = fmaf(li, a1, l[j] * a2); }
         }
     }
     if constexpr (NH > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
@@ -398,8 +401,8 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
         const float mm = fmaxf(m0, m1);
         const float a0 = m0 == -INFINITY ? 0.f : fast_exp(m0 - mm);
         const float a1 = m1 == -INFINITY ? 0.f : fast_exp(m1 - mm);
-        const float num = a0 * part[hp][0][j][dd] + a1 * part[hp][H1][j][dd];
-        const float den = a0 * part[hp][0][j][HD + 1] + a1 * part[hp][H1][j][HD + 1];
+        const float num = fmaf(a0, part[hp][0][j][dd], a1 * part[hp][H1][j][dd]);
+        const float den = fmaf(a0, part[hp][0][j][HD + 1], a1 * part[hp][H1][j][HD + 1]);
         const float r = num / den;
         if (a.out_frag) O[frag_offset(row0 + j, h * HD + dd, a.d >> 5)] = f2bf(r);
         else O[(size_t)(row0 + j) * a.d + h * HD + dd] = f2bf(r);
@@ -454,6 +457,7 @@ constexpr int AS_SLOT = 4096;                  // bytes: K or V^T of one 32-key 
 
 template <int KB, int TI, int RING>
 __global__ __launch_bounds__(64 * AS_WAVES) void attn_decode_stream_kernel(AttnDecodeArgs a) {
+#pragma clang fp contract(off)
     static_assert(RING >= 2 && RING <= 12, "ring depth");
     __shared__ __attribute__((aligned(16))) unsigned char ring_mem[AS_WAVES][RING * AS_SLOT];
     __shared__ float part[AS_WAVES][KB][HD + 2];   // [wave][beam]: o[64], m, l
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(64 * AS_WAVES) void attn_decode_stream_kernel(AttnD
         auto dot8 = [&](const float (&x)[8], const float (&y)[8]) {
             float p = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) p += x[e] * y[e];
+            for (int e = 0; e < 8; ++e) p = fmaf(x[e], y[e], p);
             p += __shfl_xor(p, 1, 64);
             p += __shfl_xor(p, 2, 64);
             p += __shfl_xor(p, 4, 64);
@@ -685,9 +689,9 @@ __global__ __launch_bounds__(64 * AS_WAVES) void attn_decode_stream_kernel(AttnD
                     const float mn = fmaxf(m[j], sv);
                     const float al = fast_exp(m[j] - mn);
                     const float p = fast_exp(sv - mn);
-                    l[j] = l[j] * al + p;
+                    l[j] = fmaf(l[j], al, p);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[j][e] = o[j][e] * al + p * vv[e];
+                    for (int e = 0; e < 8; ++e) o[j][e] = fmaf(o[j][e], al, p * vv[e]);
                     m[j] = mn;
                 }
             }
@@ -728,11 +732,11 @@ __global__ __launch_bounds__(64 * AS_WAVES) void attn_decode_stream_kernel(AttnD
                 const float mn = fmaxf(m[j], m2);
                 const float a1 = m[j] == -INFINITY ? 0.f : fast_exp(m[j] - mn);
                 const float a2 = m2 == -INFINITY ? 0.f : fast_exp(m2 - mn);
-                l[j] = l[j] * a1 + l2 * a2;
+                l[j] = fmaf(l[j], a1, l2 * a2);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float o2 = __shfl_xor(o[j][e], off, 64);
-                    o[j][e] = o[j][e] * a1 + o2 * a2;
+                    o[j][e] = fmaf(o[j][e], a1, o2 * a2);
                 }
                 m[j] = mn;
             }
@@ -754,8 +758,8 @@ __global__ __launch_bounds__(64 * AS_WAVES) void attn_decode_stream_kernel(AttnD
                 const float a1 = mi == -INFINITY ? 0.f : fast_exp(mi - mn);
                 const float a2 = m[j] == -INFINITY ? 0.f : fast_exp(m[j] - mn);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) part[wave][j][sub * 8 + e] = part[wave][j][sub * 8 + e] * a1 + o[j][e] * a2;
-                if (sub == 0) { part[wave][j][HD] = mn; part[wave][j][HD + 1] = li * a1 + l[j] * a2; }
+                for (int e = 0; e < 8; ++e) part[wave][j][sub * 8 + e] = fmaf(part[wave][j][sub * 8 + e], a1, o[j][e] * a2);
+                if (sub == 0) { part[wave][j][HD] = mn; part[wave][j][HD + 1] = fmaf(li, a1, l[j] * a2); }
             }
         }
         __builtin_amdgcn_wave_barrier();
