@@ -104,14 +104,19 @@ def cpu_baseline(sample_batch: int, max_steps: int, threads: int = 0, repeats: i
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "port_vs_reference.json")) as f:
             pr = json.load(f)
         out["port_vs_reference_ratio"] = pr["port_vs_reference_ratio"]
-        out["reference_estimate"] = round(out["value"] / pr["port_vs_reference_ratio"], 4)
+        # EXTRAPOLATED: this host's port figure / a ratio stored in oracle/port_vs_reference.json (measured on another host)
+        out["reference_estimate"] = {"value": round(out["value"] / pr["port_vs_reference_ratio"], 4),
+                                     "how": "this run's port value / the stored ratio (not a measurement of this host)",
+                                     "ratio_measured_on": {"host_cpus": pr.get("host_cpus"), "threads": pr.get("threads"),
+                                                           "batch": pr.get("batch")}}
         out["sample"] += (f"; the port runs at {pr['port_vs_reference_ratio']:.2f} x the speed of the reference's own modules "
                           f"(bs={pr['batch']}, {pr['threads']} threads, measured where /root/reference exists: "
                           f"{pr['port_s']} s vs {pr['reference_s']} s)")
     except (OSError, KeyError, ValueError):
         pass
-    out["bs64_note"] = ("the GPU workload's own batch (bs = 64) is behind --cpu-big-batch 64 (one pass = 75 s): 0.85 captions/s on a host of "
-                        "this class (profiles/r03_a_bench.json); the reference's modules at bs = 64 here: 59.4 s against the port's 61.8 s")
+    out["bs64_note_historical"] = ("NOT measured in this run: the GPU workload's own batch (bs = 64) is behind --cpu-big-batch 64 (one "
+                                   "pass = 75 s); round 3 measured 0.85 captions/s on a GPU-box host (profiles/r03_a_bench.json), and "
+                                   "in the build container the reference's modules took 59.4 s against the port's 61.8 s at bs = 64")
     if big_batch and big_batch != sample_batch:
         big = _cpu_run(big_batch, max_steps, threads)
         out["bs%d" % big_batch] = {"value": round(big["captions_per_s"], 4), "vit_s": round(big["vit_s"], 2),
@@ -231,7 +236,65 @@ def bench_parity(eng, tokens, info, args):
     st["logit_err_bound"] = round(lbound, 5)
     st["identical_floor"] = floor
     st["reference"] = f"tests/golden/{name}.npz"
+    if not chained:
+        st["teacher_forced"] = bench_teacher_forced(eng, name, g, args)
+        if st["teacher_forced"] is not None and not st["teacher_forced"]["ok"]:
+            st["ok"] = False
+            st.setdefault("violation", "teacher_forced: " + st["teacher_forced"].get("violation", ""))
     return st
+
+
+def bench_teacher_forced(eng, name, g, args):
+    """EVERY decision of every row against the reference (generativeimage2text_amd.parity.teacher_forced_parity): the engine is
+    fed the reference's own ids[:, :t], t = 1 .. L-1, through gitmi_step_logits; the argmax after the no-repeat rule must be the
+    reference's id wherever its fp32 margin is >= 2 x the fixed logit-error bound, and the logit error is taken over every
+    row x every vocabulary column x every decision (against an f32-mode engine built here on the same weights and images,
+    itself held to 1e-4 of the frozen reference logits of tests/golden/<case>_tf.npz)."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", name + "_tf.npz")
+    if not os.path.isfile(path):
+        return None
+    from generativeimage2text_amd.configs import config_for_model
+    from generativeimage2text_amd.engine import Engine
+    from generativeimage2text_amd.parity import teacher_forced_parity, tf_bounds
+    from generativeimage2text_amd.synthetic import random_frames, random_state_dict
+    gt = np.load(path)
+    cfg = config_for_model(args.model)
+    span = float(gt["logit_max"]) - float(gt["logit_min"])
+    b = tf_bounds(name, model_family(args.model), args.precision, span)
+    frames = random_frames(cfg, args.batch, args.frames, seed=0)
+    f32_logits = None
+    e32 = None
+    if args.precision != "f32":
+        e32 = Engine(cfg, precision="f32", max_batch=args.batch, max_beams=1, max_frames=max(1, args.frames),
+                     max_text_len=args.max_steps)
+        e32.load_state_dict(random_state_dict(cfg, seed=parity_golden(args)[1]))
+        e32.encode(frames, return_features=False)
+        f32_logits = e32.step_logits
+    try:
+        eng.encode(frames, return_features=False)
+        st = teacher_forced_parity(eng.step_logits, g["predictions"], gt, cfg.eos, b["thr"], b["lerr"], f32_step_logits=f32_logits)
+    finally:
+        if e32 is not None:
+            e32.close()
+    st["reference"] = f"tests/golden/{name}_tf.npz"
+    return st
+
+
+def alt_precision_line(argv_child):
+    """The fp16-operand build (libgitmi_f16.so: the same kernels, same MFMA rate on gfx950, 3 more mantissa bits per operand) on
+    the SAME workload and schedule, run as a child `python bench.py --precision f16 --brief` after this process has gone idle:
+    captions/s of a short timed loop and the same `parity` object, so the default line carries both builds."""
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv_child
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        c = json.loads(line)
+    except Exception as exc:          # the headline must not die with the side measurement
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    return {"precision": c["dtype"], "library": c["config"]["library"], "captions_per_s": c["value"],
+            "ms_per_step": c["ms_per_step"], "steps": c["steps"], "parity": c.get("parity"),
+            "timed_ids_equal_solo": c.get("timed_ids_equal_solo")}
 
 
 def bench_wide_margin(args, cfg, device):
@@ -254,7 +317,8 @@ def bench_wide_margin(args, cfg, device):
     from generativeimage2text_amd.engine import Engine
     from generativeimage2text_amd.synthetic import random_state_dict, seeded_images
     g = np.load(path)
-    wsrc = eval(str(g["weights"]), {"__builtins__": {}}, {})              # ("wide", seed, eos_bias, successor[, images of])
+    import ast
+    wsrc = ast.literal_eval(str(g["weights"]))              # ("wide", seed, eos_bias, successor[, images of])
     beams = 1 if args.search == "greedy" else 4
     F = max(1, args.frames)
     eng = Engine(cfg, precision=args.precision, max_batch=args.batch, max_beams=beams, max_frames=F, max_text_len=20)
@@ -357,16 +421,10 @@ def main(argv=None, engine_factory=None):
                     help="N > 1: N requests of --batch images are served by ONE engine pass over N x batch rows "
                          "(Engine.generate_coalesced; the concatenation is inside the timed region).  A step is still one "
                          "request of --batch images; the default 1 is the BASELINE configuration (one pass per request)")
-    ap.add_argument("--decode-group", type=int, default=1,
-                    help="G > 1: the contexts are MEMBERS of decode groups of G (gitmi_set_decode_group): every request "
-                         "of --batch images is encoded + prefilled by its own context as it is submitted, and the G "
-                         "requests of a group share ONE decode chain over G x batch rows (gitmi_group_decode).  A step is "
-                         "still one request of --batch images; --contexts must be a multiple of G")
-    ap.add_argument("--phased", type=int, default=0,
-                    help="G > 0: schedule the contexts in groups of G batches -- the image encoders (+ prefill) of a group "
-                         "first (at most --encoder-chains at a time), then its G decode chains side by side with no "
-                         "encoder running (gitmi_generate_encode / gitmi_generate_decode); 0: every context submits "
-                         "whole calls and the phases of different batches mix freely")
+    ap.add_argument("--brief", action="store_true",
+                    help="timed loop + parity only: no roofline passes, no CPU baseline (what the alt_precision child runs)")
+    ap.add_argument("--no-alt-precision", action="store_true",
+                    help="skip the child run of the fp16-operand build that the default bf16 line reports as alt_precision")
     ap.add_argument("--experiment", action="store_true",
                     help="A/B harness only: load libgitmi_exp.so (the bf16 build with -DGITMI_EXPERIMENT), whose engine reads "
                          "kernel-shape overrides from GITMI_* environment variables; the line says so in config.library")
@@ -407,24 +465,14 @@ def main(argv=None, engine_factory=None):
     from generativeimage2text_amd.engine import Engine
     from generativeimage2text_amd.synthetic import random_state_dict, random_frames
 
-    if (args.decode_group > 1 or args.phased > 0 or os.environ.get("BENCH_GEMM_IMPL")) and not args.experiment and not standin:
-        raise SystemExit("--decode-group / --phased / BENCH_GEMM_IMPL are schedules and switches of the measurement build "
-                         "(they measured slower than the default mixed schedule: DESIGN.md section 4): add --experiment")
+    if os.environ.get("BENCH_GEMM_IMPL") and not args.experiment and not standin:
+        raise SystemExit("BENCH_GEMM_IMPL is a switch of the measurement build: add --experiment")
     if args.experiment:
         from generativeimage2text_amd.engine import use_experiment_build
         use_experiment_build(True)
     cfg = config_for_model(args.model)
     beams = 1 if args.search == "greedy" else 4
     coalesce = max(1, args.coalesce)
-    if coalesce > 1 and args.phased > 0:
-        raise SystemExit("--coalesce and --phased are separate schedules")
-    dgroup = max(1, args.decode_group)
-    if dgroup > 1:
-        if coalesce > 1 or args.phased > 0:
-            raise SystemExit("--decode-group, --coalesce and --phased are separate schedules")
-        if args.contexts % dgroup or args.steps % dgroup:
-            raise SystemExit(f"--contexts {args.contexts} and --steps {args.steps} must be multiples of --decode-group {dgroup}")
-        args.warmup = (args.warmup + dgroup - 1) // dgroup * dgroup
     if args.steps % coalesce:
         raise SystemExit(f"--steps {args.steps} is not a multiple of --coalesce {coalesce} (a partial pass would re-capture "
                          f"the context's hipGraph inside the timed region)")
@@ -446,20 +494,10 @@ def main(argv=None, engine_factory=None):
         set_gemm_impl(int(os.environ["BENCH_GEMM_IMPL"]))
     # several batches in flight: context i%C runs on its own stream, so the latency-bound decode steps of
     # one batch overlap the MFMA-bound encoder of the next (weights are shared, workspaces are not)
-    if args.phased > 0:
-        args.contexts = args.phased
     if args.contexts > 1 and not args.solo_policy and not standin:
         eng.set_shared_device(True)             # before cloning: the clones inherit it
-    groups = []
-    if dgroup > 1:
-        # `eng` stays a plain context (solo passes, profiling); members and group contexts are clones of it
-        ctxs = [eng.clone() for _ in range(args.contexts)]
-        groups = [eng.clone(max_batch=dgroup * args.batch) for _ in range(args.contexts // dgroup)]
-        for i, c in enumerate(ctxs):
-            c.set_decode_group(groups[i // dgroup], (i % dgroup) * args.batch)
-    else:
-        ctxs = [eng] + [eng.clone() for _ in range(max(1, args.contexts) - 1)]
-    for c in ctxs[1:] + groups:
+    ctxs = [eng] + [eng.clone() for _ in range(max(1, args.contexts) - 1)]
+    for c in ctxs[1:]:
         if args.no_graph:
             c.set_graph(False)
     chains = max(1, args.encoder_chains)
@@ -472,8 +510,6 @@ def main(argv=None, engine_factory=None):
     stride = int(os.environ.get("BENCH_STREAM_STRIDE", "1"))
     pool = [dev.Stream() for _ in range(len(ctxs) * stride)]
     streams = pool[::stride][:len(ctxs)]
-    gstreams = [dev.Stream() for _ in groups]
-    pending = [[] for _ in groups]
     counter = [0]
     if args.search == "greedy":
         search = Engine.make_search("greedy", args.max_steps, 1, 1)
@@ -506,71 +542,10 @@ def main(argv=None, engine_factory=None):
                 lat_events.append((e0, e1))
         return tokens, info
 
-    def grouped_step(record_latency=False):
-        """one request: its member context encodes + prefills it; the request that completes a group submits the group's
-        decode chain over all G requests"""
-        i = counter[0] % len(ctxs)
-        counter[0] += 1
-        g, slot = divmod(i, dgroup)
-        with dev.stream(streams[i]):
-            if record_latency:
-                e0 = dev.Event(enable_timing=True)
-                e0.record()
-                pending[g].append(e0)
-            ctxs[i].generate_encode(frames, search)
-        if slot != dgroup - 1:
-            return None
-        with dev.stream(gstreams[g]):
-            tokens, logprobs, info = groups[g].group_decode(max(1, args.frames), dgroup * args.batch, search, sync=False)
-            if world > 1:
-                for r in range(dgroup):
-                    gather_results(tokens[r * args.batch:(r + 1) * args.batch], logprobs[r * args.batch:(r + 1) * args.batch])
-            if record_latency:
-                e1 = dev.Event(enable_timing=True)
-                e1.record()
-                lat_events.extend((e0, e1) for e0 in pending[g])
-                pending[g] = []
-        return tokens[-args.batch:], info
-
     def fence():
         if world > 1:
             dist.barrier()
         dev.synchronize()
-
-    # phased schedule: one group = up to G batches; all encoders (+ prefill) of the group, then all its decode chains.
-    # Stream i carries batch i of every group; events make every decode wait for the group's LAST encoder and every
-    # encoder of the next group for the group's decodes, so that no encoder ever runs next to a decode chain.
-    group_dec_done = []
-
-    def run_group(n, record_latency=False):
-        enc_done, outs, starts = [], [], []
-        for i in range(n):
-            with dev.stream(streams[i]):
-                for ev in group_dec_done:
-                    streams[i].wait_event(ev)
-                if record_latency:
-                    e0 = dev.Event(enable_timing=True)
-                    e0.record()
-                    starts.append(e0)
-                ctxs[i].generate_encode(frames, search)
-                ev = dev.Event()
-                ev.record()
-                enc_done.append(ev)
-        group_dec_done.clear()
-        for i in range(n):
-            with dev.stream(streams[i]):
-                for ev in enc_done:
-                    streams[i].wait_event(ev)
-                tokens, logprobs, info = ctxs[i].generate_decode(search, sync=False)
-                if world > 1:
-                    gather_results(tokens, logprobs)
-                ev = dev.Event(enable_timing=record_latency)
-                ev.record()
-                group_dec_done.append(ev)
-                if record_latency:
-                    lat_events.append((starts[i], ev))
-                outs.append((tokens, info))
-        return outs[-1]
 
     def coalesced_pass(n, record_latency=False):
         """n requests of --batch images -> one engine pass on the next context"""
@@ -591,20 +566,11 @@ def main(argv=None, engine_factory=None):
 
     def run_steps(k, record_latency=False):
         out = None
-        if dgroup > 1:
-            for _ in range(k):
-                out = grouped_step(record_latency) or out
-        elif coalesce > 1:
+        if coalesce > 1:
             done = 0
             while done < k:
                 n = min(coalesce, k - done)
                 out = coalesced_pass(n, record_latency)
-                done += n
-        elif args.phased > 0:
-            done = 0
-            while done < k:
-                n = min(args.phased, k - done)
-                out = run_group(n, record_latency)
                 done += n
         else:
             for _ in range(k):
@@ -613,7 +579,6 @@ def main(argv=None, engine_factory=None):
 
     # every context captures its hipGraph before anything is timed (a context's first call captures and instantiates)
     run_steps(len(ctxs) * coalesce)
-    run_steps(len(ctxs) if dgroup > 1 else 0)        # a second round: the members' repacks have now waited on a decode
     fence()
     run_steps(args.warmup)
     fence()
@@ -671,18 +636,18 @@ def main(argv=None, engine_factory=None):
                        "shared_device_policy": bool(args.contexts > 1 and not args.solo_policy),
                        "encoder_chains": 0 if (args.free_run or len(ctxs) <= chains) else chains,
                        "schedule": (f"mixed, {coalesce} requests of {args.batch} images coalesced per engine pass" if coalesce > 1
-                                    else f"mixed, decode groups: every request encoded by its own context, {dgroup} requests "
-                                         f"per decode chain ({dgroup * args.batch} rows)" if dgroup > 1
-                                    else "mixed" if args.phased <= 0 else f"phased: groups of {args.phased} batches, "
-                                    f"encoders first, then the decode chains side by side")},
+                                    else "mixed")},
             # a batch's own latency (submit -> ids ready) while `contexts_in_flight` batches share the GPU
             "batch_latency_ms": {"median": round(lat[len(lat) // 2], 3), "max": round(lat[-1], 3)},
         }
         if gather_stats is not None:
             result["gather"] = gather_stats
 
-    # ---- roofline passes (rank 0 of N=1 only) ---------------------------------------------------------------
-    if rank == 0 and world == 1 and not standin:
+    # ---- roofline passes: one context alone on rank 0's GPU after the timed region (N > 1: the other ranks wait at the final
+    #      barrier, so every line -- 1, 2, 4, 8 GPUs -- carries `roofline` / `roofline_decode`) -----------------------------
+    if rank == 0 and not standin and args.brief:
+        tokens_solo, _, info_solo = eng.generate(frames, search, sync=True)
+    if rank == 0 and not standin and not args.brief:
         pmc = pmc_profile({"gemm": "gemm_p8", "attn_decode": "attn_decode", "dgemm": "dgemm_kernel", "vocab": "vocab_topm"})
         # (1) eager launches, HIP events around every GEMM launch on the launch stream: per-kernel durations
         eng.profile_enable(1)
@@ -752,31 +717,7 @@ def main(argv=None, engine_factory=None):
             ss_gbs = sgprof["decode_step_bytes"] / (ss_ms * 1e-3) / 1e9 if ss_ms > 0 else 0.0
             result["roofline_decode"]["solo_policy"] = {"avg_step_ms": round(ss_ms, 4), "achieved": round(ss_gbs, 1),
                                                         "frac": round(ss_gbs / PEAK_HBM_GBS, 4)}
-        if dgroup > 1:
-            # the production decode chain of this schedule runs over the rows of a whole group: time THAT chain (graph
-            # replays of one group context alone; its members publish once, the cache stays valid between replays)
-            for m in ctxs[:dgroup]:
-                m.generate_encode(frames, search)
-            groups[0].group_decode(max(1, args.frames), dgroup * args.batch, search, sync=True)
-            g0, g1 = dev.Event(enable_timing=True), dev.Event(enable_timing=True)
-            g0.record()
-            for _ in range(5):
-                groups[0].group_decode(max(1, args.frames), dgroup * args.batch, search, sync=False)
-            g1.record()
-            dev.synchronize()
-            gstep_ms = g0.elapsed_time(g1) / 5 / max(1, args.max_steps - 1)
-            n_img_tok = max(1, args.frames) * ((cfg.image_size // cfg.patch) ** 2 + 1)
-            kv_row = cfg.dec_layers * 2.0 * (n_img_tok + beams * 0.5 * (1 + args.max_steps)) * cfg.dec_hidden * 2
-            gbytes = gprof["decode_step_bytes"] + (dgroup - 1) * args.batch * kv_row      # weights once, K/V per row
-            ggbs = gbytes / (gstep_ms * 1e-3) / 1e9
-            result["roofline_decode"].update({
-                "achieved": round(ggbs, 1), "frac": round(ggbs / PEAK_HBM_GBS, 4), "bytes_per_step": gbytes,
-                "avg_step_ms": round(gstep_ms, 4), "rows_per_step": dgroup * args.batch * beams,
-                "solo_request_step_ms": round(step_ms, 4),
-                "method": f"HIP events around 5 replays of the decode hipGraph of one GROUP context alone ({dgroup} requests, "
-                          f"{dgroup * args.batch} rows per chain: the production launch path of this schedule); "
-                          "solo_request_step_ms = the chain of one request on its own"})
-        if pmc and dgroup == 1:
+        if pmc:
             per_step = 0.0
             for key, launches in (("dgemm", 4 * cfg.dec_layers), ("attn_decode", cfg.dec_layers), ("vocab", 1)):
                 if key in pmc and "hbm_bytes" in pmc[key]:
@@ -788,11 +729,24 @@ def main(argv=None, engine_factory=None):
         result["phases_ms"] = {k: round(prof[k], 3) for k in ("vit_ms", "prefill_ms", "decode_ms", "total_ms", "gemm_ms")}
         result["phases_ms"]["graph_encode_prefill_ms"] = round(gprof["vit_ms"], 3)
         result["phases_ms"]["graph_decode_ms"] = round(gprof["decode_ms"], 3)
+    if rank == 0 and not standin:
+        # the ids of the timed schedule's last batch are the ids of the solo pass (same images, same weights)
+        result["timed_ids_equal_solo"] = bool(torch.equal(tokens.cpu(), tokens_solo.cpu()))
         result["parity"] = bench_parity(eng, tokens_solo, info_solo, args)
         if result["parity"] is not None:
             result["parity"]["wide_margin"] = bench_wide_margin(args, cfg, frames[0].device)
-        # the ids of the timed schedule's last batch are the ids of the solo pass (same images, same weights)
-        result["timed_ids_equal_solo"] = bool(torch.equal(tokens.cpu(), tokens_solo.cpu()))
+    if rank == 0 and world == 1 and not standin and not args.brief:
+        if (args.precision == "bf16" and not args.no_alt_precision and not args.experiment and coalesce == 1
+                and golden_name is not None):
+            # the fp16-operand build on the same workload and schedule, in a child process, with this process idle
+            dev.synchronize()
+            child = ["--precision", "f16", "--brief", "--no-cpu-baseline", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                     "--batch", str(args.batch), "--model", args.model, "--search", args.search, "--max-steps", str(args.max_steps),
+                     "--frames", str(args.frames), "--contexts", str(args.contexts), "--encoder-chains", str(args.encoder_chains)]
+            child += ["--solo-policy"] if args.solo_policy else []
+            child += ["--free-run"] if args.free_run else []
+            child += ["--no-graph"] if args.no_graph else []
+            result["alt_precision"] = alt_precision_line(child)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.max_steps, args.cpu_threads,
                                                   big_batch=args.cpu_big_batch)

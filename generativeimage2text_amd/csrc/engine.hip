@@ -175,7 +175,6 @@ struct gitmi_engine {
     hipGraph_t graph_b = nullptr;
     hipGraphExec_t graph_exec_b = nullptr;
     bool graph_is_split = false;
-    bool half_submitted = false;        // gitmi_generate_encode submitted, its gitmi_generate_decode not yet
     // residual streams of the image encoder and the prefill (v_x, p_y, p_hf) stored in fp16 instead of fp32 (bf16 mode
     // only, the default there; GITMI_STREAM_F16=0 keeps fp32): half the bytes of their read-modify-writes at 2^-11 relative
     // rounding.  Measured (profiles/r03_a_bench_f16_*.json, interleaved A/B): encode + prefill 5.31 -> 5.03 ms,
@@ -187,17 +186,6 @@ struct gitmi_engine {
     gitmi_engine* enc_after = nullptr;
     std::vector<gitmi_engine*> enc_watchers;   // contexts whose enc_after is this one (they wait on enc_done)
     hipEvent_t enc_done = nullptr;
-    // decode group (gitmi_set_decode_group): the image K/V (decode layout) of this MEMBER context live in `kv_group`'s
-    // cache, images [kv_image_off, kv_image_off + B); the group context runs ONE decode chain over the images of all its
-    // members (gitmi_group_decode).  A member's K/V repack is deferred to the end of its prefill (a graph of its own)
-    // so that only those few launches, not its image encoder, wait for the group's previous decode chain.
-    gitmi_engine* kv_group = nullptr;
-    int kv_image_off = 0;
-    std::vector<gitmi_engine*> kv_members;      // on the group context
-    hipEvent_t kv_published = nullptr;          // member: the K/V of its latest request are in the group's cache
-    bool kv_pending = false;                    // member: a request was published that no gitmi_group_decode has been submitted for
-    hipEvent_t group_dec_done = nullptr;        // group: the latest decode chain over the cache has finished
-    bool graph_is_group = false;
     double split_encode_ms = 0, split_decode_ms = 0;
     int split_calls = 0, split_steps = 0;
     std::vector<TimedSpan> spans;
@@ -389,16 +377,6 @@ extern "C" void gitmi_destroy(gitmi_engine* e) {
         w.erase(std::remove(w.begin(), w.end(), e), w.end());
     }
     for (gitmi_engine* w : e->enc_watchers) w->enc_after = nullptr;
-    if (e->kv_group) {
-        auto& v = e->kv_group->kv_members;
-        v.erase(std::remove(v.begin(), v.end(), e), v.end());
-    }
-    for (gitmi_engine* m : e->kv_members) {       // members of a destroyed group go back to their own caches
-        m->kv_group = nullptr; m->kv_image_off = 0; m->kv_pending = false;
-        destroy_graph(m);
-    }
-    if (e->kv_published) hipEventDestroy(e->kv_published);
-    if (e->group_dec_done) hipEventDestroy(e->group_dec_done);
     destroy_graph(e);
     if (e->own_stream) hipStreamDestroy(e->own_stream);
     if (e->fence_in) hipEventDestroy(e->fence_in);
@@ -803,13 +781,12 @@ extern "C" int gitmi_finalize_weights(gitmi_engine* e) {
 // workspaces, KV caches, search state, streams and graph).  Lets a server keep several batches in
 // flight on different HIP streams: the latency-bound decode steps of one batch overlap the
 // MFMA-bound encoder of the next.  `src` must outlive the clone.
-static int clone_impl(gitmi_engine* src, int max_batch, gitmi_engine** out) {
+extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
     if (!src || !out) return fail("gitmi_clone: null argument");
     if (!src->finalized) return fail("gitmi_clone: source weights not finalized");
-    if (max_batch < 1) return fail("gitmi_clone_sized: max_batch %d", max_batch);
     HIPCK(hipSetDevice(src->device));
     gitmi_engine* e = new gitmi_engine();
-    e->cfg = src->cfg; e->cfg.max_batch = max_batch; e->device = src->device; e->f32 = src->f32; e->esz = src->esz; e->stream_f16 = src->stream_f16;
+    e->cfg = src->cfg; e->device = src->device; e->f32 = src->f32; e->esz = src->esz; e->stream_f16 = src->stream_f16;
     e->attn_impl = src->attn_impl; e->Kp = src->Kp; e->Kp_pad = src->Kp_pad;
     // a clone starts at the native resolution (its own gitmi_set_image_shape state and resized table)
     e->N_nat = e->N = src->N_nat; e->g_nat = e->gh = e->gw = src->g_nat; e->H = e->W = src->cfg.image_size;
@@ -832,13 +809,6 @@ static int clone_impl(gitmi_engine* src, int max_batch, gitmi_engine** out) {
     *out = e;
     return 0;
 }
-extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
-    return clone_impl(src, src ? src->cfg.max_batch : 0, out);
-}
-GITMI_EXP_EXPORT int gitmi_clone_sized(gitmi_engine* src, int max_batch, gitmi_engine** out) {
-    return clone_impl(src, max_batch, out);
-}
-
 // ---- input resolution (CLIP/model.py:243-251) ---------------------------------------------
 extern "C" int gitmi_set_image_shape(gitmi_engine* e, int H, int W, void* stream) {
     if (!e) return fail("null engine");
@@ -925,19 +895,10 @@ static int encode_frames_impl(gitmi_engine* e, const float* const* frames, int F
 // image K/V of layer l into the decode layout: head-major (fp32 VALU kernel) or the MFMA operand layouts (bf16)
 static int kv_repack(gitmi_engine* e, int l, int B, int Nimg, hipStream_t s) {
     const gitmi_config& c = e->cfg;
-    // a member of a decode group writes into the group's cache, at its image offset (per image: all heads x padded keys)
-    gitmi_engine* o = e->kv_group ? e->kv_group : e;
-    const size_t off = (size_t)e->kv_image_off * (e->f32 ? Nimg : round_up(Nimg, 32)) * c.dec_hidden * e->esz;
-    void* kh = (char*)o->img_kh[l] + off;
-    void* vh = (char*)o->img_vh[l] + off;
+    void* kh = e->img_kh[l];
+    void* vh = e->img_vh[l];
     if (e->f32) HIPCK(launch_kv_repack(e->img_kv[l], kh, vh, B, Nimg, c.dec_heads, c.dec_hidden, true, s));
     else HIPCK(launch_kv_repack_frag(e->img_kv[l], kh, vh, B, Nimg, round_up(Nimg, 32), c.dec_heads, c.dec_hidden, s));
-    return 0;
-}
-
-// decode-group member: the repacks of every layer, after the prefill (its own graph: generate_run)
-static int publish_kv(gitmi_engine* e, hipStream_t s) {
-    for (int l = 0; l < e->cfg.dec_layers; ++l) RCK(kv_repack(e, l, e->cur_B, e->cur_Nimg, s));
     return 0;
 }
 
@@ -946,7 +907,6 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
     const int d = c.dec_hidden, ffn = c.dec_ffn, D = c.vit_width;
     const int B = e->cur_B, Nimg = e->cur_Nimg, M = B * Nimg;
     SpanGuard phase(e, s, TAG_PREFILL, 0);
-    const bool defer = e->kv_group != nullptr;          // publish_kv() follows
     RCK(gemm_stream(e, s, e->feats, D, e->vp_w, e->vp_b, nullptr, 0, e->p_y, d, M, d, D, TAG_GEMM_OTHER));
     RCK(ln_stream(e, s, e->p_y, d, e->vp_lng, e->vp_lnb, 1e-5f, e->p_ht, d, e->p_hf, d, M, d));
     for (int l = 0; l < c.dec_layers; ++l) {
@@ -954,12 +914,12 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
         const bool last = l + 1 == c.dec_layers;
         if (!last) {
             RCK(gemm(e, s, e->p_ht, d, L.wqkv, L.bqkv, nullptr, 0, e->img_kv[l], 3 * d, e->f32, M, 3 * d, d, 0, TAG_GEMM_OTHER));
-            if (!defer) RCK(kv_repack(e, l, B, Nimg, s));
+            RCK(kv_repack(e, l, B, Nimg, s));
         } else {
             // the last layer's image-row outputs are never consumed: only its K and V are needed
             RCK(gemm(e, s, e->p_ht, d, (char*)L.wqkv + (size_t)d * d * e->esz, L.bqkv + d, nullptr, 0,
                      (char*)e->img_kv[l] + (size_t)d * e->esz, 3 * d, e->f32, M, 2 * d, d, 0, TAG_GEMM_OTHER));
-            if (!defer) RCK(kv_repack(e, l, B, Nimg, s));
+            RCK(kv_repack(e, l, B, Nimg, s));
             break;
         }
         AttnFullArgs a{};
@@ -1167,7 +1127,6 @@ extern "C" int gitmi_encode_frames(gitmi_engine* e, const float* const* frames, 
 extern "C" int gitmi_prefill(gitmi_engine* e, void* stream) {
     RCK(check_ready(e));
     if (!e->have_feats) return fail("prefill: no encoded frames");
-    if (e->kv_group) return fail("prefill: this context is a member of a decode group (gitmi_generate_encode publishes its K/V)");
     return prefill_impl(e, (hipStream_t)stream);
 }
 
@@ -1464,49 +1423,15 @@ static int generate_body(gitmi_engine* e, const float* const* frames, int F, int
 }
 
 // common tail of gitmi_generate / gitmi_generate_prefixed: start_dev / plen_dev / img_of_dev are already enqueued on `s`
-// phase 0: the whole call.  phase 1 / 2: its two halves as separate submissions (gitmi_generate_encode /
-// gitmi_generate_decode) -- 1 = stage the frames, image encoder + decoder prefill; 2 = search over the text positions +
-// results -- for schedules that order the halves of several contexts themselves.  phase 3: the decode half on a GROUP
-// context, over the image K/V its member contexts published (gitmi_group_decode).
-// A member of a decode group (e->kv_group) only takes phase 1: encoder + prefill graph, then -- once the group's previous
-// decode chain has released the cache -- the graph of its K/V repacks.
 static int generate_run(gitmi_engine* e, const float* const* frames, int F, int B, int Q, int minP, int maxP, bool ragged,
                         const gitmi_search* sp, int64_t* tokens_out, float* logprob_out, int32_t* info_out,
-                        int32_t* sent_out, hipStream_t s, int phase = 0) {
+                        int32_t* sent_out, hipStream_t s) {
     const gitmi_config& c = e->cfg;
     const bool long_budget = sp->max_steps - minP > 32;
     const bool graph = e->use_graph && !e->profiling && !long_budget;
-    const bool group = phase == 3, member = e->kv_group != nullptr;
-    if (member && phase != 1) return fail("this context is a member of a decode group: gitmi_generate_encode + gitmi_group_decode");
-    // host order is the contract (include/gitmi.h): a member's next request would overwrite K/V its group has not been
-    // ASKED to decode yet -- no event can order that, so it is refused
-    if (member && e->kv_pending)
-        return fail("generate_encode: the previous request of this member (images from %d) has not been submitted to "
-                    "gitmi_group_decode yet", e->kv_image_off);
-    const int F_in = c.num_frames > 0 ? std::min(F, c.num_frames) : F;
-    if (group) {        // host-side state a prefill on this context would have left behind
-        e->cur_B = B; e->cur_F = F_in; e->cur_Nimg = F_in * e->N;
-        e->have_feats = e->have_prefill = true;
-    }
-    if (!graph) {
-        if (member) {
-            if (e->enc_after && e->enc_after->enc_done) HIPCK(hipStreamWaitEvent(s, e->enc_after->enc_done, 0));
-            RCK(generate_encode(e, frames, F, B, s));
-            if (e->enc_done && !e->enc_watchers.empty()) HIPCK(hipEventRecord(e->enc_done, s));
-            if (e->kv_group->group_dec_done) HIPCK(hipStreamWaitEvent(s, e->kv_group->group_dec_done, 0));
-            RCK(publish_kv(e, s));
-            HIPCK(hipEventRecord(e->kv_published, s));
-            e->kv_pending = true;
-            return 0;
-        }
-        if (phase == 1) return generate_encode(e, frames, F, B, s);
-        if (group) phase = 2;
-        if (phase == 2)
-            return generate_decode(e, Q, minP, maxP, ragged, sp, (long long*)tokens_out, logprob_out, info_out,
-                                   sent_out ? sent_out : e->out_sent, s, long_budget && !e->profiling);
+    if (!graph)
         return generate_body(e, frames, F, B, Q, minP, maxP, ragged, sp, (long long*)tokens_out, logprob_out, info_out,
                              sent_out ? sent_out : e->out_sent, s, long_budget && !e->profiling);
-    }
 
     // ---- hipGraph path: the launch sequence only depends on (B,Q,F,minP,search); inputs and outputs are
     // staged through engine-owned buffers so the captured pointers stay valid across calls.
@@ -1518,31 +1443,27 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
     }
     const size_t frame_bytes = (size_t)B * 3 * e->H * e->W * sizeof(float);
     const int F_eff = c.num_frames > 0 ? std::min(F, c.num_frames) : F;
-    if (phase == 0 || phase == 1)
-        for (int f = 0; f < F_eff; ++f)
-            HIPCK(hipMemcpyAsync(e->frame_stage[f], frames[f], frame_bytes, hipMemcpyDeviceToDevice, x));
+    for (int f = 0; f < F_eff; ++f)
+        HIPCK(hipMemcpyAsync(e->frame_stage[f], frames[f], frame_bytes, hipMemcpyDeviceToDevice, x));
     gitmi_engine::GraphKey key{};
     key.B = B; key.Q = Q; key.F = F_eff; key.P = minP; key.kind = sp->kind; key.k = sp->beam_size; key.pn = sp->per_node_beam_size;
     key.T = sp->max_steps; key.H = e->H; key.W = e->W; key.lp = sp->length_penalty;
     key.ragged = ragged ? 1 : 0; key.ident = e->img_identity ? 1 : 0; key.temb = e->use_temb ? 1 : 0;
     key.smp = sp->do_sample; key.top_k = sp->top_k; key.top_p = sp->top_p; key.temp = sp->temperature; key.seed = sp->seed;
     key.rp = sp->repetition_penalty; key.nh = sp->num_keep_best > 1 ? sp->num_keep_best : 1;
-    // two graphs (encode + prefill | decode) whenever something has to happen between them: profiling events, the
-    // enc_done record other contexts wait for, or the caller submits the halves itself
-    const bool split = e->profile_mode == 2 || e->enc_after != nullptr || !e->enc_watchers.empty() || phase != 0;
-    if (phase == 2 && !(e->graph_valid && key == e->graph_key && e->graph_is_split && !e->graph_is_group && e->half_submitted))
-        return fail("generate_decode: no matching gitmi_generate_encode was submitted on this context");
-    if (!e->graph_valid || !(key == e->graph_key) || split != e->graph_is_split || group != e->graph_is_group) {
+    // two graphs (encode + prefill | decode) whenever something has to happen between them: profiling events or the
+    // enc_done record other contexts wait for
+    const bool split = e->profile_mode == 2 || e->enc_after != nullptr || !e->enc_watchers.empty();
+    if (!e->graph_valid || !(key == e->graph_key) || split != e->graph_is_split) {
         destroy_graph(e);
         std::vector<const float*> fp(F_eff);
         for (int f = 0; f < F_eff; ++f) fp[f] = e->frame_stage[f];
-        auto capture = [&](int part, hipGraph_t* gr_out) -> int {       // part 0: whole call, 1: encode + prefill, 2: decode, 4: K/V repacks of a group member
+        auto capture = [&](int part, hipGraph_t* gr_out) -> int {       // part 0: whole call, 1: encode + prefill, 2: decode
             HIPCK(hipStreamBeginCapture(x, hipStreamCaptureModeThreadLocal));
             int rc = 0;
             if (part == 0) rc = generate_body(e, fp.data(), F_eff, B, Q, minP, maxP, ragged, sp, e->out_tokens, e->out_lp,
                                               e->out_info, e->out_sent, x, false);
             else if (part == 1) rc = generate_encode(e, fp.data(), F_eff, B, x);
-            else if (part == 4) rc = publish_kv(e, x);
             else rc = generate_decode(e, Q, minP, maxP, ragged, sp, e->out_tokens, e->out_lp, e->out_info, e->out_sent, x, false);
             hipGraph_t gr = nullptr;
             hipError_t ce = hipStreamEndCapture(x, &gr);
@@ -1551,48 +1472,30 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
             *gr_out = gr;
             return 0;
         };
-        if (group) {
-            RCK(capture(2, &e->graph_b));
-            HIPCK(hipGraphInstantiate(&e->graph_exec_b, e->graph_b, nullptr, nullptr, 0));
-        } else if (!split) {
+        if (!split) {
             RCK(capture(0, &e->graph));
             HIPCK(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
         } else {
             RCK(capture(1, &e->graph));
             HIPCK(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
-            RCK(capture(member ? 4 : 2, &e->graph_b));
+            RCK(capture(2, &e->graph_b));
             HIPCK(hipGraphInstantiate(&e->graph_exec_b, e->graph_b, nullptr, nullptr, 0));
         }
         e->graph_key = key;
         e->graph_valid = true;
         e->graph_is_split = split;
-        e->graph_is_group = group;
     } else {
         // host-side mirror of the state generate_body leaves behind
         e->cur_B = B; e->cur_F = F_eff; e->cur_Nimg = F_eff * e->N;
         e->have_feats = e->have_prefill = true;
     }
-    if (group) {
-        HIPCK(hipGraphLaunch(e->graph_exec_b, x));
-    } else if (member) {
+    if (!split) {
+        HIPCK(hipGraphLaunch(e->graph_exec, x));
+    } else if (e->profile_mode != 2) {
         if (e->enc_after && e->enc_after->enc_done) HIPCK(hipStreamWaitEvent(x, e->enc_after->enc_done, 0));
         HIPCK(hipGraphLaunch(e->graph_exec, x));
         if (e->enc_done && !e->enc_watchers.empty()) HIPCK(hipEventRecord(e->enc_done, x));
-        if (e->kv_group->group_dec_done) HIPCK(hipStreamWaitEvent(x, e->kv_group->group_dec_done, 0));
         HIPCK(hipGraphLaunch(e->graph_exec_b, x));
-        HIPCK(hipEventRecord(e->kv_published, x));
-        e->kv_pending = true;
-        e->half_submitted = false;
-    } else if (!split) {
-        HIPCK(hipGraphLaunch(e->graph_exec, x));
-    } else if (e->profile_mode != 2 || phase != 0) {
-        if (phase != 2) {
-            if (e->enc_after && e->enc_after->enc_done) HIPCK(hipStreamWaitEvent(x, e->enc_after->enc_done, 0));
-            HIPCK(hipGraphLaunch(e->graph_exec, x));
-            if (e->enc_done && !e->enc_watchers.empty()) HIPCK(hipEventRecord(e->enc_done, x));
-        }
-        if (phase != 1) HIPCK(hipGraphLaunch(e->graph_exec_b, x));
-        e->half_submitted = phase == 1;
     } else {
         for (auto& ev : e->gev)
             if (!ev) HIPCK(hipEventCreate(&ev));
@@ -1607,13 +1510,11 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
         HIPCK(hipEventElapsedTime(&b, e->gev[1], e->gev[2]));
         e->split_encode_ms += a; e->split_decode_ms += b; e->split_calls += 1; e->split_steps += sp->max_steps - 1;
     }
-    if (phase != 1) {
-        const size_t nout = (size_t)Q * (size_t)(sp->num_keep_best > 1 ? sp->num_keep_best : 1);      // sequences returned
-        HIPCK(hipMemcpyAsync(tokens_out, e->out_tokens, nout * sp->max_steps * sizeof(long long), hipMemcpyDeviceToDevice, x));
-        HIPCK(hipMemcpyAsync(logprob_out, e->out_lp, nout * sizeof(float), hipMemcpyDeviceToDevice, x));
-        HIPCK(hipMemcpyAsync(info_out, e->out_info, 4 * sizeof(int), hipMemcpyDeviceToDevice, x));
-        if (sent_out) HIPCK(hipMemcpyAsync(sent_out, e->out_sent, (size_t)Q * 2 * sizeof(int), hipMemcpyDeviceToDevice, x));
-    }
+    const size_t nout = (size_t)Q * (size_t)(sp->num_keep_best > 1 ? sp->num_keep_best : 1);      // sequences returned
+    HIPCK(hipMemcpyAsync(tokens_out, e->out_tokens, nout * sp->max_steps * sizeof(long long), hipMemcpyDeviceToDevice, x));
+    HIPCK(hipMemcpyAsync(logprob_out, e->out_lp, nout * sizeof(float), hipMemcpyDeviceToDevice, x));
+    HIPCK(hipMemcpyAsync(info_out, e->out_info, 4 * sizeof(int), hipMemcpyDeviceToDevice, x));
+    if (sent_out) HIPCK(hipMemcpyAsync(sent_out, e->out_sent, (size_t)Q * 2 * sizeof(int), hipMemcpyDeviceToDevice, x));
     if (x != s) {
         HIPCK(hipEventRecord(e->fence_out, x));
         HIPCK(hipStreamWaitEvent(s, e->fence_out, 0));
@@ -1636,113 +1537,6 @@ extern "C" int gitmi_generate(gitmi_engine* e, const float* const* frames, int F
     // start tokens [B, P] on device (shared prefix, or [CLS]) -- filled by a kernel, no host copy
     RCK(fill_uniform_sentences(e, B, (const long long*)prefix, P, s));
     return generate_run(e, frames, F, B, B, P, P, false, sp, tokens_out, logprob_out, info_out, nullptr, s);
-}
-
-// gitmi_generate as two submissions (same arguments; the decode half must follow the encode half of the same call on
-// the same context).  Lets a server order the halves of several contexts itself, e.g. run the MFMA-bound encoders of a
-// group of batches first and their latency-bound decode chains side by side afterwards (bench.py --phased).
-static int check_generate_args(gitmi_engine* e, int F, int B, const int64_t* prefix, int* P, const gitmi_search* sp) {
-    const gitmi_config& c = e->cfg;
-    if (!sp) return fail("generate: null argument");
-    if (F < 1 || F > c.max_frames) return fail("generate: F=%d outside [1,%d]", F, c.max_frames);
-    if (B < 1 || B > c.max_batch) return fail("generate: B=%d outside [1,%d]", B, c.max_batch);
-    if (!prefix) *P = 1;
-    if (*P < 1 || *P > c.max_text_len) return fail("generate: prefix length %d outside [1,%d]", *P, c.max_text_len);
-    if (sp->max_steps < *P || sp->max_steps > c.max_text_len) return fail("generate: max_steps %d outside [P,%d]", sp->max_steps, c.max_text_len);
-    return 0;
-}
-
-GITMI_EXP_EXPORT int gitmi_generate_encode(gitmi_engine* e, const float* const* frames, int F, int B, const int64_t* prefix, int P,
-                                     const gitmi_search* sp, void* stream) {
-    RCK(check_ready(e));
-    if (!frames) return fail("generate_encode: null argument");
-    RCK(check_generate_args(e, F, B, prefix, &P, sp));
-    e->img_identity = true;
-    return generate_run(e, frames, F, B, B, P, P, false, sp, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream, 1);
-}
-
-GITMI_EXP_EXPORT int gitmi_generate_decode(gitmi_engine* e, int F, int B, const int64_t* prefix, int P, const gitmi_search* sp,
-                                     int64_t* tokens_out, float* logprob_out, int32_t* info_out, void* stream) {
-    RCK(check_ready(e));
-    if (!tokens_out || !logprob_out || !info_out) return fail("generate_decode: null argument");
-    RCK(check_generate_args(e, F, B, prefix, &P, sp));
-    hipStream_t s = (hipStream_t)stream;
-    RCK(fill_uniform_sentences(e, B, (const long long*)prefix, P, s));
-    return generate_run(e, nullptr, F, B, B, P, P, false, sp, tokens_out, logprob_out, info_out, nullptr, s, 2);
-}
-
-// ---- decode groups: ONE decode chain for the requests of several contexts ----------------------------------------
-static void unlink_decode_group(gitmi_engine* m) {
-    if (!m->kv_group) return;
-    auto& v = m->kv_group->kv_members;
-    v.erase(std::remove(v.begin(), v.end(), m), v.end());
-    m->kv_group = nullptr;
-    m->kv_image_off = 0;
-    m->kv_pending = false;
-    destroy_graph(m);                   // its graphs write into the group's cache
-}
-
-GITMI_EXP_EXPORT int gitmi_set_decode_group(gitmi_engine* member, gitmi_engine* group, int image_offset) {
-    if (!member) return fail("set_decode_group: null member");
-    HIPCK(hipSetDevice(member->device));
-    HIPCK(hipDeviceSynchronize());
-    unlink_decode_group(member);
-    if (!group) return 0;
-    if (group == member) return fail("set_decode_group: a context cannot be its own group");
-    if (!member->finalized || !group->finalized) return fail("set_decode_group: weights not finalized");
-    if (group->kv_group) return fail("set_decode_group: the group context is itself a member of a group");
-    if (!member->kv_members.empty()) return fail("set_decode_group: the member context is a group");
-    const gitmi_engine* wm = member->parent ? member->parent : member;
-    const gitmi_engine* wg = group->parent ? group->parent : group;
-    if (wm != wg || member->device != group->device || member->f32 != group->f32)
-        return fail("set_decode_group: member and group must be contexts of the same engine (gitmi_clone / gitmi_clone_sized)");
-    const gitmi_config &a = member->cfg, &b = group->cfg;
-    if (a.max_frames != b.max_frames || member->Nmax != group->Nmax)
-        return fail("set_decode_group: member and group differ in frame / image-token capacity");
-    if (image_offset < 0 || image_offset + a.max_batch > b.max_batch)
-        return fail("set_decode_group: images [%d, %d) do not fit the group's max_batch=%d", image_offset,
-                    image_offset + a.max_batch, b.max_batch);
-    for (const gitmi_engine* o : group->kv_members)
-        if (image_offset < o->kv_image_off + o->cfg.max_batch && o->kv_image_off < image_offset + a.max_batch)
-            return fail("set_decode_group: images [%d, %d) overlap another member's", image_offset, image_offset + a.max_batch);
-    if (!member->kv_published) HIPCK(hipEventCreateWithFlags(&member->kv_published, hipEventDisableTiming));
-    if (!group->group_dec_done) HIPCK(hipEventCreateWithFlags(&group->group_dec_done, hipEventDisableTiming));
-    member->kv_group = group;
-    member->kv_image_off = image_offset;
-    group->kv_members.push_back(member);
-    return 0;
-}
-
-GITMI_EXP_EXPORT int gitmi_group_decode(gitmi_engine* e, int F, int B, const int64_t* prefix, int P, const gitmi_search* sp,
-                                  int64_t* tokens_out, float* logprob_out, int32_t* info_out, void* stream) {
-    RCK(check_ready(e));
-    if (!tokens_out || !logprob_out || !info_out) return fail("group_decode: null argument");
-    if (e->kv_members.empty()) return fail("group_decode: no member contexts (gitmi_set_decode_group)");
-    RCK(check_generate_args(e, F, B, prefix, &P, sp));
-    const int F_in = e->cfg.num_frames > 0 ? std::min(F, e->cfg.num_frames) : F;
-    hipStream_t s = (hipStream_t)stream;
-    // images [0, B) must be covered by members that have published a request of the same geometry.  A published request
-    // stays in the cache until its member publishes the next one: decoding it AGAIN (bench.py's solo decode-step probe) is
-    // allowed and returns the same rows; what is refused is a member that never published (cur_B == 0) or a changed geometry
-    std::vector<char> have((size_t)B, 0);
-    for (gitmi_engine* m : e->kv_members) {
-        if (m->kv_image_off >= B) continue;
-        if (m->cur_F != F_in || m->N != e->N || m->cur_B < 1)
-            return fail("group_decode: the member at image %d has no published request of this geometry", m->kv_image_off);
-        for (int i = m->kv_image_off; i < std::min(B, m->kv_image_off + m->cur_B); ++i) have[(size_t)i] = 1;
-    }
-    for (int i = 0; i < B; ++i)
-        if (!have[(size_t)i]) return fail("group_decode: image %d of %d was not published by any member", i, B);
-    for (gitmi_engine* m : e->kv_members) {
-        if (m->kv_image_off >= B) continue;
-        HIPCK(hipStreamWaitEvent(s, m->kv_published, 0));
-        m->kv_pending = false;
-    }
-    RCK(fill_uniform_sentences(e, B, (const long long*)prefix, P, s));
-    e->img_identity = true;
-    RCK(generate_run(e, nullptr, F, B, B, P, P, false, sp, tokens_out, logprob_out, info_out, nullptr, s, 3));
-    HIPCK(hipEventRecord(e->group_dec_done, s));
-    return 0;
 }
 
 // Q sentences with their own prefixes over B encoded images (batched VQA: the questions of one image share its K/V).
@@ -1925,7 +1719,7 @@ extern "C" int gitmi_op_attention(const void* qkv, void* out, int B, int N, int 
 // ---- decode-chain kernels (kernels_dgemm.hip), one launch each -----------------------------------------------
 #ifdef GITMI_EXPERIMENT
 static int g_dgemm_dbg = 0;
-extern "C" int gitmi_debug_set_dgemm(int dbg) { g_dgemm_dbg = dbg; return 0; }      // timing bits of kernels_dgemm.hip
+GITMI_EXP_EXPORT int gitmi_debug_set_dgemm(int dbg) { g_dgemm_dbg = dbg; return 0; }      // timing bits of kernels_dgemm.hip
 #else
 static const int g_dgemm_dbg = 0;
 #endif
@@ -2040,7 +1834,7 @@ GITMI_EXP_EXPORT int gitmi_debug_head_from(gitmi_engine* dst, gitmi_engine* src,
 }
 
 GITMI_EXP_EXPORT int gitmi_debug_set_gemm_impl(int impl) {
-    set_gemm_impl(impl);
+    if (!set_gemm_impl(impl)) return fail("debug_set_gemm_impl: unknown selector %d (low byte: -1, 0, 9 or 11)", impl);
     return 0;
 }
 

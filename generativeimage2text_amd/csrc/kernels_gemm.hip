@@ -290,9 +290,13 @@ static hipError_t launch_gemm_tiles(const GemmArgs& g, hipStream_t s) {
 
 static int g_gemm_impl = -1;
 static int g_gemm_dbg = 0;
-void set_gemm_impl(int impl) {
-    if (impl >= 0) { g_gemm_dbg = impl >> 8; impl &= 0xff; } else g_gemm_dbg = 0;
+bool set_gemm_impl(int impl) {
+    int dbg = 0;
+    if (impl >= 0) { dbg = impl >> 8; impl &= 0xff; }
+    if (impl != -1 && impl != 0 && impl != 9 && impl != 11) return false;      // unknown selector: refused, state unchanged
+    g_gemm_dbg = dbg;
     g_gemm_impl = impl;
+    return true;
 }
 
 // what the LDS-DMA kernel (kernels_gemm10.hip) needs of the operands besides its shape rules (gemm_p8_supports): bf16/fp16

@@ -20,7 +20,7 @@ hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t
 hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s);     // 256x256x64, half-tile pipeline, staggered wave groups
 bool gemm_p8_supports(const GemmArgs& g);
 int gemm_p8_cost(const GemmArgs& g, int mh);   // rounds x relative tile time of the 256-row (mh=128) / 192-row (96) tile
-void set_gemm_impl(int impl);   // measurement builds: -1 auto, 0 tile kernel only, 9 LDS-DMA kernel wherever it can run (+ dbg bits << 8)
+bool set_gemm_impl(int impl);   // measurement builds: -1 auto, 0 tile kernel only, 9 LDS-DMA kernel, 11 loader/consumer kernel wherever it can run (+ dbg bits << 8); false = unknown selector
 
 // ---- decode-step GEMM chain (kernels_dgemm.hip): LayerNorm folded into the consumer, row partials from the producer
 struct DGemmArgs {

@@ -34,8 +34,7 @@ EXPORTED_SYMBOLS = [
 ]
 # libgitmi_exp.so only (include/gitmi_experiment.h): schedules that measured slower than the default, debug hooks
 EXPERIMENT_SYMBOLS = [
-    "gitmi_generate_encode", "gitmi_generate_decode", "gitmi_clone_sized", "gitmi_set_decode_group", "gitmi_group_decode",
-    "gitmi_debug_import_stage", "gitmi_debug_head_from", "gitmi_debug_set_gemm_impl",
+    "gitmi_debug_import_stage", "gitmi_debug_head_from", "gitmi_debug_set_gemm_impl", "gitmi_debug_set_dgemm",
 ]
 
 
@@ -134,14 +133,10 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     lib.gitmi_op_kv_repack.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_sample_rows.argtypes = [vp, i32, i32, C.c_float, i32, C.c_float, i32, C.c_uint64, i32, vp, vp, vp, vp]
     if operands == "exp":
-        lib.gitmi_generate_encode.argtypes = [vp, C.POINTER(vp), i32, i32, vp, i32, C.POINTER(GitmiSearch), vp]
-        lib.gitmi_generate_decode.argtypes = [vp, i32, i32, vp, i32, C.POINTER(GitmiSearch), vp, vp, vp, vp]
         lib.gitmi_debug_import_stage.argtypes = [vp, vp, i32, vp]
         lib.gitmi_debug_head_from.argtypes = [vp, vp, i32, vp, vp]
         lib.gitmi_debug_set_gemm_impl.argtypes = [i32]
-        lib.gitmi_clone_sized.argtypes = [vp, i32, C.POINTER(vp)]
-        lib.gitmi_set_decode_group.argtypes = [vp, vp, i32]
-        lib.gitmi_group_decode.argtypes = [vp, i32, i32, vp, i32, C.POINTER(GitmiSearch), vp, vp, vp, vp]
+        lib.gitmi_debug_set_dgemm.argtypes = [i32]
     for name in EXPORTED_SYMBOLS + (EXPERIMENT_SYMBOLS if operands == "exp" else []):
         if name not in ("gitmi_last_error", "gitmi_destroy"):
             getattr(lib, name).restype = C.c_int
@@ -226,22 +221,16 @@ class Engine:
     def _ck(self, rc: int) -> None:
         _ck(rc, self.lib)
 
-    def clone(self, max_batch: Optional[int] = None) -> "Engine":
+    def clone(self) -> "Engine":
         """A second context sharing this engine's packed weights (own workspaces / KV caches / graph),
-        for keeping several batches in flight on different streams.  Keep `self` alive while it is used.
-        max_batch: capacity of the clone when it differs (a decode-group context holds the rows of all its members)."""
+        for keeping several batches in flight on different streams.  Keep `self` alive while it is used."""
         other = object.__new__(Engine)
         other.lib, other.device, other.cfg, other.precision = self.lib, self.device, self.cfg, self.precision
         other.c = GitmiConfig.from_buffer_copy(self.c)
-        if max_batch is not None:
-            other.c.max_batch = int(max_batch)
         other.n_tok = (self.c.image_size // self.c.patch) ** 2 + 1
         other._hw = (int(self.c.image_size), int(self.c.image_size))
         other._h = C.c_void_p()
-        if max_batch is None or int(max_batch) == int(self.c.max_batch):
-            self._ck(self.lib.gitmi_clone(self._h, C.byref(other._h)))
-        else:       # a decode-group context (measurement build)
-            self._ck(_experiment_only(self.lib, "gitmi_clone_sized")(self._h, int(other.c.max_batch), C.byref(other._h)))
+        self._ck(self.lib.gitmi_clone(self._h, C.byref(other._h)))
         other._finalized, other._cur_B, other._cur_F = True, 0, 0
         other._parent = self
         return other
@@ -371,55 +360,6 @@ class Engine:
             out.append((tokens[lo:lo + n], logprobs[lo:lo + n]))
             lo += n
         return out, info
-
-    def generate_encode(self, frames: Sequence[torch.Tensor], search: GitmiSearch,
-                        prefix: Optional[torch.Tensor] = None) -> None:
-        """First half of generate() as its own submission (image encoder + decoder prefill) on the current stream;
-        generate_decode() with the same search / prefix must follow on this context."""
-        arr, keep, B = self._frames_arg(frames)
-        P, pfx = 1, None
-        if prefix is not None:
-            pfx = prefix.to(device=keep[0].device, dtype=torch.int64).reshape(-1).contiguous()
-            P = int(pfx.numel())
-        self._ck(_experiment_only(self.lib, "gitmi_generate_encode")(self._h, arr, len(keep), B, _ptr(pfx), P, C.byref(search), _stream()))
-        self._cur_B, self._half = B, (len(keep), B, pfx, P)
-
-    def set_decode_group(self, group: Optional["Engine"], image_offset: int = 0) -> None:
-        """Make this context a MEMBER of `group` (a clone(max_batch=...) context): generate_encode() writes the image K/V of
-        its request into the group's cache at `image_offset`, group.group_decode() searches over all members' images in
-        ONE decode chain.  group=None detaches."""
-        self._ck(_experiment_only(self.lib, "gitmi_set_decode_group")(self._h, group._h if group is not None else None, int(image_offset)))
-        self._group = group
-
-    def group_decode(self, n_frames: int, n_images: int, search: GitmiSearch, prefix: Optional[torch.Tensor] = None,
-                     sync: bool = True):
-        """On a group context: the search over the first n_images images its members published (their generate_encode
-        calls come first in host order).  -> (tokens [n_images, max_steps], logprobs [n_images], info) -- row i belongs to
-        the member whose image_offset covers i."""
-        dev = f"cuda:{self.device}"
-        P, pfx = 1, None
-        if prefix is not None:
-            pfx = prefix.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
-            P = int(pfx.numel())
-        tokens, logprobs = self._out(n_images, search, dev)
-        info = torch.empty(4, device=dev, dtype=torch.int32)
-        self._ck(_experiment_only(self.lib, "gitmi_group_decode")(self._h, int(n_frames), int(n_images), _ptr(pfx), P, C.byref(search),
-                                        tokens.data_ptr(), logprobs.data_ptr(), info.data_ptr(), _stream()))
-        if sync:
-            torch.cuda.synchronize(self.device)
-        return tokens, logprobs, info
-
-    def generate_decode(self, search: GitmiSearch, sync: bool = True):
-        """Second half: the search over the text positions.  -> (tokens, logprobs, info) exactly as generate()."""
-        F, B, pfx, P = self._half
-        dev = f"cuda:{self.device}"
-        tokens, logprobs = self._out(B, search, dev)
-        info = torch.empty(4, device=dev, dtype=torch.int32)
-        self._ck(_experiment_only(self.lib, "gitmi_generate_decode")(self._h, F, B, _ptr(pfx), P, C.byref(search), tokens.data_ptr(),
-                                           logprobs.data_ptr(), info.data_ptr(), _stream()))
-        if sync:
-            torch.cuda.current_stream().synchronize()
-        return tokens, logprobs, info
 
     def generate_prefixed(self, frames: Sequence[torch.Tensor], search: GitmiSearch,
                           prefixes: Sequence[Sequence[int]], image_of: Optional[Sequence[int]] = None, sync: bool = True):
@@ -551,7 +491,7 @@ def op_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = Non
     N = W.shape[0]
     out = torch.empty(M, N, device=A.device, dtype=out_dtype)
     _ck(lib.gitmi_op_gemm(A.data_ptr(), W.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, K, N,
-                          _torch_dtype_code(A), _torch_dtype_code(out), act, _stream()))
+                          _torch_dtype_code(A), _torch_dtype_code(out), act, _stream()), lib)
     return out
 
 
@@ -561,7 +501,7 @@ def op_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: 
     rows, D = x.shape
     out = torch.empty(rows, D, device=x.device, dtype=out_dtype)
     _ck(lib.gitmi_op_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, out.data_ptr(), None, rows, D,
-                               _torch_dtype_code(out), _stream()))
+                               _torch_dtype_code(out), _stream()), lib)
     return out
 
 
@@ -569,7 +509,7 @@ def op_attention(qkv: torch.Tensor, B: int, N: int, H: int, impl: int) -> torch.
     lib = load_library()
     assert qkv.is_cuda and qkv.is_contiguous() and qkv.shape == (B * N, 3 * H * 64)
     out = torch.empty(B * N, H * 64, device=qkv.device, dtype=qkv.dtype)
-    _ck(lib.gitmi_op_attention(qkv.data_ptr(), out.data_ptr(), B, N, H, _torch_dtype_code(qkv), impl, _stream()))
+    _ck(lib.gitmi_op_attention(qkv.data_ptr(), out.data_ptr(), B, N, H, _torch_dtype_code(qkv), impl, _stream()), lib)
     return out
 
 
@@ -625,7 +565,7 @@ def op_dgemm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, colsum: Optio
     out = torch.empty((M + 15) // 16 * 16 if frag_out else M, N, device=A.device, dtype=torch.bfloat16)
     strips = 0 if stats is None else int(stats.shape[0])
     _ck(lib.gitmi_op_dgemm(Af.data_ptr(), Wf.data_ptr(), bias.data_ptr(), _ptr(colsum), _ptr(stats), strips, eps,
-                           out.data_ptr(), 1 if frag_out else 0, M, N, K, act, int(strips_per_wg), _stream()))
+                           out.data_ptr(), 1 if frag_out else 0, M, N, K, act, int(strips_per_wg), _stream()), lib)
     return from_frag(out, M) if (frag_out and not packed) else out
 
 
@@ -644,7 +584,7 @@ def op_dgemm_res(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, res_x: to
     strips = 0 if res_stats is None else int(res_stats.shape[0])
     _ck(lib.gitmi_op_dgemm_res(Af.data_ptr(), Wf.data_ptr(), bias.data_ptr(), res_x.data_ptr(), _ptr(res_stats), strips,
                                _ptr(res_gamma), _ptr(res_beta), res_eps, x.data_ptr(), xb.data_ptr(), st.data_ptr(),
-                               M, N, K, _stream()))
+                               M, N, K, _stream()), lib)
     return x, (xb if packed else from_frag(xb, M)), st
 
 
@@ -673,14 +613,15 @@ def op_vocab_topm(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, mtop: in
     strips = 0 if stats is None else int(stats.shape[0])
     _ck(lib.gitmi_op_vocab_topm(Af.data_ptr(), Wf.data_ptr(), bp.data_ptr(), _ptr(cp), _ptr(stats), strips, eps,
                                 M, V, K, cols_per_wg, mtop, _ptr(suppress_tok), pv.data_ptr(), pi.data_ptr(),
-                                pl.data_ptr(), _ptr(lg), int(max_wgs), _stream()))
+                                pl.data_ptr(), _ptr(lg), int(max_wgs), _stream()), lib)
     return pv, pi, pl, lg
 
 
 def set_gemm_impl(impl: int) -> None:
     """Measurement build only (use_experiment_build()): -1 auto, 0 register-staged tile kernel only, 9 the LDS-DMA kernel
     wherever it can run; 9 | (bits << 8): 64 / 128 force its 192- / 256-row tile (tools/gemm_bench.py lists the others)."""
-    _ck(_experiment_only(load_library(), "gitmi_debug_set_gemm_impl")(int(impl)))
+    lib = load_library()
+    _ck(_experiment_only(lib, "gitmi_debug_set_gemm_impl")(int(impl)), lib)
 
 
 def op_attn_decode(qkv, img_k, img_v, txt_k, txt_v, kv_src, B, H, N_img, T_max, pos, beams, dbg=0):
@@ -693,7 +634,7 @@ def op_attn_decode(qkv, img_k, img_v, txt_k, txt_v, kv_src, B, H, N_img, T_max, 
         img_k, img_v = kv_repack(img_k, img_v)
     _ck(lib.gitmi_op_attn_decode(qkv.data_ptr(), img_k.data_ptr(), img_v.data_ptr(), txt_k.data_ptr(), txt_v.data_ptr(),
                                  kv_src.data_ptr(), out.data_ptr(), B, H, N_img, T_max, pos, beams, _torch_dtype_code(qkv),
-                                 dbg, _stream()))
+                                 dbg, _stream()), lib)
     return out
 
 
@@ -708,7 +649,7 @@ def op_sample_rows(logits: torch.Tensor, temperature: float = 1.0, top_k: int = 
     tok = torch.empty(R, ndraw, device=logits.device, dtype=torch.int32)
     filt = torch.empty(R, V, device=logits.device, dtype=torch.float32) if want_filtered else None
     _ck(lib.gitmi_op_sample_rows(logits.data_ptr(), R, V, float(temperature), int(top_k), float(top_p), int(ndraw), int(seed),
-                                 int(step), lp.data_ptr(), tok.data_ptr(), _ptr(filt), _stream()))
+                                 int(step), lp.data_ptr(), tok.data_ptr(), _ptr(filt), _stream()), lib)
     return filt, tok, lp
 
 
@@ -723,7 +664,7 @@ def kv_repack(img_k: torch.Tensor, img_v: torch.Tensor):
     Np = (N + 31) // 32 * 32
     kf = torch.empty(B * H * Np * 64, device=img_k.device, dtype=torch.bfloat16)
     vt = torch.empty(B * H * Np * 64, device=img_k.device, dtype=torch.bfloat16)
-    _ck(lib.gitmi_op_kv_repack(rows.data_ptr(), kf.data_ptr(), vt.data_ptr(), B, N, H, _stream()))
+    _ck(lib.gitmi_op_kv_repack(rows.data_ptr(), kf.data_ptr(), vt.data_ptr(), B, N, H, _stream()), lib)
     return kf, vt
 
 
@@ -737,7 +678,7 @@ def preprocess_image(rgb_hwc: torch.Tensor, crop: int = 224) -> torch.Tensor:
     nw = crop if W <= H else int(crop * W / H)
     tmp = torch.empty(H * nw * 3, dtype=torch.uint8, device=rgb_hwc.device)
     out = torch.empty(3, crop, crop, dtype=torch.float32, device=rgb_hwc.device)
-    _ck(lib.gitmi_preprocess_image(rgb_hwc.data_ptr(), H, W, crop, tmp.data_ptr(), tmp.numel(), out.data_ptr(), _stream()))
+    _ck(lib.gitmi_preprocess_image(rgb_hwc.data_ptr(), H, W, crop, tmp.data_ptr(), tmp.numel(), out.data_ptr(), _stream()), lib)
     return out
 
 
@@ -751,5 +692,5 @@ def preprocess_image_to(rgb_hwc: torch.Tensor, out_h: int, out_w: int) -> torch.
     tmp = torch.empty(H * out_w * 3, dtype=torch.uint8, device=rgb_hwc.device)
     out = torch.empty(3, out_h, out_w, dtype=torch.float32, device=rgb_hwc.device)
     _ck(lib.gitmi_preprocess_image_to(rgb_hwc.data_ptr(), H, W, int(out_h), int(out_w), tmp.data_ptr(), tmp.numel(),
-                                      out.data_ptr(), _stream()))
+                                      out.data_ptr(), _stream()), lib)
     return out

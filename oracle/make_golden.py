@@ -337,6 +337,66 @@ def run_full_case(name: str):
         assert float(margins.min()) >= WIDE_MARGIN, margins.min()
 
 
+# ---- teacher-forced decisions along the reference's own ids (round 5) --------------------------------------------
+# A free-running bf16 row can be compared with the reference only up to its FIRST near-tie (parity.ids_parity): on the
+# benchmark fixture that is 152 of 1 216 decisions.  Feeding the engine the reference's ids[:, :t] for every t makes
+# every decision of every row comparable (gitmi_step_logits is the reference's `step` callable): `<case>_tf.npz` freezes,
+# for every (row, decision), the reference's top-8 raw logits + ids and the logits of 128 sampled vocabulary columns,
+# taken from ONE teacher-forced pass of the unmodified reference's textual head over its own predictions (causal mask:
+# position p of that pass is the step that chose token p + 1; decoder.py:521-600).
+TF_TOP, TF_COLS = 8, 128
+TF_CASES = ("full_bench_b64_greedy", "full_base_b64_greedy", "full_large_b32_greedy", "full_vatex_b16_greedy",
+            "full_wide_b64_greedy", "full_wide_large_b32_greedy", "full_wide_vatex_b16_greedy")
+
+
+def run_tf_case(name: str):
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg, w, frames, search, tie = full_case_inputs(name)
+    assert search.kind == "greedy" and search.beam_size == 1, name
+    F = len(frames)
+    preds = torch.from_numpy(gold["predictions"])                          # [B, L] incl. the start token
+    B, L = preds.shape
+    model = build_reference(cfg, w, search, tie)
+    t0 = time.time()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref_feat = (torch.cat([f + e for f, e in zip([model.image_encoder(im) for im in frames],
+                                                     model.img_temperal_embedding)], dim=1)
+                    if cfg.num_frames else
+                    torch.cat([model.image_encoder(im) for im in frames], dim=1) if F > 1 else model.image_encoder(frames[0]))
+        ref_all = model.textual(ref_feat, preds)[:, :-1, :].float()        # [B, L-1, V]; row p decides token p + 1
+        ora_all = O.textual_logits_full(cfg, w, ref_feat, preds)[:, :-1, :].float()
+    t_ref = time.time() - t0
+    tf_err = (ora_all - ref_all).abs().max().item()
+    assert tf_err < 2e-4, (name, "oracle vs reference, teacher-forced logits at every position", tf_err)
+    # the pass reproduces the search: no-repeat rule from the second decision on (decoder.py:330), then argmax == the id
+    # the reference chose, and top-1 - top-2 == the frozen step margin -- for every decision taken before a row's EOS
+    dec = ref_all.clone()
+    for s_ in range(1, L - 1):
+        dec[torch.arange(B), s_, preds[:, s_]] = -10000.0
+    live = torch.ones(B, L - 1, dtype=torch.bool)
+    for s_ in range(1, L - 1):
+        live[:, s_] = live[:, s_ - 1] & (preds[:, s_] != cfg.eos)
+    top2 = dec.topk(2, dim=-1)
+    assert torch.equal(top2.indices[..., 0][live], preds[:, 1:][live]), (name, "teacher-forced argmax != reference ids")
+    margin = (top2.values[..., 0] - top2.values[..., 1])
+    sm = torch.from_numpy(gold["step_margin"])
+    m_err = (margin - sm)[live & sm.isfinite()].abs().max().item()
+    assert m_err < 2e-4, (name, "teacher-forced margins vs step_margin", m_err)
+    top = ref_all.topk(TF_TOP, dim=-1)
+    g = torch.Generator().manual_seed(17)
+    cols = torch.stack([torch.randperm(cfg.vocab, generator=g)[:TF_COLS].sort().values for _ in range(L - 1)])   # [L-1, C]
+    col_vals = torch.gather(ref_all, 2, cols[None].expand(B, -1, -1))
+    print(f"[{name}_tf] OK {t_ref:.1f}s  decisions {int(live.sum())}  oracle-vs-reference {tf_err:.2e}  margin-vs-frozen {m_err:.2e}  "
+          f"span {ref_all.max().item() - ref_all.min().item():.3f}  margin median {margin[live].median().item():.4f}", flush=True)
+    np.savez_compressed(
+        os.path.join(GOLD, name + "_tf.npz"),
+        top_ids=top.indices.numpy().astype(np.int32), top_vals=top.values.numpy().astype(np.float32),
+        cols=cols.numpy().astype(np.int32), col_vals=col_vals.numpy().astype(np.float32),
+        margin=margin.numpy().astype(np.float32), live=live.numpy(),
+        logit_min=np.float32(ref_all.min().item()), logit_max=np.float32(ref_all.max().item()))
+
+
 def write_minmax_fixture():
     """Outputs of the reference's MinMaxResizeForTest.get_size (inference.py:29-64) for a spread of image sizes."""
     import_reference()
@@ -551,6 +611,9 @@ def main():
     for name in FULL_CASES:          # minutes each: only on request (--only full / --only NAME[,NAME...])
         if args.only is not None and (args.only == "full" or name in args.only.split(",")):
             run_full_case(name)
+    for name in TF_CASES:            # ~1-3 min each: --only tf / --only NAME_tf[,...]
+        if args.only is not None and (args.only == "tf" or name + "_tf" in args.only.split(",")):
+            run_tf_case(name)
 
 
 if __name__ == "__main__":

@@ -119,27 +119,10 @@ class _StandInEngine:
         self.calls = 0
         self.log = []
 
-    def clone(self, max_batch=None):
-        c = _StandInEngine(self.rank, max_batch or self.batch, self.T)
+    def clone(self):
+        c = _StandInEngine(self.rank, self.batch, self.T)
         c.log = self.log
         return c
-
-    # decode groups (bench.py --decode-group): members encode, the group decodes the rows of all its members
-    def set_decode_group(self, group, image_offset=0):
-        self.group, self.offset = group, image_offset
-        group.members = getattr(group, "members", []) + [self]
-
-    def generate_encode(self, frames, search, prefix=None):
-        self.log.append(("encode", self.offset))
-        self.published = True
-
-    def group_decode(self, n_frames, n_images, search, prefix=None, sync=True):
-        assert all(m.published for m in self.members) and n_images == self.batch
-        self.log.append(("decode", n_images))
-        for m in self.members:
-            m.published = False
-        toks = torch.full((n_images, self.T), 1000 + self.rank, dtype=torch.int64)
-        return toks, torch.full((n_images,), -float(self.rank)), torch.tensor([self.T, 0, self.T - 1, 0], dtype=torch.int32)
 
     def set_encode_after(self, other):
         pass
@@ -184,40 +167,6 @@ def _bench_main_worker(rank, world, port, tmpdir):
         assert res is None and gathered[-1] == (None, None)
 
 
-def _bench_group_worker(rank, world, port, tmpdir):
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank))
-    import bench
-    gathered = []
-    real_gather = bench.gather_results
-
-    def spy(tokens, logprobs):
-        out = real_gather(tokens, logprobs)
-        gathered.append(out)
-        return out
-    bench.gather_results = spy
-    res = bench.main(["--gpus", str(world), "--steps", "4", "--warmup", "2", "--batch", "3", "--contexts", "2",
-                      "--decode-group", "2", "--no-cpu-baseline"],
-                     engine_factory=lambda args, r: (_StandInEngine(r, args.batch, args.max_steps), [torch.zeros(1)]))
-    if rank == 0:
-        # every request of a group is gathered on its own: [world x batch, T] rows in rank order, twice per group decode
-        assert res["n_gpus"] == world and res["config"]["global_batch"] == world * 3
-        t, l = gathered[-1]
-        assert t.shape == (world * 3, 20) and t[:3].eq(1000).all() and t[3:].eq(1001).all()
-        assert len(gathered) % 2 == 0
-        open(os.path.join(tmpdir, "ok"), "w").write(json.dumps(res))
-    else:
-        assert res is None and gathered[-1] == (None, None)
-
-
-def test_two_rank_bench_decode_groups_with_standin_engine(tmp_path):
-    """bench.main --decode-group 2 under a 2-rank launcher environment (gloo, stand-in engine): each rank runs its own
-    groups; the rows of every request reach rank 0 in rank order."""
-    mp.spawn(_bench_group_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    assert json.loads((tmp_path / "ok").read_text())["n_gpus"] == 2
-
-
 def test_two_rank_bench_main_with_standin_engine(tmp_path):
     """bench.main under a 2-rank launcher environment (gloo, stand-in engine): every rank runs, rank 0 prints ONE line
     with n_gpus == --gpus == WORLD_SIZE, the gather delivers every rank's rows to rank 0."""
@@ -232,30 +181,6 @@ def test_eight_rank_bench_main_with_standin_engine(tmp_path):
     mp.spawn(_bench_main_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
     res = json.loads((tmp_path / "ok").read_text())
     assert res["n_gpus"] == 8 and res["config"]["global_batch"] == 24 and res["scaling"] == "weak"
-
-
-def test_bench_decode_group_schedule_with_standin_engine():
-    """bench.main --decode-group 2 (one rank, stand-in engine): every request is encoded by its own member context, the
-    request that completes a group submits ONE decode over both requests' rows, a step stays one request."""
-    sys.path.insert(0, ROOT)
-    import bench
-    env = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK") if k in os.environ}
-    try:
-        root = []
-
-        def factory(args, r):
-            root.append(_StandInEngine(r, args.batch, args.max_steps))
-            return root[0], [torch.zeros(1)]
-        res = bench.main(["--steps", "8", "--warmup", "3", "--batch", "3", "--contexts", "4", "--decode-group", "2",
-                          "--no-cpu-baseline"], engine_factory=factory)
-    finally:
-        os.environ.update(env)
-    assert res["config"]["global_batch"] == 3 and res["steps"] == 8 and "2 requests per decode chain (6 rows)" in res["config"]["schedule"]
-    log = root[0].log
-    # capture rounds 4 + 4, warm-up rounded up to 4, 8 timed requests: 20 encodes, one decode per two of them
-    assert [e for e in log if e[0] == "encode"].__len__() == 20 and [e for e in log if e[0] == "decode"] == [("decode", 6)] * 10
-    for i in range(0, len(log), 3):
-        assert [e[0] for e in log[i:i + 3]] == ["encode", "encode", "decode"] and [e[1] for e in log[i:i + 2]] == [0, 3]
 
 
 def test_bench_refuses_gpu_count_mismatch(tmp_path):

@@ -58,7 +58,7 @@ def test_product_libraries_export_the_c_abi_and_nothing_else():
             assert not hasattr(lib, name), name
     if os.path.exists(engine.LIB_PATH_EXP):
         defined, undefined = dyn(engine.LIB_PATH_EXP)
-        assert defined == declared | extra | {"gitmi_debug_set_dgemm"}
+        assert defined == declared | extra
         assert "getenv" in undefined
 
 
@@ -741,3 +741,71 @@ def test_margin_threshold_follows_the_logit_bound():
     with pytest.raises(AssertionError):
         P.ids_parity(bad, ref, margin, 0.0358, chained=False)
     assert set(P.IDENTICAL_REQUIRED) == {"full_wide_b64_greedy", "full_wide_large_b32_greedy", "full_wide_vatex_b16_greedy"}
+
+
+def test_teacher_forced_parity_counts_and_violations():
+    """parity.teacher_forced_parity on a scripted `step`: decisions are read with the no-repeat rule, a flip at a narrow
+    margin is counted but allowed, a flip at a wide margin and a logit error above the bound are violations, and the frozen
+    fixtures it runs on in the GPU suite are self-consistent (argmax of the frozen top-8 after the no-repeat rule == the
+    reference's ids; margins == the step margins of the free-running golden)."""
+    import torch
+    from generativeimage2text_amd import parity as P
+    V, B, L = 50, 3, 5
+    rng = np.random.RandomState(0)
+    table = rng.randn(L - 1, B, V).astype(np.float32)                       # logits of decision s for row r
+    ref = np.zeros((B, L), dtype=np.int64)
+    ref[:, 0] = 1
+    margin = np.zeros((B, L - 1), dtype=np.float32)
+    for s in range(L - 1):
+        d = table[s].copy()
+        if s >= 1:
+            d[np.arange(B), ref[:, s]] = -10000.0
+        order = np.argsort(-d, axis=1)
+        ref[:, s + 1] = order[:, 0]
+        margin[:, s] = d[np.arange(B), order[:, 0]] - d[np.arange(B), order[:, 1]]
+    top = np.argsort(-table, axis=2)[:, :, :8]                              # [L-1, B, 8]
+    cols = np.stack([np.sort(rng.permutation(V)[:16]) for _ in range(L - 1)])
+    gold = {"live": np.ones((B, L - 1), bool), "margin": margin,
+            "top_ids": np.transpose(top, (1, 0, 2)).astype(np.int32),
+            "top_vals": np.transpose(np.take_along_axis(table, top, axis=2), (1, 0, 2)),
+            "cols": cols.astype(np.int32), "col_vals": np.stack([table[s][:, cols[s]] for s in range(L - 1)], axis=1),
+            "logit_min": np.float32(table.min()), "logit_max": np.float32(table.max())}
+
+    def step_of(tab):
+        return lambda tokens: torch.from_numpy(tab[tokens.shape[1] - 1])
+
+    st = P.teacher_forced_parity(step_of(table), ref, gold, eos=2, thr=1e-3, lerr_bound=1e-4, f32_step_logits=step_of(table))
+    assert st["ok"] and st["agree"] == st["decisions"] == B * (L - 1) and st["max_logit_err"] == 0.0, st
+    # a flip at a narrow margin: lift the runner-up of (row 0, decision 2) just above the winner
+    narrow = table.copy()
+    d = narrow[2][0].copy(); d[ref[0, 2]] = -10000.0
+    second = int(np.argsort(-d)[1])
+    narrow[2][0][second] += margin[0, 2] + 1e-3
+    thr = float(margin[0, 2]) + 0.5
+    st = P.teacher_forced_parity(step_of(narrow), ref, gold, eos=2, thr=thr, lerr_bound=10.0)
+    assert st["ok"] and st["agree"] == st["decisions"] - 1 and st["max_flipped_margin"] == pytest.approx(margin[0, 2], abs=1e-4), st
+    assert st["rows_all_agree"] == B - 1
+    st = P.teacher_forced_parity(step_of(narrow), ref, gold, eos=2, thr=float(margin[0, 2]) * 0.5, lerr_bound=10.0)
+    assert not st["ok"] and "row 0 decision 2" in st["violation"], st
+    st = P.teacher_forced_parity(step_of(table + 0.01), ref, gold, eos=2, thr=1e-3, lerr_bound=5e-3)
+    assert not st["ok"] and "above the bound" in st["violation"], st
+    # the frozen fixtures: internally consistent with the free-running goldens
+    gdir = os.path.join(ROOT, "tests", "golden")
+    names = sorted(f[:-7] for f in os.listdir(gdir) if f.endswith("_tf.npz"))
+    assert "full_bench_b64_greedy" in names
+    for name in names:
+        g, t = np.load(os.path.join(gdir, name + ".npz")), np.load(os.path.join(gdir, name + "_tf.npz"))
+        ids, live = g["predictions"], t["live"]
+        Bn, Ln = ids.shape
+        assert t["top_ids"].shape == (Bn, Ln - 1, 8) and t["col_vals"].shape[:2] == (Bn, Ln - 1)
+        vals = t["top_vals"].astype(np.float64).copy()
+        for s in range(1, Ln - 1):
+            vals[:, s][t["top_ids"][:, s] == ids[:, s][:, None]] = -10000.0
+        order = np.argsort(-vals, axis=2)
+        choice = np.take_along_axis(t["top_ids"], order[:, :, :1], axis=2)[:, :, 0]
+        assert (choice == ids[:, 1:])[live].all(), name
+        sv = np.take_along_axis(vals, order[:, :, :2], axis=2)
+        m = sv[:, :, 0] - sv[:, :, 1]
+        fin = live & np.isfinite(g["step_margin"])
+        assert np.abs(m - t["margin"])[live].max() < 1e-5 and np.abs(t["margin"] - g["step_margin"])[fin].max() < 2e-4, name
+        assert (P.tf_bounds(name, str(g["config"]), "bf16", 12.0)["thr"] > 0)

@@ -106,24 +106,14 @@ def _run_bench_with_fakes(monkeypatch, capsys, argv):
             self.c = types.SimpleNamespace(max_batch=max_batch, vocab=cfg.vocab)
             self.half = None
 
-        def clone(self, max_batch=None):
+        def clone(self):
             other = FakeEngine.__new__(FakeEngine)
-            other.c, other.half = types.SimpleNamespace(max_batch=max_batch or self.c.max_batch, vocab=self.c.vocab), None
-            other.group, other.members, other.shared = None, [], getattr(self, "shared", False)
+            other.c, other.half = types.SimpleNamespace(max_batch=self.c.max_batch, vocab=self.c.vocab), None
+            other.shared = getattr(self, "shared", False)
             return other
 
         def set_shared_device(self, on=True):
             self.shared = on
-
-        def set_decode_group(self, group, image_offset=0):
-            self.group, self.offset = group, image_offset
-            group.members.append(self)
-
-        def group_decode(self, n_frames, n_images, search, prefix=None, sync=True):
-            sizes = [m.half for m in self.members]
-            assert all(b is not None for b in sizes) and sum(sizes) == n_images <= self.c.max_batch
-            log.append(("group_decode", n_images, self.shared))       # (the cache stays valid: a group may decode it again)
-            return self._out(n_images, search)
 
         def load_state_dict(self, sd): pass
         def close(self): pass
@@ -144,19 +134,11 @@ def _run_bench_with_fakes(monkeypatch, capsys, argv):
             log.append(("generate", int(frames[0].shape[0])))
             return self._out(int(frames[0].shape[0]), search)
 
-        def generate_encode(self, frames, search, prefix=None):
-            assert self.half is None or getattr(self, "group", None) is not None
-            self.half = int(frames[0].shape[0])
-            log.append(("encode", self.half))
-
-        def generate_decode(self, search, sync=True):
-            B, self.half = self.half, None
-            assert B is not None, "decode half without its encode half"
-            log.append(("decode", B))
-            return self._out(B, search)
-
         def step_logits(self, tokens):
             return torch.zeros(tokens.shape[0], self.c.vocab)
+
+        def encode(self, frames, return_features=True):
+            return None
 
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
@@ -171,6 +153,7 @@ def _run_bench_with_fakes(monkeypatch, capsys, argv):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BENCH_GEMM_IMPL"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline"] + argv)
+    monkeypatch.setattr(bench, "alt_precision_line", lambda child: {"precision": "f16", "child_argv": child})
     try:
         bench.main()
     finally:
@@ -191,34 +174,25 @@ def test_bench_control_flow_all_schedules(monkeypatch, capsys):
         assert k in d["roofline"] and k in d["roofline_decode"], k
     timed = [e for e in log if e[0] == "generate"]
     assert len(timed) >= 4 + 3 + 8                      # priming pass over the contexts + warm-up + timed steps (+ roofline passes)
-    # phased: every decode half follows its own encode half, groups of G
-    d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "10", "--warmup", "4", "--phased", "4", "--experiment"])
-    assert d["config"]["schedule"].startswith("phased: groups of 4") and d["config"]["contexts_in_flight"] == 4
-    halves = [e[0] for e in log if e[0] in ("encode", "decode")]
-    assert halves.count("encode") == halves.count("decode") == 4 + 4 + 10
-    assert halves[:8] == ["encode"] * 4 + ["decode"] * 4
-    assert halves[-2:] == ["decode", "decode"] and halves[-4:-2] == ["encode", "encode"]      # the last, partial group of 2
+    # round 5: every decision teacher-forced against the reference; the fp16-operand build as a child run of the same schedule
+    tf = d["parity"]["teacher_forced"]
+    assert tf["decisions"] == 64 * 19 and 0 < tf["decidable"] <= tf["decisions"] and "max_logit_err" in tf
+    child = d["alt_precision"]["child_argv"]
+    assert child[:3] == ["--precision", "f16", "--brief"] and child[child.index("--steps") + 1] == "8"
+    # --brief (what that child runs): timed loop + parity, no roofline passes
+    d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--warmup", "3", "--brief", "--precision", "f16"])
+    assert "roofline" not in d and "alt_precision" not in d and "parity" in d and d["dtype"] == "f16"
     # coalesced: two requests per engine pass
     d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--warmup", "3", "--coalesce", "2"])
     assert "2 requests of 64 images coalesced" in d["config"]["schedule"] and d["warmup"] == 4
     passes = [e for e in log if e == ("generate", 128)]
     assert len(passes) == 4 + 2 + 4                     # priming (one pass per context), warm-up 4 steps, 8 timed steps
-    # decode groups: every request encoded by its own member context, one decode per pair of requests; the serving
-    # policy (gitmi_set_shared_device) is on for every context of a multi-context run
-    d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--warmup", "3", "--decode-group", "2", "--experiment"])
-    assert "2 requests per decode chain (128 rows)" in d["config"]["schedule"] and d["warmup"] == 4 and d["config"]["shared_device_policy"]
-    assert d["roofline_decode"]["rows_per_step"] == 128
-    ev = [e for e in log if e[0] in ("encode", "group_decode")]
-    assert ev[:3] == [("encode", 64), ("encode", 64), ("group_decode", 128, True)]
-    assert len([e for e in ev if e[0] == "encode"]) == 4 + 4 + 4 + 8 + 2      # two priming rounds, warm-up, timed, the probe's publish
     import pytest
     with pytest.raises(SystemExit):
         _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "7", "--coalesce", "2"])
-    with pytest.raises(SystemExit):
-        _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--decode-group", "3", "--experiment"])
-    # the schedules that lost live in the measurement build: without --experiment they are refused
+    # the schedules that lost were removed in round 5: their flags no longer exist
     for flags in (["--decode-group", "2"], ["--phased", "4"]):
-        with pytest.raises(SystemExit, match="measurement build"):
+        with pytest.raises(SystemExit):
             _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--warmup", "4"] + flags)
 
 

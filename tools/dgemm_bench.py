@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from generativeimage2text_amd import engine as E
 
+E.use_experiment_build(True)        # gitmi_debug_set_dgemm is exported by libgitmi_exp.so only
 lib = E.load_library()
 lib.gitmi_debug_set_dgemm.argtypes = [ctypes.c_int]
 
