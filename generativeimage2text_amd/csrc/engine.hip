@@ -156,6 +156,7 @@ struct gitmi_engine {
     int dgemm_no_row_walk = -1;         // A/B (GITMI_DGEMM_NO_ROW_WALK=0|1; -1 = by policy)
     int dgemm_strips = -1;              // 16-column strips per workgroup of the wide chain GEMMs at <= 64 rows (1, 2, 4, 6; -1 = by policy)
     int vocab_wgs = -1;                 // workgroups of the vocabulary head (each walks ceil(239 / n) column blocks; 0 = one per block; -1 = by policy)
+    int gemm_tall = 1;                  // serving policy: encoder GEMMs always on 256-row tiles (1) or on the modelled height (0; GITMI_GEMM_TALL)
     int dgemm_rows = 0;                 // rows per workgroup of the N = 768 chain GEMMs (GITMI_DGEMM_ROWS: 16 / 32 / 64; 0 = by policy)
     int decode_skip = 0;                // MEASUREMENT BUILDS ONLY (GITMI_EXPERIMENT, GITMI_DECODE_SKIP): launches of the decode chain left
                                         // out -- 1 attention, 2 QKV / FFN1 GEMMs, 4 out-proj / FFN2 GEMMs, 8 vocabulary head (ids are garbage)
@@ -247,13 +248,21 @@ struct SpanGuard {
     ~SpanGuard() { if (on) hipEventRecord(e->spans[idx].b, s); }
 };
 
+// serving policy of the encoder GEMM's tile height (kernels_gemm10.hip: launch_gemm_p8): 256-row tiles whatever the round
+// fill, because other contexts' kernels fill the CUs a partial round leaves idle.  gemm_tall (measurement builds): 1 always,
+// 0 never (the modelled height, as for a context alone), 2 only for the wide GEMMs (N >= 2048), 3 only for the N < 2048 ones
+static bool gemm_tall_tiles(const gitmi_engine* e, int N) {
+    if (!e->shared_device) return false;
+    return e->gemm_tall == 1 || (e->gemm_tall == 2 && N >= 2048) || (e->gemm_tall == 3 && N < 2048);
+}
+
 // GEMM wrapper: C = act(A W^T + bias) (+ res)
 static int gemm(gitmi_engine* e, hipStream_t s, const void* A, int lda, const void* W, const float* bias,
                 const float* res, int ldr, void* C, int ldc, bool out_f32, int M, int N, int K, int act, int tag) {
     GemmArgs g{};
     g.A = A; g.W = W; g.bias = bias; g.res = res; g.C = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldr; g.act = act;
-    g.shared = e->shared_device ? 1 : 0;
+    g.shared = gemm_tall_tiles(e, N) ? 1 : 0;
     SpanGuard sp(e, s, tag, 2.0 * (double)M * (double)N * (double)K);
     HIPCK(launch_gemm(g, e->f32, out_f32, s));
     return 0;
@@ -266,7 +275,7 @@ static int gemm_stream(gitmi_engine* e, hipStream_t s, const void* A, int lda, c
     g.A = A; g.W = W; g.bias = bias; g.res = (const float*)res; g.C = C;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldr; g.act = 0;
     g.out_f16 = e->stream_f16 ? 1 : 0;
-    g.shared = e->shared_device ? 1 : 0;
+    g.shared = gemm_tall_tiles(e, N) ? 1 : 0;
     SpanGuard sp(e, s, tag, 2.0 * (double)M * (double)N * (double)K);
     HIPCK(launch_gemm(g, e->f32, !e->stream_f16, s));
     return 0;
@@ -343,6 +352,7 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     if (const char* env = getenv("GITMI_ATTN_PPW")) e->attn_ppw = atoi(env);
     if (const char* env = getenv("GITMI_ATTN_STREAM")) e->attn_stream = atoi(env);
     if (const char* env = getenv("GITMI_DECODE_SKIP")) e->decode_skip = atoi(env);
+    if (const char* env = getenv("GITMI_GEMM_TALL")) e->gemm_tall = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_ROWS")) e->dgemm_rows = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_STRIPS")) e->dgemm_strips = atoi(env);
     if (const char* env = getenv("GITMI_DGEMM_NO_ROW_WALK")) e->dgemm_no_row_walk = atoi(env);
@@ -793,7 +803,7 @@ extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
     e->Nmax = src->Nmax; e->max_pixels = src->max_pixels;
     e->use_graph = src->use_graph; e->skinny = src->skinny; e->use_temb = src->use_temb;
     e->attn_dbg = src->attn_dbg; e->dgemm_dbg = src->dgemm_dbg; e->attn_pw = src->attn_pw; e->attn_nh = src->attn_nh; e->attn_ppw = src->attn_ppw; e->attn_stream = src->attn_stream; e->decode_skip = src->decode_skip;
-    e->shared_device = src->shared_device; e->dgemm_rows = src->dgemm_rows; e->dgemm_strips = src->dgemm_strips; e->vocab_wgs = src->vocab_wgs; e->dgemm_no_row_walk = src->dgemm_no_row_walk;
+    e->shared_device = src->shared_device; e->gemm_tall = src->gemm_tall; e->dgemm_rows = src->dgemm_rows; e->dgemm_strips = src->dgemm_strips; e->vocab_wgs = src->vocab_wgs; e->dgemm_no_row_walk = src->dgemm_no_row_walk;
     e->parent = src->parent ? src->parent : src;
     e->conv_w = src->conv_w; e->cls = src->cls; e->pos = src->pos; e->pos_cur = src->pos;
     e->lnpre_g = src->lnpre_g; e->lnpre_b = src->lnpre_b; e->lnpost_g = src->lnpost_g; e->lnpost_b = src->lnpost_b;

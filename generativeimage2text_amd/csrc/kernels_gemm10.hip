@@ -92,15 +92,22 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     else if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// DBG (measurement builds only): 1 no global stores / residual reads, 2 no epilogue, 4 no ds_reads / MFMAs, 8 no loads
+// DBG (measurement builds only): 1 no global stores / residual reads, 2 no epilogue, 4 no ds_reads / MFMAs, 8 no loads,
+// 16 time stamps (tools/gemm_probe.hip): wave 0 writes s_memtime / s_memrealtime at entry, K-loop start, K-loop end and exit
+// to ((uint64_t*)g.res)[blockIdx.x * 8 ..] -- 16-bit outputs without a residual only
 // MH = rows of an activation half tile: 128 -> 256x256 tile; 96 -> 192x256 tile (3 instead of 4 row fragments per
 // quadrant), used when it fills more CUs in a single round (N = 768: 198 instead of 150 workgroups).  The A slots keep
 // their 16 KiB; with MH = 96 the last four 1-KiB pieces of a slot are loaded (clamped rows) but never read, so every
 // wave still issues two loads per half tile and the vmcnt arithmetic is unchanged.
+// MH1 (round 5) = rows of the SECOND activation half when it is shorter than the first: tiles of 224 (128 + 96), 160 (96 + 64)
+// rows ... -- any multiple of 32.  The tile height is what decides how many workgroups a launch has, and on 256 CUs
+// that decides the rounds: the N = 768 GEMMs are 150 tiles of 256 rows (59 % of the CUs for one long round) but 237 tiles
+// of 160 rows (one round at 0.625 of the length).  Quadrants (1, *) then carry MH1 / 32 row fragments instead of MH / 32.
 // EPI (fp32 outputs only): 1 direct epilogue from the accumulators, 0 the LDS-staged one (A/B: dbg bit 256)
-template <typename TOut, int ACT, int DBG = 0, int MH = 128, int EPI = 1>
+template <typename TOut, int ACT, int DBG = 0, int MH = 128, int EPI = 1, int MH1 = MH>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
-    constexpr int BM = 2 * MH, MI = MH / 32;            // row fragments of a 64/48-row quadrant
+    static_assert(MH % 32 == 0 && MH1 % 32 == 0 && MH1 <= MH && MH <= 128, "half tiles: multiples of 32 rows, second <= first");
+    constexpr int BM = MH + MH1, MI = MH / 32, MI1 = MH1 / 32;   // row fragments of a quadrant of half 0 / half 1
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x;
@@ -108,6 +115,25 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, lg = lane >> 4;
+    uint64_t ts[8];
+    auto stamp = [&](int i) {
+        if constexpr ((DBG & 16) != 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            ts[2 * i] = __builtin_amdgcn_s_memtime();
+            ts[2 * i + 1] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto stamps_out = [&]() {
+        if constexpr ((DBG & 16) != 0) {
+            if (tid == 0) {
+                uint64_t* o = reinterpret_cast<uint64_t*>(const_cast<float*>(g.res)) + (size_t)blockIdx.x * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = ts[i];
+            }
+        }
+    };
+    stamp(0);
 
     // ---- tile of this workgroup.  Workgroup b runs on XCD b % 8 (observed; only speed depends on it).  The N tiles
     // are cut into ng groups; the 8/ng XCDs of a group share its (M-major, N-fastest) tile list in contiguous,
@@ -165,7 +191,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     const int x7 = (l15 >> 1) & 7;
     const int ch0 = ((0 * 4 + lg) ^ x7) * 16;
     const int ch1 = ((1 * 4 + lg) ^ x7) * 16;
-    const int a_rd = grp * (MH / 2) * 128 + rowpart;                     // + half*HALF_BYTES + i*2048 + ch
+    const int a_rd = grp * (MH / 2) * 128 + rowpart;                     // + half*HALF_BYTES + i*2048 + ch  (half 0)
+    const int a_rd1 = grp * (MH1 / 2) * 128 + rowpart + HALF_BYTES;      //                     + i*2048 + ch  (half 1)
     const int w_rd = SLOT_B0 + wc * 32 * 128 + rowpart;            // + half*HALF_BYTES + j*2048 + ch
 
     f32x4_t acc[2][2][2][MI];  // [qm][qn][j: n-frag][i: m-frag]
@@ -180,14 +207,18 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 
     bf16x8_t af[MI][2], wf0[2][2], wf1[2][2];
 
-    auto read_a = [&](const unsigned char* sb, int half) {
+    auto read_a = [&](const unsigned char* sb, auto half_c) {
         if constexpr (DBG & 4) return;
+        constexpr int half = decltype(half_c)::value;
+        const int base = half ? a_rd1 : a_rd;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            af[i][0] = *reinterpret_cast<const bf16x8_t*>(sb + a_rd + half * HALF_BYTES + i * 2048 + ch0);
-            af[i][1] = *reinterpret_cast<const bf16x8_t*>(sb + a_rd + half * HALF_BYTES + i * 2048 + ch1);
+        for (int i = 0; i < (half ? MI1 : MI); ++i) {
+            af[i][0] = *reinterpret_cast<const bf16x8_t*>(sb + base + i * 2048 + ch0);
+            af[i][1] = *reinterpret_cast<const bf16x8_t*>(sb + base + i * 2048 + ch1);
         }
     };
+    constexpr std::integral_constant<int, 0> H0{};
+    constexpr std::integral_constant<int, 1> H1{};
     auto read_w = [&](const unsigned char* sb, int half, bf16x8_t (&wf)[2][2]) {
         if constexpr (DBG & 4) return;
 #pragma unroll
@@ -196,15 +227,16 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
             wf[j][1] = *reinterpret_cast<const bf16x8_t*>(sb + w_rd + half * HALF_BYTES + j * 2048 + ch1);
         }
     };
-    auto mma = [&](f32x4_t (&c)[2][MI], const bf16x8_t (&wf)[2][2]) {
+    auto mma = [&](f32x4_t (&c)[2][MI], const bf16x8_t (&wf)[2][2], auto half_c) {
         if constexpr (DBG & 4) return;
+        constexpr int MIq = decltype(half_c)::value ? MI1 : MI;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MIq; ++i)
                     c[j][i] = mfma16(wf[j][kk], af[i][kk], c[j][i]);
         __builtin_amdgcn_s_setprio(0);
     };
@@ -216,28 +248,28 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         // ---- P1
         read_w(sb, 0, wf0);
         __builtin_amdgcn_sched_barrier(0);
-        read_a(sb, 0);
+        read_a(sb, H0);
         if constexpr (MODE <= 1) { issue(1, 1, t + 1); wait_vm<8>(); } else { wait_vm<2>(); }
         P8_BARRIER();
-        mma(acc[0][0], wf0);
+        mma(acc[0][0], wf0, H0);
         P8_BARRIER();
         // ---- P2
         read_w(sb, 1, wf1);
         if constexpr (MODE <= 1) { issue(0, 1, t + 1); wait_vm<8>(); } else { wait_vm<0>(); }
         P8_BARRIER();
-        mma(acc[0][1], wf1);
+        mma(acc[0][1], wf1, H0);
         P8_BARRIER();
         // ---- P3
-        read_a(sb, 1);
+        read_a(sb, H1);
         if constexpr (MODE == 0) { issue(0, 0, t + 2); wait_vm<8>(); }
         P8_BARRIER();
-        mma(acc[1][1], wf1);
+        mma(acc[1][1], wf1, H1);
         P8_BARRIER();
         // ---- P4
         if constexpr (MODE == 0) { issue(1, 0, t + 2); wait_vm<8>(); }
         else if constexpr (MODE == 1) { wait_vm<4>(); }
         P8_BARRIER();
-        mma(acc[1][0], wf0);
+        mma(acc[1][0], wf0, H1);
         P8_BARRIER();
     };
 
@@ -246,10 +278,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     wait_vm<8>();                                                  // A0(0), B0(0) of this wave have landed
     P8_BARRIER();
     if (grp == 1) P8_BARRIER();                                    // group 1 runs one barrier behind
+    stamp(1);
     for (int t = 0; t < nk - 2; ++t) ktile(std::integral_constant<int, 0>{}, t);
     ktile(std::integral_constant<int, 1>{}, nk - 2);
     ktile(std::integral_constant<int, 2>{}, nk - 1);
     if (grp == 0) P8_BARRIER();
+    stamp(2);
 
     // ---- epilogue through LDS: slab = MH rows (qm) x WCOL columns ---------------------------------
     constexpr int NQN = sizeof(TOut) == 2 ? 2 : 1;                 // weight halves per slab
@@ -257,7 +291,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     constexpr int EPC = 16 / (int)sizeof(TOut);                    // elements per 16-byte chunk
     constexpr int EPS = WCOL + EPC;                                // padded row stride (elements)
     constexpr int CPR = WCOL / EPC;                                // chunks per row
-    static_assert(MH * EPS * sizeof(TOut) <= LDS_BYTES && (MH * CPR) % 512 == 0, "epilogue slab does not fit");
+    static_assert(MH * EPS * sizeof(TOut) <= LDS_BYTES && (MH * CPR) % 512 == 0 && (MH1 * CPR) % 512 == 0, "epilogue slab does not fit");
     TOut* ep = reinterpret_cast<TOut*>(smem);
     TOut* __restrict__ C = reinterpret_cast<TOut*>(g.C);
 
@@ -272,6 +306,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i) sum += acc[a][b][j][i][0] + acc[a][b][j][i][1] + acc[a][b][j][i][2] + acc[a][b][j][i][3];
         if (sum == 12345.678f) C[0] = (TOut)0;
+        stamp(3);
+        stamps_out();
         return;
     }
     f32x4_t bias4[2][2];
@@ -293,11 +329,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         const bool has_res = R != nullptr && !(DBG & 1);
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm) {
+            const int MIq = qm ? MI1 : MI, MHq = qm ? MH1 : MH;           // constants once the loop is unrolled
             f32x4_t rr[MI][2][2];
             if (has_res) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int m = m0 + qm * MH + grp * (MH / 2) + i * 16 + l15;
+                for (int i = 0; i < MIq; ++i) {
+                    const int m = m0 + qm * MH + grp * (MHq / 2) + i * 16 + l15;
                     const int mc = m < g.M ? m : g.M - 1;                      // clamped rows are loaded, never stored
                     const float* rp = R + (size_t)mc * g.ldr + col0;
 #pragma unroll
@@ -308,8 +345,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                 }
             }
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = m0 + qm * MH + grp * (MH / 2) + i * 16 + l15;
+            for (int i = 0; i < MIq; ++i) {
+                const int m = m0 + qm * MH + grp * (MHq / 2) + i * 16 + l15;
                 float* cp = Cf + (size_t)m * g.ldc + col0;
                 const bool ok = m < g.M && !(DBG & 1);
 #pragma unroll
@@ -334,6 +371,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
         for (int s = 0; s < 2 / NQN; ++s) {
+            const int MIq = qm ? MI1 : MI, MHq = qm ? MH1 : MH;           // constants once the loops are unrolled
 #pragma unroll
             for (int u = 0; u < NQN; ++u) {
                 const int qn = s * NQN + u;
@@ -341,11 +379,11 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                 for (int j = 0; j < 2; ++j) {
                     const int nl = u * 128 + wc * 32 + j * 16 + lg * 4;
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) {
+                    for (int i = 0; i < MIq; ++i) {
                         float v[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = apply_act_t<ACT>(acc[qm][qn][j][i][r] + bias4[qn][j][r]);
-                        TOut* p = ep + (grp * (MH / 2) + i * 16 + l15) * EPS + nl;
+                        TOut* p = ep + (grp * (MHq / 2) + i * 16 + l15) * EPS + nl;
                         if constexpr (sizeof(TOut) == 4) {
                             *reinterpret_cast<f32x4_t*>(p) = f32x4_t{v[0], v[1], v[2], v[3]};
                         } else {
@@ -359,7 +397,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
             }
             P8_LDS_BARRIER();
 #pragma unroll 4
-            for (int q = 0; q < MH * CPR / 512; ++q) {
+            for (int q = 0; q < MHq * CPR / 512; ++q) {
                 const int chunk = tid + q * 512;
                 const int row = chunk / CPR, cc = chunk % CPR;
                 const int m = m0 + qm * MH + row;
@@ -367,14 +405,14 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                 if (m < g.M && !(DBG & 1)) {
                     if constexpr (sizeof(TOut) == 4) {
                         f32x4_t v = *reinterpret_cast<const f32x4_t*>(ep + row * EPS + cc * EPC);
-                        if (g.res) {
+                        if (g.res && !(DBG & 16)) {
                             const f32x4_t rr = *reinterpret_cast<const f32x4_t*>(g.res + (size_t)m * g.ldr + n);
                             v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
                         }
                         *reinterpret_cast<f32x4_t*>(C + (size_t)m * g.ldc + n) = v;
                     } else {
                         u32x4_t v = *reinterpret_cast<const u32x4_t*>(ep + row * EPS + cc * EPC);
-                        if (g.res) {
+                        if (g.res && !(DBG & 16)) {
                             float f[8], rs[8];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) unpack2o<TOut>(v[e], f[2 * e], f[2 * e + 1]);
@@ -409,30 +447,42 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
             }
             P8_LDS_BARRIER();
         }
+    if constexpr ((DBG & 16) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the stamp includes the store acknowledgements
+        stamp(3);
+        stamps_out();
+    }
 }
 
 }  // namespace
 
-template <typename TOut, int MH, int EPI = 1>
+template <typename TOut, int MH, int EPI = 1, int MH1 = MH>
 static void launch_p8_t(const GemmArgs& g, hipStream_t s) {
     if (g.dbg) {      // measurement builds (tools/gemm_dbg.py); act is ignored
-        if constexpr (MH == 128) {
+        if constexpr (MH == 128 && MH1 == 128) {
             switch (g.dbg) {
                 case 1: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 1>), dim3(g.nwg), dim3(512), 0, s, g); return;
                 case 2: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 2>), dim3(g.nwg), dim3(512), 0, s, g); return;
                 case 6: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 6>), dim3(g.nwg), dim3(512), 0, s, g); return;
                 case 10: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 10>), dim3(g.nwg), dim3(512), 0, s, g); return;
+#ifdef GITMI_PROBE      // tools/gemm_probe.hip: the same variants with time stamps
+                case 16: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 16>), dim3(g.nwg), dim3(512), 0, s, g); return;
+                case 17: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 17>), dim3(g.nwg), dim3(512), 0, s, g); return;
+                case 18: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 18>), dim3(g.nwg), dim3(512), 0, s, g); return;
+                case 22: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 22>), dim3(g.nwg), dim3(512), 0, s, g); return;
+                case 26: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 26>), dim3(g.nwg), dim3(512), 0, s, g); return;
+#endif
                 default: break;
             }
         }
     }
     switch (g.act) {
         case GITMI_ACT_QUICKGELU:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_QUICKGELU, 0, MH, EPI>), dim3(g.nwg), dim3(512), 0, s, g); break;
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_QUICKGELU, 0, MH, EPI, MH1>), dim3(g.nwg), dim3(512), 0, s, g); break;
         case GITMI_ACT_GELU_ERF:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_GELU_ERF, 0, MH, EPI>), dim3(g.nwg), dim3(512), 0, s, g); break;
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_GELU_ERF, 0, MH, EPI, MH1>), dim3(g.nwg), dim3(512), 0, s, g); break;
         default:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_NONE, 0, MH, EPI>), dim3(g.nwg), dim3(512), 0, s, g); break;
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_NONE, 0, MH, EPI, MH1>), dim3(g.nwg), dim3(512), 0, s, g); break;
     }
 }
 
@@ -441,26 +491,32 @@ bool gemm_p8_supports(const GemmArgs& g) {
            (double)g.M * g.lda * 2.0 < 4.0e9 && (double)g.N * g.K * 2.0 < 4.0e9;
 }
 
-// Partition of the tile grid over the 8 XCDs for tile height 2*mh: the N tiles are cut into ng groups, the 8/ng XCDs
+// Partition of the tile grid over the 8 XCDs for tile height bm: the N tiles are cut into ng groups, the 8/ng XCDs
 // of a group share its (M-major, N-fastest) tile list in equal chunks.  Returns the rounds an XCD's 32 CUs need (one
 // workgroup per CU) for the best ng: fewest rounds first (33 tiles on one XCD cost a whole extra round), then the
 // fewest distinct operand panels among the 32 tiles an XCD runs concurrently -- ceil(32/nn) activation panels + nn
 // weight panels for a group nn tiles wide -- i.e. the best L2 sharing (8192^3: ng = 8 -> 12 panels, 1.49 PFLOP/s;
 // ng = 1 -> 33 panels, 1.05 PFLOP/s).
-static int p8_plan(const GemmArgs& g, int mh, int* ng_out, int* max_cnt_out) {
-    const int tiles_m = (g.M + 2 * mh - 1) / (2 * mh), tiles_n = g.N / BN;
+static int p8_xcd_count(const GemmArgs& g, int bm, int ng, int* max_nn_out) {
+    const int tiles_m = (g.M + bm - 1) / bm, tiles_n = g.N / BN, mg = 8 / ng;
+    int max_cnt = 0, max_nn = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int gn = x % ng, gm = x / ng;
+        const int nn = (gn + 1) * tiles_n / ng - gn * tiles_n / ng;
+        const int tg = tiles_m * nn;
+        const int cnt = (gm + 1) * tg / mg - gm * tg / mg;
+        max_cnt = cnt > max_cnt ? cnt : max_cnt;
+        max_nn = nn > max_nn ? nn : max_nn;
+    }
+    if (max_nn_out) *max_nn_out = max_nn;
+    return max_cnt;
+}
+static int p8_plan(const GemmArgs& g, int bm, int* ng_out, int* max_cnt_out) {
+    const int tiles_n = g.N / BN;
     int best_ng = 1, best_rounds = 1 << 30, best_cnt = 0, best_panels = 1 << 30;
     for (int ng = 1; ng <= 8 && ng <= tiles_n; ng *= 2) {
-        const int mg = 8 / ng;
-        int max_cnt = 0, max_nn = 0;
-        for (int x = 0; x < 8; ++x) {
-            const int gn = x % ng, gm = x / ng;
-            const int nn = (gn + 1) * tiles_n / ng - gn * tiles_n / ng;
-            const int tg = tiles_m * nn;
-            const int cnt = (gm + 1) * tg / mg - gm * tg / mg;
-            max_cnt = cnt > max_cnt ? cnt : max_cnt;
-            max_nn = nn > max_nn ? nn : max_nn;
-        }
+        int max_nn = 0;
+        const int max_cnt = p8_xcd_count(g, bm, ng, &max_nn);
         const int rounds = (max_cnt + 31) / 32;
         const int panels = (32 + max_nn - 1) / max_nn + (max_nn < 32 ? max_nn : 32);
         if (rounds < best_rounds || (rounds == best_rounds && panels < best_panels)) {
@@ -472,54 +528,72 @@ static int p8_plan(const GemmArgs& g, int mh, int* ng_out, int* max_cnt_out) {
     return best_rounds;
 }
 
-// rounds x relative tile time (4 units for the 256-row tile, 3 for the 192-row one)
-int gemm_p8_cost(const GemmArgs& g, int mh) { return p8_plan(g, mh, nullptr, nullptr) * (mh / 32); }
+// Time model of a launch with bm-row tiles, in ns: rounds x (prologue + K loop + epilogue of one tile).  Constants from the
+// workgroups' own time stamps and from the height A/B (profiles/r05_b_gemm_probe_clock_and_sections.txt, r05_c_gemm_heights.txt):
+// 1.45 us from entry to the first MFMA; 1.45 us per K tile of a 256-row tile with every CU busy, of which 35 % do not shrink
+// with the rows (the weight half tiles, barriers and waits of a K tile are the same for every height); 4.7 us of epilogue
+// for 256 rows of 16-bit output.  What it decides is how a launch quantises into rounds of 256 workgroups: N = 768 at
+// M = 12 608 is 150 tiles of 256 rows (59 % of the CUs, one long round: 28.2 / 69.8 us for K = 768 / 3072) or 237 tiles of
+// 160 rows (93 %: 22.1 / 55.7 us); N = 3072 is 600 tiles of 256 rows (three rounds, the last 34 % full: 80.3 us) or 684 of
+// 224 rows (three shorter rounds: 73.2 us).  The model ranks the heights as the A/B measured them on all twelve shapes of
+// the three BASELINE models except where two heights are within 3 %.
+int gemm_p8_cost(const GemmArgs& g, int bm) {
+    const int rounds = p8_plan(g, bm, nullptr, nullptr);
+    const int ktile = 1450 * (90 + 166 * bm / 256) / 256;          // 1450 ns x (0.35 + 0.65 bm / 256)
+    return rounds * (1450 + (g.K / BK) * ktile + 4700 * bm / 256);
+}
+
+template <int MH, int MH1>
+static void launch_p8_height(const GemmArgs& g, bool out_f32, bool staged, hipStream_t s) {
+    if (g.out_f16) launch_p8_t<f16_t, MH, 1, MH1>(g, s);
+    else if (!out_f32) launch_p8_t<bf16_t, MH, 1, MH1>(g, s);
+    else if (staged) launch_p8_t<float, MH, 0, MH1>(g, s);
+    else launch_p8_t<float, MH, 1, MH1>(g, s);
+}
 
 // g.out_f16: C (and the residual, if any) are f16_t rows -- the residual stream of the bf16 engine mode
 hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s) {
-    // the 192-row tile when it fills a partial round better (N = 768 at M = 12608: 198 workgroups instead of 150);
-    // dbg 64 / 128 force the 192- / 256-row tile (tests, A/B)
+    // tile height: the one with the lowest modelled launch time among 256 / 224 / 192 / 160 / 128 rows (ties: the taller tile,
+    // it moves fewer operand bytes per FLOP).  dbg bits force a height (tests, A/B): 64 -> 192, 128 -> 256, 16384 -> 160,
+    // 32768 -> 224, 65536 -> 128.
     // g.shared (several contexts keep the device busy: gitmi_set_shared_device): always the 256-row tile -- the CUs a
     // partial round leaves idle are filled by the other contexts' kernels, so the tile with the better FLOP/byte wins
     // (measured in the mixed schedule, profiles/r03_m_*: 10.05k -> 10.27k captions/s, while the same choice is 3 % slower
     // for a context that has the device to itself)
-    int mh = g.shared ? 128 : gemm_p8_cost(g, 96) < gemm_p8_cost(g, 128) ? 96 : 128;
-    if (g.dbg & 64) { mh = 96; g.dbg &= ~64; }
-    if (g.dbg & 128) { mh = 128; g.dbg &= ~128; }
+    static const int heights[5] = {256, 224, 192, 160, 128};
+    int bm = 256;
+    if (!g.shared) {
+        int best = gemm_p8_cost(g, 256);
+        for (int h = 1; h < 5; ++h) {
+            const int c = gemm_p8_cost(g, heights[h]);
+            if (c < best) { best = c; bm = heights[h]; }
+        }
+    }
+    if (g.dbg & 64) bm = 192;
+    if (g.dbg & 128) bm = 256;
+    if (g.dbg & 16384) bm = 160;
+    if (g.dbg & 32768) bm = 224;
+    if (g.dbg & 65536) bm = 128;
+    g.dbg &= ~(64 | 128 | 16384 | 32768 | 65536);
     g.tiles_n = g.N / BN;
     int max_cnt = 0;
-    p8_plan(g, mh, &g.ng, &max_cnt);
+    p8_plan(g, bm, &g.ng, &max_cnt);
     if (g.dbg & (1024 | 2048 | 4096 | 8192)) {           // A/B (tools/gemm_bench.py): force the XCD partition ng = 1 / 2 / 4 / 8
         const int ng = (g.dbg & 1024) ? 1 : (g.dbg & 2048) ? 2 : (g.dbg & 4096) ? 4 : 8;
         g.dbg &= ~(1024 | 2048 | 4096 | 8192);
-        if (ng <= g.tiles_n) {
-            const int tiles_m = (g.M + 2 * mh - 1) / (2 * mh), mg = 8 / ng;
-            g.ng = ng; max_cnt = 0;
-            for (int x = 0; x < 8; ++x) {
-                const int gn = x % ng, gm = x / ng;
-                const int nn = (gn + 1) * g.tiles_n / ng - gn * g.tiles_n / ng;
-                const int tg = tiles_m * nn;
-                const int cnt = (gm + 1) * tg / mg - gm * tg / mg;
-                max_cnt = cnt > max_cnt ? cnt : max_cnt;
-            }
-        }
+        if (ng <= g.tiles_n) { g.ng = ng; max_cnt = p8_xcd_count(g, bm, ng, nullptr); }
     }
+    if (g.persist && max_cnt > 32 && (bm == 256 || bm == 224) && gemm_p10_supports(g, out_f32) && (g.dbg == 0 || g.dbg == 1 || g.dbg == 32))
+        return launch_gemm_p10(g, bm, max_cnt, s);
     g.nwg = 8 * max_cnt;
     const bool staged = (g.dbg & 256) != 0;              // A/B: fp32 outputs through the LDS-staged epilogue
     g.dbg &= ~256;
-    if (g.out_f16) {
-        if (mh == 96) launch_p8_t<f16_t, 96>(g, s);
-        else launch_p8_t<f16_t, 128>(g, s);
-        return hipGetLastError();
-    }
-    if (mh == 96) {
-        if (!out_f32) launch_p8_t<bf16_t, 96>(g, s);
-        else if (staged) launch_p8_t<float, 96, 0>(g, s);
-        else launch_p8_t<float, 96>(g, s);
-    } else {
-        if (!out_f32) launch_p8_t<bf16_t, 128>(g, s);
-        else if (staged) launch_p8_t<float, 128, 0>(g, s);
-        else launch_p8_t<float, 128>(g, s);
+    switch (bm) {
+        case 224: launch_p8_height<128, 96>(g, out_f32, staged, s); break;
+        case 192: launch_p8_height<96, 96>(g, out_f32, staged, s); break;
+        case 160: launch_p8_height<96, 64>(g, out_f32, staged, s); break;
+        case 128: launch_p8_height<64, 64>(g, out_f32, staged, s); break;
+        default: launch_p8_height<128, 128>(g, out_f32, staged, s); break;
     }
     return hipGetLastError();
 }

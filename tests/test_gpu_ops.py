@@ -45,8 +45,9 @@ def test_gemm_bf16(M, N, K, act):
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_gemm_bf16_p8_variant(M, N, K, act):
     """The 256x256 half-tile pipeline kernel (kernels_gemm10.hip) with its tile height forced (measurement build): shortest K
-    (2 and 3 K tiles), ragged M, every epilogue; the 192-row and the 256-row tile must agree bit for bit (same K order), and
-    both stay within summation-order error of the register-staged tile kernel (impl 0)."""
+    (2 and 3 K tiles), ragged M, every epilogue; the 224- / 192- / 160- / 128-row tiles (round 5: second half tile shorter than
+    the first) and the 256-row tile must agree bit for bit (same K order), and all stay within summation-order error of the
+    register-staged tile kernel (impl 0)."""
     from generativeimage2text_amd import engine as E
     A = _rand(M, K, seed=11).bfloat16()
     W = _rand(N, K, seed=12, scale=K ** -0.5).bfloat16()
@@ -55,7 +56,7 @@ def test_gemm_bf16_p8_variant(M, N, K, act):
     ref = _act(A.double() @ W.double().t() + bias.double(), act)
     outs = {}
     try:
-        for tile in (9 | (128 << 8), 9 | (64 << 8), 0):
+        for tile in (9 | (128 << 8), 9 | (64 << 8), 9 | (32768 << 8), 9 | (16384 << 8), 9 | (65536 << 8), 0):
             E.set_gemm_impl(tile)
             outs[tile] = (E.op_gemm(A.cuda(), W.cuda(), bias.cuda(), res.cuda(), act, torch.float32).cpu(),
                           E.op_gemm(A.cuda(), W.cuda(), bias.cuda(), None, act, torch.bfloat16).cpu(),
@@ -67,8 +68,9 @@ def test_gemm_bf16_p8_variant(M, N, K, act):
         assert (out.double() - (ref + res.double())).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), tile
         assert (out_b.double() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item()), tile
         assert (out_br.double() - ref_br).abs().max().item() < 2e-2 * max(1.0, ref_br.abs().max().item()), tile
-    hi, lo = outs[9 | (128 << 8)], outs[9 | (64 << 8)]
-    assert all(torch.equal(a, b) for a, b in zip(hi, lo))
+    hi = outs[9 | (128 << 8)]
+    for bits in (64, 32768, 16384, 65536):
+        assert all(torch.equal(a, b) for a, b in zip(hi, outs[9 | (bits << 8)])), bits
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (64, 768, 3072), (300, 1002, 128), (1, 128, 64), (130, 70, 592)])

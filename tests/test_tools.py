@@ -83,6 +83,9 @@ def _run_bench_with_fakes(monkeypatch, capsys, argv):
         def __init__(self, enable_timing=False):
             self.t = None
 
+        def synchronize(self):
+            pass
+
         def record(self):
             self.t = time.perf_counter()
 

@@ -1,0 +1,109 @@
+// Standalone probe of the encoder GEMM (no Python, no torch): hipcc -DGITMI_PROBE --offload-arch=gfx950 -O3 -std=c++17
+//   -I generativeimage2text_amd/csrc tools/probe/gemm_probe.hip -o tools/probe/gemm_probe        (tools/probe/build.sh)
+// For every shape: event timings of the full kernel and of its compile-time ablations, and -- from the kernel's own time
+// stamps (DBG bit 16: s_memtime = shader cycles, s_memrealtime = 100 MHz) -- where a workgroup's time goes and at which
+// CLOCK the chip runs it: entry -> K-loop start (prologue), K loop, epilogue incl. the store acknowledgements; spread of the
+// workgroups' start and end times.
+#define GITMI_PROBE 1
+#include "kernels_gemm10.hip"
+#include "kernels_gemm11.hip"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+static unsigned short f2bf_host(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+struct Shape { const char* name; int M, N, K; };
+
+int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    std::vector<Shape> shapes = {{"qkv", 12608, 2304, 768}, {"c_fc", 12608, 3072, 768}, {"one_round", 8192, 2048, 768},
+                                 {"few_tiles", 768, 768, 768}, {"few_tiles_k3072", 768, 768, 3072}, {"big8k", 8192, 8192, 8192}};
+    const char* only = getenv("PROBE_SHAPES");
+    const char* fill = getenv("PROBE_FILL");                       // "zero": all-zero operands (the power A/B); default N(0,1)
+    const bool zero = fill && !strcmp(fill, "zero");
+    std::mt19937 rng(1);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    for (const Shape& sh : shapes) {
+        if (only && !strstr(only, sh.name)) continue;
+        const size_t na = (size_t)sh.M * sh.K, nw = (size_t)sh.N * sh.K, nc = (size_t)sh.M * sh.N;
+        std::vector<unsigned short> hA(na), hW(nw);
+        for (auto& v : hA) v = zero ? 0 : f2bf_host(nd(rng));
+        const float ws = 1.0f / sqrtf((float)sh.K);
+        for (auto& v : hW) v = zero ? 0 : f2bf_host(nd(rng) * ws);
+        std::vector<float> hb(sh.N);
+        for (auto& v : hb) v = nd(rng);
+        unsigned short *dA, *dW, *dC; float* db; uint64_t* dts;
+        CK(hipMalloc(&dA, na * 2)); CK(hipMalloc(&dW, nw * 2)); CK(hipMalloc(&dC, nc * 2)); CK(hipMalloc(&db, sh.N * 4));
+        CK(hipMalloc(&dts, 4096 * 8 * 8));
+        CK(hipMemcpy(dA, hA.data(), na * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hW.data(), nw * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db, hb.data(), sh.N * 4, hipMemcpyHostToDevice));
+        gitmi::GemmArgs g{};
+        g.A = dA; g.W = dW; g.bias = db; g.res = nullptr; g.C = dC; g.M = sh.M; g.N = sh.N; g.K = sh.K;
+        g.lda = sh.K; g.ldc = sh.N; g.ldr = sh.N; g.act = 0; g.shared = 1;      // shared = always the 256-row tile
+        const int tiles = ((sh.M + 255) / 256) * (sh.N / 256);
+        const double flops = 2.0 * sh.M * sh.N * sh.K;
+        printf("== %s M=%d N=%d K=%d: %d tiles of 256x256, %d K tiles each, %s operands\n", sh.name, sh.M, sh.N, sh.K, tiles, sh.K / 64,
+               zero ? "ALL-ZERO" : "N(0,1) activations, N(0,1/K) weights");
+        struct Var { int dbg; const char* label; };
+        const Var vars[] = {{0, "full"}, {1, "no stores"}, {2, "no epilogue"}, {10, "MFMA + LDS only"}, {6, "loads only"}};
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (const Var& v : vars) {
+            g.dbg = v.dbg;
+            for (int i = 0; i < 3; ++i) CK(gitmi::launch_gemm_p8(g, false, 0));
+            CK(hipDeviceSynchronize());
+            const int reps = 20;
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < reps; ++i) CK(gitmi::launch_gemm_p8(g, false, 0));
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = ms * 1e3 / reps;
+            printf("   %-16s %8.1f us/launch  %7.1f TFLOP/s-equivalent\n", v.label, us, flops / us / 1e6);
+        }
+        // stamped variants: one warm launch, then one measured
+        const Var svars[] = {{16, "full"}, {17, "no stores"}, {18, "no epilogue"}, {26, "MFMA + LDS only"}, {22, "loads only"}};
+        for (const Var& v : svars) {
+            g.dbg = v.dbg; g.res = reinterpret_cast<const float*>(dts);
+            CK(hipMemset(dts, 0, 4096 * 8 * 8));
+            CK(gitmi::launch_gemm_p8(g, false, 0)); CK(gitmi::launch_gemm_p8(g, false, 0));
+            CK(hipDeviceSynchronize());
+            std::vector<uint64_t> h(4096 * 8);
+            CK(hipMemcpy(h.data(), dts, h.size() * 8, hipMemcpyDeviceToHost));
+            g.res = nullptr;
+            // per workgroup: cycles and realtime ticks of the three sections
+            std::vector<double> cyc[3], ns[3], start, end;
+            uint64_t rt_min = ~0ull;
+            for (int b = 0; b < 4096; ++b) if (h[b * 8 + 1]) rt_min = std::min(rt_min, h[b * 8 + 1]);
+            int nb = 0;
+            for (int b = 0; b < 4096; ++b) {
+                const uint64_t* t = &h[b * 8];
+                if (!t[1]) continue;
+                ++nb;
+                for (int i = 0; i < 3; ++i) { cyc[i].push_back((double)(t[2 * (i + 1)] - t[2 * i])); ns[i].push_back(10.0 * (double)(t[2 * (i + 1) + 1] - t[2 * i + 1])); }
+                start.push_back(10.0 * (double)(t[1] - rt_min)); end.push_back(10.0 * (double)(t[7] - rt_min));
+            }
+            auto med = [](std::vector<double> x) { std::sort(x.begin(), x.end()); return x.empty() ? 0.0 : x[x.size() / 2]; };
+            auto mx = [](const std::vector<double>& x) { double m = 0; for (double v : x) m = std::max(m, v); return m; };
+            double tc = 0, tn = 0;
+            for (int i = 0; i < 3; ++i) for (size_t j = 0; j < cyc[i].size(); ++j) { tc += cyc[i][j]; tn += ns[i][j]; }
+            const int nk = sh.K / 64;
+            printf("   [stamps] %-16s %4d WGs  clock %.3f GHz | prologue %6.0f cyc %5.2f us | K loop %7.0f cyc %6.2f us = %5.0f cyc %5.3f us per K tile | "
+                   "epilogue %6.0f cyc %5.2f us | start spread %5.2f us, last start %5.2f, last end %6.2f us\n",
+                   v.label, nb, tn > 0 ? tc / tn : 0.0, med(cyc[0]), med(ns[0]) * 1e-3, med(cyc[1]), med(ns[1]) * 1e-3, med(cyc[1]) / nk,
+                   med(ns[1]) * 1e-3 / nk, med(cyc[2]), med(ns[2]) * 1e-3, med(start) * 1e-3, mx(start) * 1e-3, mx(end) * 1e-3);
+        }
+        CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(db)); CK(hipFree(dts));
+    }
+    return 0;
+}
