@@ -679,7 +679,10 @@ def main(argv=None, engine_factory=None):
             b_.synchronize()
             ev_over.append(a_.elapsed_time(b_))
         ev_over_ms = sorted(ev_over)[len(ev_over) // 2]
-        avg_ms = avg_ms_raw
+        # net of that overhead: with it removed the figure agrees with the kernel's own duration in a rocprofv3 kernel trace
+        # (profiles/r05_e_*: 49.8 us net against 49.6 us traced; raw 54.2 us)
+        avg_ms = max(avg_ms_raw - ev_over_ms, 1e-6)
+        achieved_raw = flops_per_launch / (avg_ms_raw * 1e-3) / 1e12 if avg_ms_raw > 0 else 0.0
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         result["roofline"] = {
             "kernel": f"gitmi::gemm_p8_kernel <{args.precision} operands> (the 49 image-encoder GEMM launches)"
@@ -687,9 +690,13 @@ def main(argv=None, engine_factory=None):
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
             "launches_per_step": prof["vit_gemm_launches"], "avg_launch_ms": round(avg_ms, 4),
-            "empty_event_pair_ms": round(ev_over_ms, 5),
+            "avg_launch_ms_raw": round(avg_ms_raw, 4), "empty_event_pair_ms": round(ev_over_ms, 5),
+            "frac_raw": round(achieved_raw / PEAK_BF16_TFLOPS, 4),
             "flops_per_launch": flops_per_launch,
-            "method": "HIP events around each launch on the launch stream, eager (no graph) pass after the timed region",
+            "method": "HIP events around each launch on the launch stream, eager (no graph) pass after the timed region; "
+                      "avg_launch_ms = the raw event-to-event time (avg_launch_ms_raw) minus what an event pair with nothing "
+                      "between its records measures on the same stream (empty_event_pair_ms, median of 64); frac_raw = without "
+                      "that correction",
         }
         if pmc and "gemm" in pmc:
             result["roofline"]["traffic"] = round(pmc["gemm"].get("hbm_bytes", 0)) or None
@@ -724,10 +731,11 @@ def main(argv=None, engine_factory=None):
             sgprof = solo.profile_read()
             solo.profile_enable(0)
             solo.close()
-            s_ms = sprof["vit_gemm_ms"] / max(1, sprof["vit_gemm_launches"])
+            s_raw = sprof["vit_gemm_ms"] / max(1, sprof["vit_gemm_launches"])
+            s_ms = max(s_raw - ev_over_ms, 1e-6)
             s_tf = flops_per_launch / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
-            result["roofline"]["solo_policy"] = {"avg_launch_ms": round(s_ms, 4), "achieved": round(s_tf, 2),
-                                                 "frac": round(s_tf / PEAK_BF16_TFLOPS, 4)}
+            result["roofline"]["solo_policy"] = {"avg_launch_ms": round(s_ms, 4), "avg_launch_ms_raw": round(s_raw, 4),
+                                                 "achieved": round(s_tf, 2), "frac": round(s_tf / PEAK_BF16_TFLOPS, 4)}
             ss_ms = sgprof["decode_step_ms"]
             ss_gbs = sgprof["decode_step_bytes"] / (ss_ms * 1e-3) / 1e9 if ss_ms > 0 else 0.0
             result["roofline_decode"]["solo_policy"] = {"avg_step_ms": round(ss_ms, 4), "achieved": round(ss_gbs, 1),

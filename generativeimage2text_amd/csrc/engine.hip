@@ -1844,7 +1844,7 @@ GITMI_EXP_EXPORT int gitmi_debug_head_from(gitmi_engine* dst, gitmi_engine* src,
 }
 
 GITMI_EXP_EXPORT int gitmi_debug_set_gemm_impl(int impl) {
-    if (!set_gemm_impl(impl)) return fail("debug_set_gemm_impl: unknown selector %d (low byte: -1, 0, 9 or 11)", impl);
+    if (!set_gemm_impl(impl)) return fail("debug_set_gemm_impl: unknown selector %d (low byte: -1, 0 or 9)", impl);
     return 0;
 }
 

@@ -293,7 +293,7 @@ static int g_gemm_dbg = 0;
 bool set_gemm_impl(int impl) {
     int dbg = 0;
     if (impl >= 0) { dbg = impl >> 8; impl &= 0xff; }
-    if (impl != -1 && impl != 0 && impl != 9 && impl != 11) return false;      // unknown selector: refused, state unchanged
+    if (impl != -1 && impl != 0 && impl != 9) return false;      // unknown selector: refused, state unchanged
     g_gemm_dbg = dbg;
     g_gemm_impl = impl;
     return true;
@@ -324,8 +324,7 @@ hipError_t launch_gemm(const GemmArgs& g_in, bool in_f32, bool out_f32, hipStrea
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (g.out_f16 && (in_f32 || out_f32 || g.K % 64 != 0)) return hipErrorInvalidValue;     // fp16 residual-stream rows: bf16 engine mode
     const bool fast_ok = g_gemm_impl != 0 && gemm_fast_operands(g, in_f32, out_f32) && gemm_p8_supports(g);
-    if (g_gemm_impl == 11) g.persist = 1;
-    if (fast_ok && (g.M > 512 || g_gemm_impl == 9 || g_gemm_impl == 11)) return launch_gemm_p8(g, out_f32, s);
+    if (fast_ok && (g.M > 512 || g_gemm_impl == 9)) return launch_gemm_p8(g, out_f32, s);
     if (g.out_f16) return launch_gemm_tiles<bf16_t, f16_t>(g, s);
     if (in_f32) {
         if (g.K % 16 != 0) return hipErrorInvalidValue;

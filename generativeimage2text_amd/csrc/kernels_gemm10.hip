@@ -583,8 +583,6 @@ hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s) {
         g.dbg &= ~(1024 | 2048 | 4096 | 8192);
         if (ng <= g.tiles_n) { g.ng = ng; max_cnt = p8_xcd_count(g, bm, ng, nullptr); }
     }
-    if (g.persist && max_cnt > 32 && (bm == 256 || bm == 224) && gemm_p10_supports(g, out_f32) && (g.dbg == 0 || g.dbg == 1 || g.dbg == 32))
-        return launch_gemm_p10(g, bm, max_cnt, s);
     g.nwg = 8 * max_cnt;
     const bool staged = (g.dbg & 256) != 0;              // A/B: fp32 outputs through the LDS-staged epilogue
     g.dbg &= ~256;

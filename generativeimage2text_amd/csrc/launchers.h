@@ -15,15 +15,12 @@ struct GemmArgs {
     int dbg;    // measurement builds only (gemm_p8_kernel): 1 no C stores, 2 no epilogue, 4 no MFMA, 8 no loads in loop
     int out_f16; // C and `res` are f16_t rows (residual stream of the bf16 engine mode); bf16 inputs, p8 + generic kernel only
     int shared;  // other contexts run beside this launch (serving schedule): tile choice by FLOP/byte, not by round fill
-    int persist; // 1: the persistent form (kernels_gemm11.hip) wherever a workgroup would get more than one tile and its rules hold
 };
 hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t s);
 hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s);     // 256x256x64, half-tile pipeline, staggered wave groups
 bool gemm_p8_supports(const GemmArgs& g);
-bool gemm_p10_supports(const GemmArgs& g, bool out_f32);
-hipError_t launch_gemm_p10(GemmArgs g, int bm, int max_cnt, hipStream_t s);   // persistent 256 / 224-row tiles; g.ng, g.tiles_n planned by the caller
 int gemm_p8_cost(const GemmArgs& g, int bm);   // modelled launch time (ns) with bm-row tiles: rounds x (prologue + K loop + epilogue)
-bool set_gemm_impl(int impl);   // measurement builds: -1 auto, 0 tile kernel only, 9 LDS-DMA kernel, 11 loader/consumer kernel wherever it can run (+ dbg bits << 8); false = unknown selector
+bool set_gemm_impl(int impl);   // measurement builds: -1 auto, 0 tile kernel only, 9 LDS-DMA kernel wherever it can run (+ dbg bits << 8); false = unknown selector
 
 // ---- decode-step GEMM chain (kernels_dgemm.hip): LayerNorm folded into the consumer, row partials from the producer
 struct DGemmArgs {

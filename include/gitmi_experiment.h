@@ -26,9 +26,9 @@ int  gitmi_debug_import_stage(gitmi_engine* dst, gitmi_engine* src, int stage, v
 int  gitmi_debug_head_from(gitmi_engine* dst, gitmi_engine* src, int R, float* logits_out, void* stream);
 
 /* encoder-GEMM selection for A/B measurements (process-wide): low byte -1 auto (default) | 0 register-staged tile kernel
- * only | 9 the LDS-DMA kernel wherever its shape rules hold | 11 the loader/consumer kernel (round 5) wherever ITS rules
- * hold; bits 8.. = variant / timing bits of the selected kernel (tools/gemm_bench.py lists them).  Any other low byte is
- * refused (returns non-zero, selection unchanged). */
+ * only | 9 the LDS-DMA kernel wherever its shape rules hold; bits 8.. = variant / timing bits of the selected kernel
+ * (tools/gemm_bench.py lists them: 64 / 128 / 16384 / 32768 / 65536 force the 192- / 256- / 160- / 224- / 128-row tile ...).
+ * Any other low byte is refused (returns non-zero, selection unchanged). */
 int  gitmi_debug_set_gemm_impl(int impl);
 
 /* timing bits of the decode-chain GEMMs (kernels_dgemm.hip; tools/dgemm_bench.py) for gitmi_op_dgemm / gitmi_op_dgemm_res */

@@ -3,7 +3,6 @@
 // launches each, interleaved over 3 rounds (median).  tools/probe/build.sh builds it; no Python, no torch.
 #define GITMI_PROBE 1
 #include "kernels_gemm10.hip"
-#include "kernels_gemm11.hip"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -88,47 +87,6 @@ int main() {
             const int tiles = ((sh.M + heights[h] - 1) / heights[h]) * (sh.N / 256);
             printf("   %3d rows: %4d tiles  %7.1f us  %6.1f TFLOP/s  %.3f of 2.5 PF   (model %6.1f us)\n", heights[h], tiles, us, flops / us / 1e6,
                    flops / us / 1e6 / 2500.0, gitmi::gemm_p8_cost(q, heights[h]) * 1e-3);
-        }
-        if (!sh.stream) {
-            // the persistent form (kernels_gemm11.hip) on 256- and 224-row tiles: bits of the one-tile kernel, five launches
-            // compared (race screen), then timings interleaved with the one-tile kernel; "drain" = every tile waits for its
-            // stores before the next K loop (what the form is worth without the store ordering), "no stores" = ablation
-            struct PV { const char* label; int bits; int persist; int dbg; };
-            const PV pv[] = {{"one-tile 256", 128, 0, 0}, {"persistent 256", 128, 1, 0}, {"persistent 256 drain", 128, 1, 32},
-                             {"persistent 256 no stores", 128, 1, 1}, {"one-tile 256 no stores", 128, 0, 1},
-                             {"one-tile 224", 32768, 0, 0}, {"persistent 224", 32768, 1, 0}};
-            for (int v = 1; v < 7; v += (v == 2 ? 4 : 1)) {
-                if (pv[v].dbg == 1 || !pv[v].persist) continue;
-                size_t bad_total = 0;
-                for (int rep = 0; rep < 5; ++rep) {
-                    g.dbg = pv[v].bits | pv[v].dbg; g.persist = 1; g.C = dC;
-                    CK(hipMemset(dC, 0xff, nc * 2));
-                    CK(gitmi::launch_gemm_p8(g, false, 0));
-                    CK(hipDeviceSynchronize());
-                    CK(hipMemcpy(got.data(), dC, nc * 2, hipMemcpyDeviceToHost));
-                    size_t bad = 0;
-                    for (size_t i = 0; i < nc; ++i) bad += got[i] != ref[i];
-                    bad_total += bad;
-                }
-                printf("   %-26s 5 launches vs the one-tile kernel: %zu differing outputs%s\n", pv[v].label, bad_total, bad_total ? "   !!" : "");
-            }
-            std::vector<std::vector<double>> pr(7);
-            for (int round = 0; round < 3; ++round)
-                for (int v = 0; v < 7; ++v) {
-                    g.dbg = pv[v].bits | pv[v].dbg; g.persist = pv[v].persist; g.C = dC;
-                    for (int i = 0; i < 2; ++i) CK(gitmi::launch_gemm_p8(g, false, 0));
-                    CK(hipEventRecord(e0, 0));
-                    for (int i = 0; i < 20; ++i) CK(gitmi::launch_gemm_p8(g, false, 0));
-                    CK(hipEventRecord(e1, 0));
-                    CK(hipEventSynchronize(e1));
-                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-                    pr[v].push_back(ms * 1e3 / 20);
-                }
-            for (int v = 0; v < 7; ++v) {
-                std::sort(pr[v].begin(), pr[v].end());
-                printf("   %-26s %7.1f us  %6.1f TFLOP/s  %.3f of 2.5 PF\n", pv[v].label, pr[v][1], flops / pr[v][1] / 1e6, flops / pr[v][1] / 1e6 / 2500.0);
-            }
-            g.persist = 0;
         }
         CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(dR)); CK(hipFree(dRef)); CK(hipFree(db));
     }

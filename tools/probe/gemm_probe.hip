@@ -6,7 +6,6 @@
 // workgroups' start and end times.
 #define GITMI_PROBE 1
 #include "kernels_gemm10.hip"
-#include "kernels_gemm11.hip"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
