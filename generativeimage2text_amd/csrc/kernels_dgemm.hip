@@ -520,7 +520,9 @@ template <int B, int N, class F> __device__ __forceinline__ void static_for(F&& 
     }
 }
 
-template <int MTOP, int MODE>
+// ABL (tools/probe/vocab_probe.hip only; 0 in every library): 1 no top-M insertion, 2 no log-sum-exp update, 4 no merge rounds
+// of the four lanes of a row, 8 the row block's activations are not re-read, 16 no MFMAs -- timing decomposition, wrong results
+template <int MTOP, int MODE, int ABL = 0>
 __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
     constexpr int MT = 4, NS = VOC_NS;
     constexpr bool FULLK = MODE != VOC_GENERIC, ONE_RB = MODE == VOC_GREEDY, PARK = MODE == VOC_GREEDY;
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
             const bool last_rb = rb == nrb - 1;
             const int fm_raw = rb * (16 * MT) + wave * 16 + l15;
             const int fm = fm_raw < g.M ? fm_raw : g.M - 1;
-            if constexpr (!ONE_RB) load_rows(rb);
+            if constexpr (!ONE_RB) { if (!(ABL & 8) || rb == 0) load_rows(rb); }
             // repetition penalty: which of this lane's columns (bit st*4 + r <-> column c0 + st*16 + lg*4 + r) are in the row's history
             unsigned int pen_mask = 0u;
             if constexpr (MODE == VOC_GENERIC) {
@@ -654,8 +656,10 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
 #pragma unroll
                     for (int u = 0; u < VKS; ++u)
 #pragma unroll
-                        for (int i = 0; i < MT; ++i)
-                            acc[i] = mfma16(wf[st][u], xf[u][i], acc[i]);
+                        for (int i = 0; i < MT; ++i) {
+                            if constexpr (ABL & 16) { asm volatile("" ::"v"(wf[st][u]), "v"(xf[u][i])); acc[i][0] += 1.f; }
+                            else acc[i] = mfma16(wf[st][u], xf[u][i], acc[i]);
+                        }
                     const int buf = xbuf;
                     xbuf ^= 1;
 #pragma unroll
@@ -692,9 +696,13 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
                             if ((pen_mask >> (st * 4 + r)) & 1u) x = rep_penalize(x, g.rep_penalty);
                         }
                         if (idx == last_tok) x = -10000.f;
-                        if (x > mx) { sm = sm * fast_exp(mx - x) + 1.f; mx = x; }
-                        else sm += fast_exp(x - mx);
-                        if (x > tv[MTOP - 1]) {
+                        if constexpr (ABL & 2) { asm volatile("" ::"v"(x)); }
+                        else {
+                            if (x > mx) { sm = sm * fast_exp(mx - x) + 1.f; mx = x; }
+                            else sm += fast_exp(x - mx);
+                        }
+                        if constexpr (ABL & 1) { asm volatile("" ::"v"(x)); tv[0] = fmaxf(tv[0], x); }
+                        else if (x > tv[MTOP - 1]) {
                             tv[MTOP - 1] = x; ti[MTOP - 1] = idx;
 #pragma unroll
                             for (int j = MTOP - 1; j > 0; --j) {
@@ -725,7 +733,7 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
                 else g.part_lse[slot] = float2{bm, part};
             }
 #pragma unroll
-            for (int round = 0; round < MTOP; ++round) {
+            for (int round = 0; round < ((ABL & 4) ? 1 : MTOP); ++round) {
                 float v = tv[0];
                 int id = ti[0];
                 int who = lg;

@@ -19,7 +19,7 @@ pmc)
   cp gpurun_out/pmc_summary.tsv gpurun_out/${TAG}_pmc_summary.tsv && cp gpurun_out/pmc_summary.tsv profiles/${TAG}_pmc_summary.tsv
   rm -rf gpurun_out/pmc; grep csrc_sha gpurun_out/${TAG}_pmc_summary.tsv | cut -c1-120 ;;
 bench)
-  t "default line"; timeout 400 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "rc=$?"; line gpurun_out/${TAG}_bench.json
+  t "default line"; timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "rc=$?"; line gpurun_out/${TAG}_bench.json
   t "200 steps"; timeout 200 python bench.py --no-cpu-baseline --steps 200 --warmup 8 > gpurun_out/${TAG}_bench_200steps.json 2> /dev/null; line gpurun_out/${TAG}_bench_200steps.json
   t "one context, solo policy"; timeout 200 python bench.py --no-cpu-baseline --contexts 1 --steps 10 --warmup 2 > gpurun_out/${TAG}_solo_bench.json 2> /dev/null; line gpurun_out/${TAG}_solo_bench.json ;;
 stats)
