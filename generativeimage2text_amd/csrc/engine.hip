@@ -1083,7 +1083,10 @@ static int decode_head_impl(gitmi_engine* e, const int* ids, int ld_ids, int cur
         // share the device, ~60 workgroups that each WALK four column blocks with a rolling weight refill -- the launch is
         // bound by the chip's HBM rate either way, and every CU that holds one of its waves is closed to the image encoder's
         // GEMM workgroups for the whole launch
-        v.max_wgs = e->vocab_wgs >= 0 ? e->vocab_wgs : e->shared_device ? 60 : 0;
+        // (beam batches, R > 64 rows: one column block per workgroup in either policy -- the walking form re-reads the rows of
+        // four row blocks per column block and takes 186 instead of 56 us, and the mix measures the same captions/s with either:
+        // profiles/r05_m_beam_head_wgs_ab_bench_lines.txt; the shorter launch takes 0.17 ms off every beam step)
+        v.max_wgs = e->vocab_wgs >= 0 ? e->vocab_wgs : (e->shared_device && R <= 64) ? 60 : 0;
         v.ids = ids; v.ld_ids = ld_ids; v.cur_len = cur_len; v.plen = e->plen_dev; v.beams = beams; v.suppress_kind = suppress_kind;
         v.rep_penalty = ids ? rep_penalty_of(e) : 0.f;
         v.part_val = e->part_val; v.part_idx = e->part_idx; v.part_lse = e->part_lse;

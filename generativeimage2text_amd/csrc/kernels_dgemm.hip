@@ -512,6 +512,27 @@ constexpr int VOC_MAX_BLOCKS = 8;      // column blocks a workgroup may walk (bi
 //   VOC_GENERIC any K <= 768, logits output, repetition penalty: conditional loads, stores in the loop.
 enum { VOC_GENERIC = 0, VOC_BEAM = 1, VOC_GREEDY = 2 };
 
+// x into a descending list tv (ties: the older entry stays ahead; -inf fill), in PLACE and without a dependency chain: every
+// position decides for itself from the eight comparisons -- position j takes its left neighbour if x goes in somewhere
+// before it, x if x goes in exactly here, and keeps its entry otherwise.  The same list the bubble insertion
+// (`if (x > tv[M-1]) { tv[M-1] = x; swap upwards while larger }`) leaves, bit for bit, in 5 M independent instructions
+// instead of a 7-deep chain of dependent compare-and-swaps behind a branch that some lane of the wave always takes: with one
+// wave per SIMD (256 registers) nothing hides that chain's latency -- 24 of the beam-search head's 65 us
+// (profiles/r05_l_vocab_head_beam_decomposition.txt).
+template <int M>
+__device__ __forceinline__ void topm_insert(float (&tv)[M], int (&ti)[M], float x, int idx) {
+    bool c[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) c[j] = x > tv[j];
+#pragma unroll
+    for (int j = M - 1; j >= 1; --j) {
+        tv[j] = c[j - 1] ? tv[j - 1] : (c[j] ? x : tv[j]);
+        ti[j] = c[j - 1] ? ti[j - 1] : (c[j] ? idx : ti[j]);
+    }
+    tv[0] = c[0] ? x : tv[0];
+    ti[0] = c[0] ? idx : ti[0];
+}
+
 // f(integral_constant<int, I>) for I = B .. N-1, fully unrolled with I a compile-time constant in the body
 template <int B, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (B < N) {
@@ -698,20 +719,18 @@ __global__ __launch_bounds__(256) void vocab_topm_kernel(VocabArgs g) {
                         if (idx == last_tok) x = -10000.f;
                         if constexpr (ABL & 2) { asm volatile("" ::"v"(x)); }
                         else {
-                            if (x > mx) { sm = sm * fast_exp(mx - x) + 1.f; mx = x; }
-                            else sm += fast_exp(x - mx);
+                            // online log-sum-exp, both arms of `x > mx` evaluated and selected (the arithmetic of
+                            //   if (x > mx) { sm = sm * exp(mx - x) + 1; mx = x; } else sm += exp(x - mx);
+                            // with ONE exponential and no divergent branch)
+                            const bool up = x > mx;
+                            const float e = fast_exp(up ? mx - x : x - mx);
+                            sm = up ? sm * e + 1.f : sm + e;
+                            mx = up ? x : mx;
                         }
                         if constexpr (ABL & 1) { asm volatile("" ::"v"(x)); tv[0] = fmaxf(tv[0], x); }
-                        else if (x > tv[MTOP - 1]) {
-                            tv[MTOP - 1] = x; ti[MTOP - 1] = idx;
-#pragma unroll
-                            for (int j = MTOP - 1; j > 0; --j) {
-                                if (tv[j] > tv[j - 1]) {
-                                    const float a = tv[j]; tv[j] = tv[j - 1]; tv[j - 1] = a;
-                                    const int c = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = c;
-                                }
-                            }
-                        }
+                        else if constexpr (MTOP == 1) {
+                            if (x > tv[0]) { tv[0] = x; ti[0] = idx; }
+                        } else topm_insert<MTOP>(tv, ti, x, idx);
                     }
                 }
                 // strip st of this column block is done for the last row block: its registers take the next block's strip
