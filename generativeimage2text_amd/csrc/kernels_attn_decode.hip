@@ -424,9 +424,12 @@ __global__ __launch_bounds__(64 * NH * PW) void attn_decode_mfma_kernel(AttnDeco
 // merge and output of one pair are worked off while the next pair's slots land.  A wave holds ~100 registers instead of
 // 215, a workgroup is 4 waves x RING x 4 KiB of LDS = one per CU.
 // The arithmetic is the one-wave kernel's, operation for operation (same chunks of ACS key steps, same max / rescale
-// order): bf16 outputs equal attn_decode_mfma_kernel<KB, TI, *, 1>'s in the unit test; over a whole decode the fp32
-// partials differ in the last bit (the compiler picks the fused multiply of the a*b + c*d updates of the text path per
-// instantiation), which is why the engine does not switch between the two by policy.
+// order, every fused multiply-add of the bookkeeping written out with `fp contract(off)` + explicit fmaf in BOTH kernels), so
+// the two agree BIT FOR BIT over whole decodes: the engine selects between them by policy (engine.hip: streaming for a
+// context alone with >= 384 (sentence, head) pairs and <= 256 padded keys, the register form otherwise), and
+// gitmi_set_shared_device's promise of identical results rests on it.  Guards: tests/test_gpu_ops.py (streaming == register
+// kernel on the unit entry) and tests/test_gpu_policy.py::test_shared_device_policy_is_bitwise_neutral (features, ids and
+// log-probs of the benchmark geometry under both policies, bf16 / f16 / f32 builds).
 // Ordering rules (MI355X_MICROARCH.md, LDS-DMA): a ds_read sees a DMA's bytes only after the issuing wave's counted vmcnt
 // -- loads complete in order, so `vmcnt(4 * slots issued after this one)` retires the slot (other vector-memory operations
 // issued in between only make that wait stricter); a slot is refilled only after the ds_reads that emptied it have
@@ -797,7 +800,7 @@ hipError_t launch_attn_decode_mfma(const AttnDecodeArgs& a, int B, int H, hipStr
     //    in one wave, 5 in two; GIT_BASE_VATEX bs = 16: 1.78k captions/s with one wave, 1.90k with two).
     // waves_per_pair 1 / 2 (GITMI_ATTN_NH) force one of them for A/B.
     if (a.stream_wgs > 0) {
-        // streaming kernel (measurement builds / unit entry): workgroups = min(stream_wgs, pairs / 4)
+        // streaming kernel (the solo policy's choice, engine.hip; also the unit entry): workgroups = min(stream_wgs, pairs / 4)
         const int nwg = std::max(1, std::min(a.stream_wgs, (p.n_pairs + AS_WAVES - 1) / AS_WAVES));
         if (a.beams <= 1) hipLaunchKernelGGL((attn_decode_stream_kernel<1, 3, 9>), dim3(nwg), dim3(64 * AS_WAVES), 0, s, p);
         else if (a.beams <= 2) hipLaunchKernelGGL((attn_decode_stream_kernel<2, 3, 9>), dim3(nwg), dim3(64 * AS_WAVES), 0, s, p);
