@@ -4,7 +4,8 @@
 #     pmc      rocprofv3 --pmc passes of tools/pmc_workload.py for the CURRENT csrc -> profiles/TAG_pmc_summary.tsv (bench.py reads
 #              the newest summary whose csrc hash matches; copied to profiles/ FIRST so that `bench` below reports fresh traffic)
 #     bench    the default line (python bench.py, cpu_baseline included) -> TAG_bench.json, and a 200-step line
-#     stats    the default line under rocprofv3 --kernel-trace --stats -> TAG_default_kernel_stats.txt (+ solo policy, beam-4)
+#     stats    the default line under rocprofv3 --kernel-trace --stats -> TAG_default_kernel_stats.txt (+ solo policy, beam-4, GIT_LARGE, VATEX;
+#              one row per (kernel, workgroup count), csrc hash in the header)
 #     suite    python -m pytest tests -m gpu -> TAG_pytest_gpu.txt, TAG_parity_measured.jsonl
 #     configs  bench lines of the other BASELINE configurations (beam 4, GIT_LARGE bs 32, VATEX 6 frames bs 16), bf16 and f16 builds
 #     smoke    __graft_entry__.smoke()
@@ -25,9 +26,11 @@ bench)
 stats)
   t "rocprofv3 --kernel-trace --stats: default line"
   ( cd /tmp; export TMPDIR=/tmp
-    for v in "default:" "solo:--contexts 1 --steps 10 --warmup 2" "beam4:--search beam --contexts 1 --steps 10 --warmup 2"; do
+    for v in "default:" "solo:--contexts 1 --steps 10 --warmup 2" "beam4:--search beam --contexts 1 --steps 10 --warmup 2" \
+             "large_b32:--model GIT_LARGE --batch 32 --contexts 1 --steps 8 --warmup 2" \
+             "vatex_b16:--model GIT_BASE_VATEX --frames 6 --batch 16 --contexts 1 --steps 8 --warmup 2"; do
       n=${v%%:*}; a=${v#*:}
-      timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$n -o bench -- python $R/bench.py --no-cpu-baseline $a > $R/gpurun_out/${TAG}_${n}_rocprof_bench.json 2> $R/gpurun_out/${TAG}_${n}_rocprof.err
+      timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$n -o bench -- python $R/bench.py --no-cpu-baseline --no-alt-precision $a > $R/gpurun_out/${TAG}_${n}_rocprof_bench.json 2> $R/gpurun_out/${TAG}_${n}_rocprof.err
       python $R/tools/rocprof_summary.py $R/gpurun_out/prof_$n/bench_results.db $R/gpurun_out/${TAG}_${n}_kernel_stats.txt > /dev/null
       rm -rf $R/gpurun_out/prof_$n; head -n 12 $R/gpurun_out/${TAG}_${n}_kernel_stats.txt | cut -c1-200
     done ) ;;
