@@ -30,7 +30,7 @@ stats)
              "large_b32:--model GIT_LARGE --batch 32 --contexts 1 --steps 8 --warmup 2" \
              "vatex_b16:--model GIT_BASE_VATEX --frames 6 --batch 16 --contexts 1 --steps 8 --warmup 2"; do
       n=${v%%:*}; a=${v#*:}
-      timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$n -o bench -- python $R/bench.py --no-cpu-baseline --no-alt-precision $a > $R/gpurun_out/${TAG}_${n}_rocprof_bench.json 2> $R/gpurun_out/${TAG}_${n}_rocprof.err
+      timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$n -o bench -- python $R/bench.py --no-cpu-baseline --no-alt-precision --no-teacher-forced $a > $R/gpurun_out/${TAG}_${n}_rocprof_bench.json 2> $R/gpurun_out/${TAG}_${n}_rocprof.err
       python $R/tools/rocprof_summary.py $R/gpurun_out/prof_$n/bench_results.db $R/gpurun_out/${TAG}_${n}_kernel_stats.txt > /dev/null
       rm -rf $R/gpurun_out/prof_$n; head -n 12 $R/gpurun_out/${TAG}_${n}_kernel_stats.txt | cut -c1-200
     done ) ;;
