@@ -299,6 +299,37 @@ def test_vocab_head_fused_topm(M, V, K, mtop, fold):
         assert torch.equal(ql.cpu(), pl), max_wgs
 
 
+@pytest.mark.parametrize("M", [8, 70, 256])
+@pytest.mark.parametrize("mtop", [2, 8])
+def test_vocab_head_topm_tie_order(M, mtop):
+    """Equal logits: every list of the fused head is ordered by (value descending, column ascending) -- the order the
+    positional insertion (kernels_dgemm.hip: topm_insert; round 5) must share with the bubble insertion it replaced and with
+    the 4-lane merge -- in all three kernel forms (logits-materialising, one-row-block, row-block-walking) and for walked
+    column blocks.  Integer-valued operands make the logits exact integers with hundreds of ties per 128-column block."""
+    from generativeimage2text_amd import engine as E
+    V, K, cols = 1000, 768, 128
+    g = torch.Generator().manual_seed(7)
+    x = torch.randint(-2, 3, (M, K), generator=g).float()
+    W = torch.randint(-1, 2, (V, K), generator=g).float()
+    bias = torch.zeros(V)
+    ref = x.double() @ W.double().t()                                  # exact integers, |.| << 2^24
+    assert ref.unique().numel() < V // 4                               # plenty of ties
+    order = torch.sort(ref, dim=1, descending=True, stable=True)       # stable: the lower column first among equals
+    for want_logits, max_wgs in ((True, 0), (False, 0), (False, 3), (False, 60)):
+        pv, pi, pl, lg = E.op_vocab_topm(x.bfloat16().cuda(), W.bfloat16().cuda(), bias.cuda(), mtop, cols, want_logits=want_logits,
+                                         max_wgs=max_wgs)
+        if want_logits:
+            assert torch.equal(lg.cpu().double(), ref)
+        pv, pi = pv.cpu(), pi.cpu().long()
+        for p in range(pv.shape[1]):
+            blk = ref[:, p * cols:(p + 1) * cols]
+            o = torch.sort(blk, dim=1, descending=True, stable=True)
+            k = min(mtop, blk.shape[1])
+            assert torch.equal(pv[:, p, :k].double(), o.values[:, :k]), (want_logits, max_wgs, p)
+            assert torch.equal(pi[:, p, :k], o.indices[:, :k] + p * cols), (want_logits, max_wgs, p)
+    del order
+
+
 @pytest.mark.parametrize("B,H,N_img,pos,beams", [(2, 2, 17, 0, 1), (3, 12, 197, 5, 1), (2, 12, 197, 7, 4), (1, 2, 300, 3, 3),
                                                   (1, 1, 1182, 11, 2), (2, 2, 40, 60, 4)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

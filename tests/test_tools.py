@@ -69,6 +69,21 @@ def test_rocprof_summary_on_synthetic_db(tmp_path):
     txt = open(out).read()
     assert "total GPU kernel time 0.004 ms over 3 dispatches" in txt.replace("0.0045", "0.004") or "3 dispatches" in txt
     assert "k_a" in txt and "k_b" in txt
+    assert "# csrc_sha=" in txt                                   # the trace says which kernel sources it was taken for
+    # a rocpd database with grid / workgroup columns: one row per (kernel, workgroup count) -- the same GEMM instantiation
+    # serves several shapes
+    db2 = str(tmp_path / "g.db")
+    con = sqlite3.connect(db2)
+    con.execute("create table kernels (name text, start integer, end integer, vgpr_count integer, accum_vgpr_count integer, "
+                "lds_size integer, grid_size_x integer, workgroup_size_x integer)")
+    con.executemany("insert into kernels values (?,?,?,0,0,0,?,?)",
+                    [("gemm", 0, 1000, 512 * 450, 512), ("gemm", 0, 3000, 512 * 450, 512), ("gemm", 0, 700, 512 * 150, 512)])
+    con.commit()
+    con.close()
+    out2 = str(tmp_path / "g.txt")
+    R.main(db2, out2)
+    txt2 = open(out2).read()
+    assert "gemm  <<<450 WGs>>>" in txt2 and "gemm  <<<150 WGs>>>" in txt2 and txt2.count("WGs>>>") == 2
 
 
 def _run_bench_with_fakes(monkeypatch, capsys, argv):
