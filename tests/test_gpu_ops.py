@@ -313,7 +313,7 @@ def test_vocab_head_topm_tie_order(M, mtop):
     W = torch.randint(-1, 2, (V, K), generator=g).float()
     bias = torch.zeros(V)
     ref = x.double() @ W.double().t()                                  # exact integers, |.| << 2^24
-    assert ref.unique().numel() < V // 4                               # plenty of ties
+    assert max(r.unique().numel() for r in ref) < V // 4               # every row: plenty of ties
     order = torch.sort(ref, dim=1, descending=True, stable=True)       # stable: the lower column first among equals
     for want_logits, max_wgs in ((True, 0), (False, 0), (False, 3), (False, 60)):
         pv, pi, pl, lg = E.op_vocab_topm(x.bfloat16().cuda(), W.bfloat16().cuda(), bias.cuda(), mtop, cols, want_logits=want_logits,
