@@ -14,7 +14,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 // SHAPE 0: 32 accumulator tiles of 16x16 (4 regs each), 8 A x 4 B fragments per round = 32 MFMAs of 16x16x32 (8192 MACs each)
 // SHAPE 1: 8 accumulator tiles of 32x32 (16 regs each), 4 A x 2 B fragments per round = 8 MFMAs of 32x32x16 (16384 MACs each... x2 rounds)
-template <int SHAPE>
+template <int SHAPE, int ORDER = 0>
 __global__ __launch_bounds__(512) void mfma_loop(const uint4* __restrict__ src, float* __restrict__ out, uint64_t* __restrict__ ts, int iters) {
     const int tid = threadIdx.x;
     bf16x8_t a[8], b[4];
@@ -32,10 +32,22 @@ __global__ __launch_bounds__(512) void mfma_loop(const uint4* __restrict__ src, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         for (int it = 0; it < iters; ++it) {
+            if constexpr (ORDER == 0) {          // second operand stationary over 4 MFMAs, first changes every MFMA
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            } else if constexpr (ORDER == 1) {   // first operand stationary over 8 MFMAs (the encoder GEMM's order: weights stationary over the row fragments)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            } else {                             // both operands change with every MFMA
+#pragma unroll
+                for (int d = 0; d < 8; ++d)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[(d + j) & 7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[(d + j) & 7], acc[(d + j) & 7][j], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -86,18 +98,18 @@ int main() {
             uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); hs[i] = (unsigned short)(u >> 16);
         }
         CK(hipMemcpy(d, h.data(), n16 * 16, hipMemcpyHostToDevice));
-        for (int rep = 0; rep < 2; ++rep)
-            for (int shape = 0; shape < 2; ++shape) {
-                for (int w = 0; w < 2; ++w) {
-                    if (shape == 0) hipLaunchKernelGGL(mfma_loop<0>, dim3(nwg), dim3(512), 0, 0, d, dout, dts, iters);
-                    else hipLaunchKernelGGL(mfma_loop<1>, dim3(nwg), dim3(512), 0, 0, d, dout, dts, iters);
-                }
+        for (int rep = 0; rep < 3; ++rep)
+            for (int shape = 0; shape < 4; ++shape) {
+                auto launch = [&]() {
+                    if (shape == 0) hipLaunchKernelGGL((mfma_loop<0, 0>), dim3(nwg), dim3(512), 0, 0, d, dout, dts, iters);
+                    else if (shape == 1) hipLaunchKernelGGL((mfma_loop<1, 0>), dim3(nwg), dim3(512), 0, 0, d, dout, dts, iters);
+                    else if (shape == 2) hipLaunchKernelGGL((mfma_loop<0, 1>), dim3(nwg), dim3(512), 0, 0, d, dout, dts, iters);
+                    else hipLaunchKernelGGL((mfma_loop<0, 2>), dim3(nwg), dim3(512), 0, 0, d, dout, dts, iters);
+                };
+                for (int w = 0; w < 2; ++w) launch();
                 CK(hipDeviceSynchronize());
                 CK(hipEventRecord(e0, 0));
-                for (int w = 0; w < 5; ++w) {
-                    if (shape == 0) hipLaunchKernelGGL(mfma_loop<0>, dim3(nwg), dim3(512), 0, 0, d, dout, dts, iters);
-                    else hipLaunchKernelGGL(mfma_loop<1>, dim3(nwg), dim3(512), 0, 0, d, dout, dts, iters);
-                }
+                for (int w = 0; w < 5; ++w) launch();
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -106,8 +118,8 @@ int main() {
                 double cyc = 0, rt = 0;
                 for (int b = 0; b < nwg; ++b) { cyc += (double)t[2 * b]; rt += (double)t[2 * b + 1] * 10.0; }
                 const double flops = 2.0 * nwg * 8 * (double)iters * 32 * 8192.0;        // per launch: both shapes 32 x 8192 MACs per wave-iteration
-                printf("%-9s operands  %-22s %8.1f TFLOP/s   clock %.3f GHz   %.1f cycles per 8192-MAC unit per SIMD\n", fill ? "ALL-ZERO" : "N(0,.05)",
-                       shape ? "v_mfma_f32_32x32x16_bf16" : "v_mfma_f32_16x16x32_bf16", flops / (ms / 5 * 1e-3) / 1e12, cyc / rt,
+                printf("%-9s operands  %-26s %8.1f TFLOP/s   clock %.3f GHz   %.1f cycles per 8192-MAC unit per SIMD\n", fill ? "ALL-ZERO" : "N(0,.05)",
+                       shape == 1 ? "32x32x16" : shape == 0 ? "16x16x32 B stationary x4" : shape == 2 ? "16x16x32 A stationary x8" : "16x16x32 both change", flops / (ms / 5 * 1e-3) / 1e12, cyc / rt,
                        cyc / nwg / ((double)iters * 32) / 2.0);
             }
     }
