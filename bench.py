@@ -700,6 +700,9 @@ def main(argv=None, engine_factory=None):
                       "between its records measures on the same stream (empty_event_pair_ms, median of 64); frac_raw = without "
                       "that correction",
         }
+        # (no figures here: a pointer.  The kernel's K loop is power-limited on N(0,1) operands -- identical cycle counts, lower clock --
+        # so `frac` is priced against a peak this instruction mix cannot draw the power for; the measurement is a standalone probe)
+        result["roofline"]["ceiling_evidence"] = "tools/probe/gemm_probe.hip -> profiles/r05_b_*, r05_h_gemm_power_ab.txt, r05_t_bench_socket_power.txt"
         if pmc and "gemm" in pmc:
             result["roofline"]["traffic"] = round(pmc["gemm"].get("hbm_bytes", 0)) or None
             result["roofline"]["mfma_busy_pct"] = pmc["gemm"].get("mfma_util_pct")
