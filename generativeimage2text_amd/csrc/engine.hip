@@ -47,6 +47,7 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 struct HostTensor {
     std::vector<float> data;
     std::vector<int64_t> shape;
+    float amax = 0.f;                   // max |value| (gitmi_load_tensor; every value is finite)
     size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
 };
 
@@ -434,6 +435,13 @@ extern "C" int gitmi_load_tensor(gitmi_engine* e, const char* key, const void* d
         const uint16_t* p = (const uint16_t*)data_host;
         for (size_t i = 0; i < n; ++i) t.data[i] = half_to_float(p[i]);
     } else return fail("gitmi_load_tensor: bad dtype %d", dtype);
+    // a checkpoint with inf / NaN in it fails here, by name, not as garbage ids later
+    float amax = 0.f;
+    for (size_t i = 0; i < n; ++i) {
+        if (!std::isfinite(t.data[i])) return fail("gitmi_load_tensor: '%s' holds a non-finite value at element %zu", key, i);
+        amax = std::max(amax, std::fabs(t.data[i]));
+    }
+    t.amax = amax;
     e->host_w[k] = std::move(t);
     return 0;
 }
@@ -455,10 +463,21 @@ static int up_f32(gitmi_engine* e, const std::string& key, std::initializer_list
     HIPCK(hipMemcpy(*dst, t->data.data(), t->numel() * 4, hipMemcpyHostToDevice));
     return 0;
 }
+// a MATRIX that becomes an MFMA operand must fit the operand format: fp16 tops out at 65504 (bf16 and f32 share fp32's exponent)
+static int operand_range_check(gitmi_engine* e, const char* what, float amax) {
+#ifdef GITMI_OPS_F16
+    if (!e->f32 && amax > 65504.f)
+        return fail("'%s': max |w| = %g is outside the fp16 operand range (65504): load this checkpoint with precision "
+                    "\"bf16\" or \"f32\"", what, (double)amax);
+#endif
+    (void)e; (void)what; (void)amax;
+    return 0;
+}
 // matrix [rows, K] -> compute dtype [rows, Kpad] written at dst + row_off rows
 static int up_mat_into(gitmi_engine* e, const std::string& key, int64_t rows, int K, int Kpad, void* dst, size_t row_off) {
     const HostTensor* t;
     RCK(get_w(e, key, {rows, (int64_t)K}, &t));
+    RCK(operand_range_check(e, key.c_str(), t->amax));
     float* tmp = nullptr;
     HIPCK(hipMalloc((void**)&tmp, t->numel() * 4));
     hipError_t err = hipMemcpy(tmp, t->data.data(), t->numel() * 4, hipMemcpyHostToDevice);
@@ -597,11 +616,13 @@ static int fold_layernorm(gitmi_engine* e, const std::vector<float>& W, const st
                           const std::vector<float>& gamma, const std::vector<float>& beta, int64_t rows, int K,
                           void** Wf, float** bf, float** cs) {
     std::vector<float> wf((size_t)rows * K), b2((size_t)rows), c2((size_t)rows);
+    float amax = 0.f;
     for (int64_t n = 0; n < rows; ++n) {
         double sum = 0.0, cst = bias[n];
         const float* w = &W[(size_t)n * K];
         float* o = &wf[(size_t)n * K];
         for (int k = 0; k < K; ++k) {
+            amax = std::max(amax, std::fabs(w[k] * gamma[k]));
             o[k] = bf16_round(w[k] * gamma[k]);
             sum += (double)o[k];
             cst += (double)beta[k] * (double)w[k];
@@ -609,6 +630,7 @@ static int fold_layernorm(gitmi_engine* e, const std::vector<float>& W, const st
         c2[n] = (float)sum;
         b2[n] = (float)cst;
     }
+    RCK(operand_range_check(e, "a decoder matrix with its LayerNorm gain folded in (W . gamma)", amax));
     const int64_t rows_pad = (rows + 127) / 128 * 128;       // the vocabulary head reads bias / colsum a workgroup (128 columns) at a time
     RCK(dev_alloc(e, Wf, (size_t)rows_pad * K * 2));
     float* tmp = nullptr;

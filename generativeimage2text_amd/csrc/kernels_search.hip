@@ -843,7 +843,13 @@ __global__ void search_finish_kernel(SearchState st, int cur, int cur_len, long 
         info_out[0] = st.kind == 0 ? (s_all_stop ? s_max_stop : cur_len) : st.T;
         info_out[1] = (st.kind == 0 && st.k == 1) ? s_all_early : 0;
         info_out[2] = st.info[2];
-        info_out[3] = 0;
+        // sequences whose log-prob is not finite: an operand left the range of the 16-bit format somewhere upstream (an inf in
+        // any activation turns the LayerNorm statistics, the softmax and the log-sum-exp of its sentence into NaN) -- the host
+        // side raises instead of returning garbage ids
+        const int nout = st.kind == 0 ? 1 : st.nh;
+        int bad = 0;
+        for (int i = 0; i < st.B * nout; ++i) bad += !isfinite(logprob_out[i]);
+        info_out[3] = bad;
     }
 }
 

@@ -340,7 +340,17 @@ class Engine:
         self._cur_B = B
         if sync:
             torch.cuda.current_stream().synchronize()
+            self.check_finite(info)
         return tokens, logprobs, info
+
+    def check_finite(self, info: torch.Tensor) -> None:
+        """info[3] of a finished call (include/gitmi.h): sequences with a non-finite log-prob -- an activation left the range
+        of the 16-bit operand format (fp16 tops out at 65504).  Raises instead of handing back garbage ids; callers of
+        generate(sync=False) call this once the stream has been synchronised."""
+        bad = int(info[3].item())
+        if bad:
+            raise GitmiError(f"{bad} sequence(s) came back with a non-finite log-probability: an activation overflowed the "
+                             f"{self.precision} operand range of this build -- run this checkpoint with precision='bf16' or 'f32'")
 
     def generate_coalesced(self, requests: Sequence[Sequence[torch.Tensor]], search: GitmiSearch, sync: bool = True):
         """Several requests (each a list of F frame tensors [B_i,3,H,W], same F and resolution) served by ONE engine pass
@@ -387,6 +397,7 @@ class Engine:
         self._cur_B = B
         if sync:
             torch.cuda.current_stream().synchronize()
+            self.check_finite(info)
         return tokens, logprobs, sent, info
 
     # -- search seam ---------------------------------------------------------------------------

@@ -14,7 +14,7 @@ from .configs import GitModelConfig
 
 
 def random_state_dict(cfg: GitModelConfig, seed: int = 1234, eos_bias: float = -5.0,
-                      successor: float = 0.0) -> Dict[str, torch.Tensor]:
+                      successor: float = 0.0, stats: str = "init") -> Dict[str, torch.Tensor]:
     """eos_bias < 0 keeps captions from ending early so that every caption costs max_steps-1 decode steps
     (the fixed-work protocol of SURVEY.md 8d).
 
@@ -25,7 +25,13 @@ def random_state_dict(cfg: GitModelConfig, seed: int = 1234, eos_bias: float = -
     structure, W_out[v] = N(0, .02) + successor * E[perm[v]] (E = word embedding, perm a seeded permutation): after
     token u the logit of perm^-1(u) stands out by ~2 (20 x the bf16 logit error).  The word embedding of [CLS] and
     position 0 are zero, so the hidden state of the first step is what attention reads from the IMAGE: the first token
-    is image-dependent, every later one follows the chain of its predecessor -- rows differ, no row loops."""
+    is image-dependent, every later one follows the chain of its predecessor -- rows differ, no row loops.
+
+    stats="trained": the same matrices with the STATISTICS a trained checkpoint has and a fresh initialisation lacks
+    (apply_trained_statistics below): LayerNorm gains spread over [0.2, 5], LayerNorm / Linear biases of order 1, a few
+    residual-stream channels 100-1000x above the rest, class / positional embeddings well above their init scale."""
+    if stats not in ("init", "trained"):
+        raise ValueError(f"stats must be 'init' or 'trained', not {stats!r}")
     g = torch.Generator().manual_seed(seed)
 
     def rn(*shape, std):
@@ -90,7 +96,78 @@ def random_state_dict(cfg: GitModelConfig, seed: int = 1234, eos_bias: float = -
         sd["textual.embedding.positions.weight"][0] = 0.0
     for i in range(cfg.num_frames):
         sd[f"img_temperal_embedding.{i}"] = rn(1, 1, D, std=0.02)
+    if stats == "trained":
+        apply_trained_statistics(cfg, sd, seed)
     return sd
+
+
+# residual-stream channels of the image encoder that carry an outlier, and what puts it there: (block, bias, multiple of the
+# stream's typical magnitude ~1).  Trained CLIP ViTs carry a handful of such channels from the first blocks on, two to three
+# orders of magnitude above the rest; every later LayerNorm, GEMM and the 16-bit stream rows have to live with them.
+OUTLIER_CHANNELS = ((1, "mlp.c_proj.bias", 300.0), (2, "attn.out_proj.bias", -100.0), (4, "mlp.c_proj.bias", 1000.0))
+
+
+def apply_trained_statistics(cfg: GitModelConfig, sd: Dict[str, torch.Tensor], seed: int) -> None:
+    """Rewrite, in place, the parts of a random-init state dict whose init values are degenerate (LayerNorm 1 / 0, Linear
+    bias 0, width**-0.5 embeddings) with trained-checkpoint-like statistics; the weight MATRICES are left alone.
+      * every LayerNorm: gain log-uniform in [0.2, 5], bias N(0, 1) (decoder post-norm LayerNorms: N(0, 0.5) -- their output IS
+        the hidden state the next layer adds to);
+      * every Linear bias N(0, 0.1); q / k / v biases N(0, 0.5);
+      * OUTLIER_CHANNELS: three residual channels of the image encoder lifted to 100x / 300x / 1000x the stream's magnitude by a
+        bias of the block that writes them (the gain of those channels in the following LayerNorms is 0.2: a trained model has
+        learned to scale its outliers down, it has not learned to do without them);
+      * class embedding N(0, 0.5), positional embedding N(0, 0.1) with a class-row of N(0, 0.5)."""
+    import math
+    g = torch.Generator().manual_seed(seed + 104729)
+    D = cfg.vit_width
+    picks = torch.randperm(D, generator=g)[:len(OUTLIER_CHANNELS)].tolist()
+
+    def ln(prefix, n, bias_std=1.0, calm=()):
+        gain = torch.exp(torch.rand(n, generator=g) * (math.log(5.0) - math.log(0.2)) + math.log(0.2))
+        for ch in calm:
+            gain[ch] = 0.2
+        sd[prefix + ".weight"] = gain
+        sd[prefix + ".bias"] = torch.randn(n, generator=g) * bias_std
+
+    def lin_bias(key, std=0.1):
+        sd[key] = torch.randn(sd[key].shape, generator=g) * std
+
+    sd["image_encoder.class_embedding"] = torch.randn(D, generator=g) * 0.5
+    pos = torch.randn(cfg.n_tok, D, generator=g) * 0.1
+    pos[0] = torch.randn(D, generator=g) * 0.5
+    sd["image_encoder.positional_embedding"] = pos
+    ln("image_encoder.ln_pre", D)
+    live = []                                           # outlier channels present in the stream so far
+    for i in range(cfg.vit_layers):
+        p = f"image_encoder.transformer.resblocks.{i}."
+        ln(p + "ln_1", D, calm=live)
+        lin_bias(p + "attn.in_proj_bias", 0.5)
+        lin_bias(p + "attn.out_proj.bias")
+        for (blk, key, mult), ch in zip(OUTLIER_CHANNELS, picks):
+            if blk == i and key.startswith("attn"):
+                sd[p + key][ch] = mult
+                live = live + [ch]
+        ln(p + "ln_2", D, calm=live)
+        lin_bias(p + "mlp.c_fc.bias")
+        lin_bias(p + "mlp.c_proj.bias")
+        for (blk, key, mult), ch in zip(OUTLIER_CHANNELS, picks):
+            if blk == i and key.startswith("mlp"):
+                sd[p + key][ch] = mult
+                live = live + [ch]
+    ln("image_encoder.ln_post", D, calm=live)
+    d = cfg.dec_hidden
+    lin_bias("textual.visual_projection.0.bias")
+    ln("textual.visual_projection.1", d, bias_std=0.5)
+    ln("textual.embedding.layer_norm", d, bias_std=0.5)
+    for i in range(cfg.dec_layers):
+        p = f"textual.transformer.encoder.layer.{i}."
+        for nm in ("query", "key", "value"):
+            lin_bias(p + f"attention.self.{nm}.bias", 0.5)
+        lin_bias(p + "attention.output.dense.bias")
+        lin_bias(p + "intermediate.dense.bias")
+        lin_bias(p + "output.dense.bias")
+        for nm in ("attention.output.LayerNorm", "output.LayerNorm"):
+            ln(p + nm, d, bias_std=0.5)
 
 
 def random_frames(cfg: GitModelConfig, batch: int, frames: int = 1, seed: int = 0, device="cuda") -> List[torch.Tensor]:

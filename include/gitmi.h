@@ -205,11 +205,15 @@ int  gitmi_step_logits(gitmi_engine* e, const int64_t* tokens, int R, int t,
  *   tokens_out   : int64 [B, max_steps]; sequences INCLUDE the start tokens, EOS-padded.
  *   logprob_out  : fp32 [B]  (AUTOREGRESSIVE: sum/num_valid, decoder.py:429-438;
  *                              GENERATOR: length-normalised score, decoder.py:1310-1320)
- *   info_out     : int32 [4] = { seq_len, early_all_eos, steps_run, 0 }
+ *   info_out     : int32 [4] = { seq_len, early_all_eos, steps_run, nonfinite }
  *                  seq_len = length of the tensor the reference returns (AUTOREGRESSIVE stops
  *                  when every beam ended, decoder.py:319; GENERATOR always max_steps);
  *                  early_all_eos=1 is the first-step early return of decoder.py:279-291;
- *                  steps_run = text positions appended (max_steps - 1 unless a long-budget call stopped early). */
+ *                  steps_run = text positions appended (max_steps - 1 unless a long-budget call stopped early);
+ *                  nonfinite = returned sequences whose log-prob is inf / NaN: an operand left the range of the 16-bit
+ *                  operand format (fp16: 65504) somewhere upstream -- the ids of such a call are meaningless and the
+ *                  caller must treat it as an error (the Python binding raises).  Weights are range-checked when they
+ *                  are loaded (gitmi_load_tensor / gitmi_finalize_weights fail by name). */
 int  gitmi_generate(gitmi_engine* e, const float* const* frames, int F, int B,
                     const int64_t* prefix, int P, const gitmi_search* search,
                     int64_t* tokens_out, float* logprob_out, int32_t* info_out, void* stream);

@@ -35,8 +35,9 @@ def golden_case(name):
     from oracle import git_oracle as O
     g = load_golden(name)
     cfg = O.CONFIGS[str(g["config"])]
-    wkw = eval(str(g["weights_kw"]), {"__builtins__": {}}, {"dict": dict})
-    kind, max_steps, k, pn, lp = eval(str(g["search"]), {"__builtins__": {}}, {})
+    import ast
+    wkw = ast.literal_eval(str(g["weights_kw"]))          # repr() of a plain dict / tuple, written by oracle/make_golden.py
+    kind, max_steps, k, pn, lp = ast.literal_eval(str(g["search"]))
     search = O.SearchConfig(kind, max_steps, k, pn, lp)
     w = O.make_weights(cfg, **wkw)
     hw = tuple(int(v) for v in g["hw"]) if "hw" in g and g["hw"].size else None      # non-native resolution cases

@@ -4,15 +4,15 @@ were generated from the real reference (oracle/make_golden.py).
 Tolerances (stated per north_star):
   f32 engine mode  : tokens bit-identical to the reference; features / logits / log-probs |err| <= 1e-4
                      (measured ~3e-6: fp32 summation order only)
-  bf16 engine mode : FIXED constants per model geometry (generativeimage2text_amd.parity.BF16_BOUNDS, set once from
-                     measurements with ~2x head-room, never from the run under test): visual features <= ferr abs on
-                     unit-variance LayerNorm outputs, teacher-forced logits within lerr_frac of the logit span,
-                     teacher-forced argmax identical wherever the reference's top-1/top-2 margin exceeds thr, and
-                     END-TO-END ids compared on EVERY row: a row may leave the reference's ids only at a step whose fp32
-                     decision margin (golden `step_margin`) is below thr -- a genuine near-tie; rows without such a step
-                     must be identical; the full-batch goldens additionally carry a FLOOR on identical rows
-                     (parity.IDENTICAL_FLOORS).  Every case appends its measured figures to
-                     gpurun_out/parity_measured.jsonl (copied to profiles/ per round).
+  f16 engine mode  : the HEADLINE build (fp16 operands).  ONE tolerance, from the specification (tools/parity.py):
+                     |logit error| <= SPEC_LOGIT_FRAC = 1e-3 of the reference's logit span, on every case; a decision may
+                     flip only where the fp32 margin is below 2 x that bound; END-TO-END ids compared on EVERY row: a row may
+                     leave the reference's ids only at such a near-tie; fixtures whose every margin is wider must be identical.
+  bf16 engine mode : the alternative build: 3 fewer mantissa bits, bound 2^3 x the constant (it does NOT meet the
+                     specification on general weights: profiles/r06_*error_attribution*).
+                     Regression guards beside the tolerance (constants, never derived from the run under test): visual
+                     features <= FEATURE_ERR, floors on identical rows of the full-batch goldens (IDENTICAL_FLOORS).  Every case
+                     appends its measured figures to gpurun_out/parity_measured.jsonl (copied to profiles/ per round).
 """
 import numpy as np
 import pytest
@@ -33,7 +33,7 @@ FULL_CASES = ["full_bench_b64_greedy", "full_base_b64_greedy", "full_base_b64_be
 
 
 def record_measurement(**kw):
-    """One JSON line per bf16 comparison (what the fixed bounds of parity.BF16_BOUNDS are set from)."""
+    """One JSON line per 16-bit comparison (the measured side of every bound in tools/parity.py)."""
     import json, os
     from conftest import ROOT
     d = os.path.join(ROOT, "gpurun_out")
@@ -106,12 +106,8 @@ def check_f32(name):
 
 def check_bf16(name, precision="bf16", serving=False):
     """precision "bf16" (benchmarked build) or "f16" (the fp16-operand build of the same kernels: scaled bounds)"""
-    from generativeimage2text_amd.parity import F16_SCALE, bf16_bounds, ids_parity, lerr_frac_bound
+    from tools.parity import FEATURE_ERR, ids_parity, logit_bound, margin_threshold
     g, cfg, feats, logits, preds, lps = run_case(name, precision, serving=serving)
-    bnd = dict(bf16_bounds(cfg.name))
-    if precision == "f16":
-        bnd["thr"] *= F16_SCALE["thr"]
-        bnd["ferr"] *= F16_SCALE["ferr"]
     big = cfg.vocab > 5000
     fs = feats[:, ::7, ::5] if big else feats
     ferr = float(np.abs(fs.numpy() - g["feat_sample"]).max())
@@ -123,25 +119,25 @@ def check_bf16(name, precision="bf16", serving=False):
            "config": cfg.name, "ferr": round(ferr, 5),
            "lerr": round(lerr, 5), "span": round(span, 3), "lerr_frac": round(lerr / span, 6)}
     try:
-        assert ferr < bnd["ferr"], ferr
-        assert lerr < lerr_frac_bound(name, cfg.name, precision) * span, (lerr, span)
-        # token identity wherever the reference's own margin is resolvable at bf16 precision
-        from generativeimage2text_amd.parity import margin_threshold
-        lbound = lerr_frac_bound(name, cfg.name, precision) * span
+        assert ferr < FEATURE_ERR[precision], ferr
+        lbound = logit_bound(precision, span)               # the specification's constant x span (x 2^3 for bf16)
+        assert lerr < lbound, (lerr, span)
+        # token identity wherever the reference's own margin is resolvable within that bound
         am = logits.argmax(-1).numpy()
         for r in range(am.shape[0]):
-            if g["tf_top2_margin"][r] > margin_threshold(cfg.name, lbound, False, precision):
+            if g["tf_top2_margin"][r] > margin_threshold(precision, lbound, False):
                 assert am[r] == g["tf_argmax"][r]
         # end-to-end ids, every row
         ref_p = g["predictions"]
-        kind, _, k, _, _ = eval(str(g["search"]), {"__builtins__": {}}, {})
+        import ast
+        kind, _, k, _, _ = ast.literal_eval(str(g["search"]))
         if ref_p.shape[1] <= 1 and kind == "greedy":                        # first-step early return (decoder.py:279-291)
             if preds.shape == ref_p.shape:
                 assert np.array_equal(preds.numpy(), ref_p)
             return
         chained = not (kind == "greedy" and k == 1)
         # golden predictions of prefixed cases have the prefix stripped (decoder.py:1004-1006): decision s wrote position s
-        stats = ids_parity(preds.numpy(), ref_p, g["step_margin"], margin_threshold(cfg.name, lbound, chained, precision),
+        stats = ids_parity(preds.numpy(), ref_p, g["step_margin"], margin_threshold(precision, lbound, chained),
                            chained, first_decision_pos=0 if g["prefix"].size else 1)
         rec.update(stats)
         print(name, stats)
@@ -187,8 +183,8 @@ def test_serving_policy_shapes_against_reference_goldens(name, prec):
 
 @pytest.mark.parametrize("name", TINY_CASES + BIG_CASES)
 def test_f16_operand_build_within_tolerance(name):
-    """libgitmi_f16.so: the same kernels built for fp16 operands (Engine(precision="f16")); bounds 0.3x / threshold 0.4x
-    of the bf16 build's."""
+    """libgitmi_f16.so, the headline build: the same kernels built for fp16 operands (Engine(precision="f16")), held to the
+    specification's constant itself (tools/parity.SPEC_LOGIT_FRAC)."""
     check_bf16(name, "f16")
 
 
@@ -209,8 +205,8 @@ def test_full_batch_ids_against_reference(name):
     """BASELINE.json configs at their full batch sizes (cfg2 B=64 greedy as benchmarked and with perturbed affines, cfg3
     B=64 beam 4, cfg4 GIT_LARGE B=32, cfg5 VATEX 6 frames B=16): reference ids from tests/golden/full_*.npz.
     f32 mode: bit-identical ids on every row.  bf16 mode (the benchmarked one): every row compared, divergence only at
-    a near-tie of the fp32 reference (generativeimage2text_amd.parity)."""
-    from generativeimage2text_amd.parity import ids_parity
+    a near-tie of the fp32 reference (tools/parity.py)."""
+    from tools.parity import ids_parity
     g = load_golden(name)
     cfg, w, frames, search, _ = MG.full_case_inputs(name)
     B, F = frames[0].shape[0], len(frames)
@@ -237,16 +233,15 @@ def test_full_batch_ids_against_reference(name):
             assert preds.shape == ref_p.shape and np.array_equal(preds.numpy(), ref_p)
             assert np.allclose(lps.numpy(), ref_l, atol=1e-4)
         else:
-            from generativeimage2text_amd.parity import (IDENTICAL_FLOORS, IDENTICAL_FLOORS_F16, lerr_frac_bound,
-                                                         margin_threshold)
+            from tools.parity import IDENTICAL_FLOORS, IDENTICAL_FLOORS_F16, logit_bound, margin_threshold
             floors = IDENTICAL_FLOORS_F16 if prec == "f16" else IDENTICAL_FLOORS
             span = float(g["tf_logits"].max() - g["tf_logits"].min())
             rec = {"case": (name if prec == "bf16" else name + "@" + prec) + ("@serving" if serving else ""),
                    "config": cfg.name, "lerr": round(lerr, 5), "span": round(span, 3), "lerr_frac": round(lerr / span, 6)}
             try:
-                lbound = lerr_frac_bound(name, cfg.name, prec) * span
+                lbound = logit_bound(prec, span)
                 assert lerr < lbound, (lerr, span)
-                stats = ids_parity(preds.numpy(), ref_p, g["step_margin"], margin_threshold(cfg.name, lbound, chained, prec),
+                stats = ids_parity(preds.numpy(), ref_p, g["step_margin"], margin_threshold(prec, lbound, chained),
                                    chained, min_identical=floors[name])
                 rec.update(stats)
                 print(name, prec, "logit err %.4f of span %.2f" % (lerr, span), stats)
@@ -256,7 +251,8 @@ def test_full_batch_ids_against_reference(name):
 
 
 TF_CASES = ["full_bench_b64_greedy", "full_base_b64_greedy", "full_large_b32_greedy", "full_vatex_b16_greedy",
-            "full_wide_b64_greedy", "full_wide_large_b32_greedy", "full_wide_vatex_b16_greedy"]
+            "full_wide_b64_greedy", "full_wide_large_b32_greedy", "full_wide_vatex_b16_greedy",
+            "full_trained_b8_greedy", "full_trained_b64_greedy"]
 
 
 @pytest.mark.parametrize("name", TF_CASES)
@@ -270,7 +266,7 @@ def test_teacher_forced_decisions_against_reference(name):
     oracle/make_golden.py from ONE teacher-forced pass of the unmodified reference) and over ALL 30 522 columns against the
     f32 engine mode, which is itself held to 1e-4 of the frozen values.  f32 mode: every live decision must agree.
     bf16 and f16 builds, solo and serving kernel shapes."""
-    from generativeimage2text_amd.parity import teacher_forced_parity, tf_bounds
+    from tools.parity import teacher_forced_parity, tf_bounds
     g, gt = load_golden(name), load_golden(name + "_tf")
     cfg, w, frames, search, _ = MG.full_case_inputs(name)
     B, F = frames[0].shape[0], len(frames)
@@ -287,7 +283,7 @@ def test_teacher_forced_decisions_against_reference(name):
             cache[t] = e32.step_logits(tokens).clone()
         return cache[t]
 
-    b32 = tf_bounds(name, cfg.name, "f32", span)
+    b32 = tf_bounds("f32", span)
     st = teacher_forced_parity(f32_logits, ref, gt, cfg.eos, b32["thr"], b32["lerr"])
     record_measurement(case=name + "@tf@f32", config=cfg.name, **st)
     assert st["ok"], st
@@ -295,7 +291,7 @@ def test_teacher_forced_decisions_against_reference(name):
     e32.close()
     for prec in ("bf16", "f16"):
         eng = make_engine(cfg, w, prec, B, search, frames=F)
-        b = tf_bounds(name, cfg.name, prec, span)
+        b = tf_bounds(prec, span)                              # the specification's constant x span (x 2^3 for bf16)
         for serving in (False, True):
             eng.set_shared_device(serving)
             eng.encode(dev)
@@ -303,11 +299,13 @@ def test_teacher_forced_decisions_against_reference(name):
             record_measurement(case=name + "@tf@" + prec + ("@serving" if serving else ""), config=cfg.name, **st)
             print(name, prec, "serving" if serving else "solo", st)
             assert st["ok"], st
+            assert np.isfinite(st["max_logit_err"]), st
         eng.close()
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("name", ["full_wide_b64_greedy", "full_wide_large_b32_greedy", "full_wide_vatex_b16_greedy"])
+@pytest.mark.parametrize("name", ["full_wide_b64_greedy", "full_wide_large_b32_greedy", "full_wide_vatex_b16_greedy",
+                                  "full_trained_b8_greedy", "full_trained_b64_greedy"])
 def test_wide_margin_batch_ids_identical_to_reference(name, prec):
     """north_star: "greedy outputs bit-identical to reference token IDs".  With plain random-init weights that clause is
     undecidable for ANY 16-bit pipeline: Gaussian logits over 30522 tokens put a top-1 / top-2 gap below the pipeline's own
@@ -317,12 +315,21 @@ def test_wide_margin_batch_ids_identical_to_reference(name, prec):
     (synthetic.random_state_dict(successor=1.0)) and 64 images on which EVERY decision of the fp32 reference has a margin
     >= 0.2 (oracle/make_golden.py: select_wide_images; first tokens differ with the image, 20 distinct ids per row) -- and
     there every precision of the engine must return the reference's ids on 64 of 64 rows.  The same construction for the
-    other two greedy BASELINE configurations: cfg4 GIT_LARGE B = 32 (32 of 32) and cfg5 VATEX 6 frames B = 16 (16 of 16)."""
-    from generativeimage2text_amd.parity import ids_parity
+    other two greedy BASELINE configurations: cfg4 GIT_LARGE B = 32 (32 of 32) and cfg5 VATEX 6 frames B = 16 (16 of 16).
+    full_trained_b8 / b64 (round 6): cfg2 with the STATISTICS of a trained checkpoint (synthetic.apply_trained_statistics:
+    LayerNorm gains over [0.2, 5], biases of order 1, three ViT residual channels 100x / 300x / 1000x above the rest): every
+    margin >= 0.03 = 2 x the specification's logit tolerance, so the f32 mode and the headline fp16 build must return every
+    row; the bf16 build (bound 2^3 x wider than those margins) is held to finite outputs and its own logit bound."""
+    from tools.parity import identity_required, ids_parity, logit_bound
     g = load_golden(name)
     cfg, w, frames, search, _ = MG.full_case_inputs(name)
     B, F = frames[0].shape[0], len(frames)
-    assert float(g["step_margin"].min()) >= 0.1 and B == MG.FULL_CASES[name][2]
+    trained = "trained" in name
+    min_margin = float(g["step_margin"].min())
+    assert min_margin >= (0.03 if trained else 0.1) and B == MG.FULL_CASES[name][2]
+    span_ref = float(g["tf_logits"].max() - g["tf_logits"].min())
+    must = identity_required(prec, span_ref, min_margin)
+    assert must or (trained and prec == "bf16"), (name, prec, min_margin, span_ref)
     eng = make_engine(cfg, w, prec, B, search, frames=F)
     dev = [f.cuda() for f in frames]
     for serving in (False, True):               # solo kernel shapes, then the serving policy's, on the same engine
@@ -332,14 +339,18 @@ def test_wide_margin_batch_ids_identical_to_reference(name, prec):
         logits = eng.step_logits(torch.from_numpy(g["tf_tokens"]))[:4, ::3].cpu().numpy()
         lerr = float(np.abs(logits - g["tf_logits"]).max())
         span = float(g["tf_logits"].max() - g["tf_logits"].min())
-        stats = ids_parity(preds.numpy(), g["predictions"], g["step_margin"], 0.1, chained=False, min_identical=B)
+        assert np.isfinite(logits).all() and torch.isfinite(lps).all(), (name, prec, "non-finite outputs")
+        assert lerr < logit_bound(prec, span), (lerr, span)
+        thr = min(min_margin, 0.1) if must else 2.0 * logit_bound(prec, span)
+        stats = ids_parity(preds.numpy(), g["predictions"], g["step_margin"], thr, chained=False, min_identical=B if must else None)
         record_measurement(case=name + "@" + prec + ("@serving" if serving else ""), config=cfg.name, lerr=round(lerr, 5),
                            span=round(span, 3), lerr_frac=round(lerr / span, 6),
-                           min_margin=round(float(g["step_margin"].min()), 4), **stats)
-        assert stats["identical"] == B and stats["safe_rows"] == B, (serving, stats)
-        assert np.allclose(lps.numpy(), g["logprobs"], atol=1e-4 if prec == "f32" else 0.05), np.abs(lps.numpy() - g["logprobs"]).max()
+                           min_margin=round(min_margin, 4), required=bool(must), **stats)
+        if must:
+            assert stats["identical"] == B and stats["safe_rows"] == B, (serving, stats)
+            assert np.allclose(lps.numpy(), g["logprobs"], atol=1e-4 if prec == "f32" else 0.05), np.abs(lps.numpy() - g["logprobs"]).max()
         # the rows are not copies of each other (the VATEX model's first token is all but image-independent: one caption)
-        assert len({tuple(r) for r in preds.numpy().tolist()}) >= {64: 8, 32: 4}.get(B, 1)
+        assert len({tuple(r) for r in preds.numpy().tolist()}) >= ({64: 8, 32: 4}.get(B, 1) if not trained else 2)
     eng.close()
 
 
@@ -349,7 +360,7 @@ def test_wide_margin_batch_beam4_ids_identical_to_reference(prec):
     length_penalty 0.6): tests/golden/full_wide_b64_beam4.npz, frozen from the unmodified reference.  No margin certificate
     exists for a beam search (the 2k candidates a step keeps include Gaussian-close runner-ups for any weights: median
     adjacent gap 0.01): f32 mode must return 64 of 64 rows, the 16-bit modes at least parity.WIDE_BEAM_FLOOR (measured 62 / 63)."""
-    from generativeimage2text_amd.parity import WIDE_BEAM_FLOOR
+    from tools.parity import WIDE_BEAM_FLOOR
     name = "full_wide_b64_beam4"
     g = load_golden(name)
     cfg, w, frames, search, _ = MG.full_case_inputs(name)
@@ -650,11 +661,11 @@ def test_long_step_budget_polling_path(kind):
             assert torch.allclose(lps, ref["logprobs"], atol=2e-3)
         else:
             # bf16 (fused head, folded LayerNorms, eager polling path): a row may differ from the reference only if one of
-            # its decisions is a near-tie (fixed threshold, parity.BF16_BOUNDS); compared on EOS-padded rows
-            from generativeimage2text_amd.parity import bf16_bounds, ids_parity
+            # its decisions is a near-tie (fixed threshold, tools/parity.BEAM_MARGIN_THR); compared on EOS-padded rows
+            from tools.parity import BEAM_MARGIN_THR, ids_parity
             L = max(preds.shape[1], ref["predictions"].shape[1])
             pad = lambda x: torch.cat([x, torch.full((x.shape[0], L - x.shape[1]), cfg.eos, dtype=x.dtype)], 1).numpy()
-            stats = ids_parity(pad(preds), pad(ref["predictions"]), margins, 2 * bf16_bounds(cfg.name)["thr"], chained=True)
+            stats = ids_parity(pad(preds), pad(ref["predictions"]), margins, BEAM_MARGIN_THR["bf16"], chained=True)
             record_measurement(case="long_budget_" + kind, config=cfg.name, **stats)
             assert torch.isfinite(lps).all()
         eng.close()
@@ -696,9 +707,9 @@ def test_ragged_prefixes_equal_per_question_reference_calls(kind):
             assert got == want[q][0], (kind, q, got, want[q][0])
             assert abs(float(logprobs[q]) - want[q][1]) < 1e-4, (kind, q)
     # bf16 mode runs the same call (fused vocabulary head, folded LayerNorms): a sentence may differ from its own
-    # reference call only if one of that call's decisions is a near-tie (fixed threshold, parity.BF16_BOUNDS)
-    from generativeimage2text_amd.parity import bf16_bounds
-    thr = bf16_bounds(cfg.name)["thr"] * (1 if (search.kind == "greedy" and search.beam_size == 1) else 2)
+    # reference call only if one of that call's decisions is a near-tie (fixed thresholds of tools/parity.py)
+    from tools.parity import BEAM_MARGIN_THR, GREEDY_MARGIN_CAP
+    thr = GREEDY_MARGIN_CAP["bf16"] if (search.kind == "greedy" and search.beam_size == 1) else BEAM_MARGIN_THR["bf16"]
     eb = make_engine(cfg, w, "bf16", 8, search)
     tb, lb, sb, _ = eb.generate_prefixed(dev, search_struct(search), prefixes, image_of)
     tb, sb = tb.cpu(), sb.cpu()

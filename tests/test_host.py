@@ -718,16 +718,23 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
 
 
 def test_margin_threshold_follows_the_logit_bound():
-    """parity.margin_threshold: for one-beam searches the margin below which a row may leave the reference's ids is
-    2 x the (fixed) logit-error bound, capped by the per-geometry constant; beam search keeps 2 x the constant; the f16 build
-    scales the constant.  ids_parity with it: a divergence at a wide margin fails, at a narrow one passes, the floor on
-    identical rows is enforced."""
-    from generativeimage2text_amd import parity as P
-    cap = P.bf16_bounds("GIT_BASE")["thr"]
-    assert P.margin_threshold("GIT_BASE", 0.0179, False) == pytest.approx(0.0358)            # the benchmark workload's bound
-    assert P.margin_threshold("GIT_BASE", 0.35, False) == cap                                # wide-span oracle weights: the cap
-    assert P.margin_threshold("GIT_BASE", 0.0179, True) == pytest.approx(2 * cap)            # beam: fixed
-    assert P.margin_threshold("GIT_BASE", 1.0, False, "f16") == pytest.approx(cap * P.F16_SCALE["thr"])
+    """tools/parity.py: ONE tolerance, the specification's 1e-3 of the reference's logit span, for the headline (fp16) build on
+    every case; 2^3 x for bf16 (three fewer mantissa bits); f32 mode 1e-4 absolute.  The margin below which a one-beam row may
+    leave the reference's ids is 2 x that bound (capped by a regression constant); beam search keeps a fixed constant.
+    ids_parity with it: a divergence at a wide margin fails, at a narrow one passes, the floor on identical rows is enforced."""
+    from tools import parity as P
+    assert P.SPEC_LOGIT_FRAC == 1e-3 and P.FORMAT_FACTOR == {"f16": 1.0, "bf16": 8.0}
+    assert P.logit_bound("f16", 14.5) == pytest.approx(0.0145) and P.logit_bound("bf16", 14.5) == pytest.approx(0.116)
+    assert P.logit_bound("f32", 14.5) == 1e-4
+    assert P.tf_bounds("f16", 18.5) == {"lerr": pytest.approx(0.0185), "thr": pytest.approx(0.037)}
+    assert P.margin_threshold("f16", 0.0145, False) == pytest.approx(0.029)                       # follows the bound
+    assert P.margin_threshold("bf16", 0.35, False) == P.GREEDY_MARGIN_CAP["bf16"]                  # wide-span weights: the cap
+    assert P.margin_threshold("bf16", 0.0179, True) == P.BEAM_MARGIN_THR["bf16"]                   # beam: fixed
+    assert P.identity_required("f32", 14.0, 1e-3) and P.identity_required("f16", 14.0, 0.03)
+    assert not P.identity_required("bf16", 14.0, 0.03) and P.identity_required("bf16", 14.5, 0.25)
+    import generativeimage2text_amd
+    assert not os.path.exists(os.path.join(os.path.dirname(generativeimage2text_amd.__file__), "parity.py")), \
+        "acceptance policy is test infrastructure: it must not ship inside the product package"
     ref = np.array([[101, 5, 6, 7], [101, 8, 9, 10]])
     margin = np.array([[0.5, 0.01, 0.5], [0.5, 0.5, 0.5]], dtype=np.float32)
     got = ref.copy()
@@ -740,7 +747,8 @@ def test_margin_threshold_follows_the_logit_bound():
     bad[1, 1] = 99                                           # row 1 has no narrow decision: any divergence is a failure
     with pytest.raises(AssertionError):
         P.ids_parity(bad, ref, margin, 0.0358, chained=False)
-    assert set(P.IDENTICAL_REQUIRED) == {"full_wide_b64_greedy", "full_wide_large_b32_greedy", "full_wide_vatex_b16_greedy"}
+    assert set(P.IDENTICAL_REQUIRED) == {"full_wide_b64_greedy", "full_wide_large_b32_greedy", "full_wide_vatex_b16_greedy",
+                                         "full_trained_b8_greedy", "full_trained_b64_greedy"}
 
 
 def test_teacher_forced_parity_counts_and_violations():
@@ -749,7 +757,7 @@ def test_teacher_forced_parity_counts_and_violations():
     fixtures it runs on in the GPU suite are self-consistent (argmax of the frozen top-8 after the no-repeat rule == the
     reference's ids; margins == the step margins of the free-running golden)."""
     import torch
-    from generativeimage2text_amd import parity as P
+    from tools import parity as P
     V, B, L = 50, 3, 5
     rng = np.random.RandomState(0)
     table = rng.randn(L - 1, B, V).astype(np.float32)                       # logits of decision s for row r
@@ -808,4 +816,7 @@ def test_teacher_forced_parity_counts_and_violations():
         m = sv[:, :, 0] - sv[:, :, 1]
         fin = live & np.isfinite(g["step_margin"])
         assert np.abs(m - t["margin"])[live].max() < 1e-5 and np.abs(t["margin"] - g["step_margin"])[fin].max() < 2e-4, name
-        assert (P.tf_bounds(name, str(g["config"]), "bf16", 12.0)["thr"] > 0)
+        span = float(t["logit_max"]) - float(t["logit_min"])
+        assert P.tf_bounds("f16", span)["thr"] == pytest.approx(2e-3 * span)      # ONE constant for every fixture
+        if name.startswith("full_trained"):          # every margin >= 2 x the headline build's bound: identity is REQUIRED
+            assert P.identity_required("f16", span, float(g["step_margin"].min())), name

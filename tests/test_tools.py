@@ -3,6 +3,8 @@ import os
 import sqlite3
 import sys
 
+import pytest
+
 from conftest import ROOT
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -171,7 +173,15 @@ def _run_bench_with_fakes(monkeypatch, capsys, argv):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BENCH_GEMM_IMPL"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline"] + argv)
-    monkeypatch.setattr(bench, "alt_precision_line", lambda child: {"precision": "f16", "child_argv": child})
+    monkeypatch.setattr(bench, "alt_precision_line", lambda child: {"precision": child[1], "child_argv": child})
+    children = []
+
+    def fake_child(argv_child, timeout_s=150):
+        children.append(list(argv_child))
+        return {"value": 1000.0, "ms_per_step": 1.0, "steps": 8, "dtype": "f16", "config": {"workload": " ".join(argv_child[:4])},
+                "roofline_decode": {"avg_step_ms": 0.3}, "parity": {"ok": True, "rows": 64, "identical": 60, "wide_margin": None}}
+    monkeypatch.setattr(bench, "child_line", fake_child)
+    bench._test_children = children
     try:
         bench.main()
     finally:
@@ -192,20 +202,32 @@ def test_bench_control_flow_all_schedules(monkeypatch, capsys):
         assert k in d["roofline"] and k in d["roofline_decode"], k
     timed = [e for e in log if e[0] == "generate"]
     assert len(timed) >= 4 + 3 + 8                      # priming pass over the contexts + warm-up + timed steps (+ roofline passes)
-    # round 5: every decision teacher-forced against the reference; the fp16-operand build as a child run of the same schedule
+    # round 5: every decision teacher-forced against the reference; round 6: the headline is the fp16-operand build (the one
+    # that meets the specification's logit tolerance), the bf16 build runs as a child on the same schedule
+    assert d["dtype"] == "f16" and d["config"]["library"] == "libgitmi_f16.so"
     tf = d["parity"]["teacher_forced"]
     assert tf["decisions"] == 64 * 19 and 0 < tf["decidable"] <= tf["decisions"] and "max_logit_err" in tf
+    assert tf["spec_logit_frac"] == pytest.approx(1e-3) and tf["logit_err_bound"] == pytest.approx(1e-3 * tf["logit_span"], rel=1e-3)
     child = d["alt_precision"]["child_argv"]
-    assert child[:3] == ["--precision", "f16", "--brief"] and child[child.index("--steps") + 1] == "8"
+    assert child[:3] == ["--precision", "bf16", "--brief"] and child[child.index("--steps") + 1] == "8"
+    # the second parity leg: trained-checkpoint statistics, same geometry, every row required of the headline build
+    tr = d["parity"]["trained_statistics"]
+    assert tr["reference"].endswith("full_trained_b64_greedy.npz") and tr["required"] == 64 and tr["teacher_forced"]["decisions"] == 64 * 19
+    assert tr["ok"] is False and d["parity"]["ok"] is False           # the stand-in engine returns constant ids: the leg must notice
+    # the other BASELINE configurations ride in the same line, one short child each, in this run's precision
+    assert set(d["other_configs"]) == {"cfg3_base_b64_beam4", "cfg4_large_b32_greedy", "cfg5_vatex_b16_6frames"}
+    import bench
+    assert all(c[c.index("--precision") + 1] == "f16" and "--brief" in c for c in bench._test_children)
+    assert d["other_configs"]["cfg3_base_b64_beam4"]["parity"]["identical"] == 60
     # --brief (what that child runs): timed loop + parity, no roofline passes
     d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--warmup", "3", "--brief", "--precision", "f16"])
-    assert "roofline" not in d and "alt_precision" not in d and "parity" in d and d["dtype"] == "f16"
+    assert "roofline" not in d and "alt_precision" not in d and "other_configs" not in d and "parity" in d and d["dtype"] == "f16"
+    assert d["roofline_decode"]["avg_step_ms"] == 0.25
     # coalesced: two requests per engine pass
     d, log = _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "8", "--warmup", "3", "--coalesce", "2"])
     assert "2 requests of 64 images coalesced" in d["config"]["schedule"] and d["warmup"] == 4
     passes = [e for e in log if e == ("generate", 128)]
     assert len(passes) == 4 + 2 + 4                     # priming (one pass per context), warm-up 4 steps, 8 timed steps
-    import pytest
     with pytest.raises(SystemExit):
         _run_bench_with_fakes(monkeypatch, capsys, ["--steps", "7", "--coalesce", "2"])
     # the schedules that lost were removed in round 5: their flags no longer exist
