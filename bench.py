@@ -525,6 +525,11 @@ def main(argv=None, engine_factory=None):
     ap.add_argument("--cpu-sweep", action="store_true",
                     help="only time the CPU port at several thread counts (median of 3, bs=8) and print JSON")
     args = ap.parse_args(argv)
+    if args.e2e_tsv:
+        from tools.e2e_tsv import main as e2e_main
+        e2e_main(["--rows", str(args.e2e_tsv), "--precision", args.precision, "--batch", str(args.batch),
+                  "--contexts", str(args.contexts)])
+        return
     if args.cpu_sweep:
         res = []
         for th in (16, 32, 64, 128):

@@ -356,85 +356,194 @@ class CaptioningModel:
                                   repetition_penalty=getattr(d, "repetition_penalty", 1.0),
                                   num_keep_best=int(sp.get("num_keep_best", 1)))
 
-    def forward(self, batch: Mapping[str, Union[torch.Tensor, Sequence[torch.Tensor]]],
-                search_param: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+    def close(self) -> None:
+        """Free the engine contexts (workspaces, KV caches, packed weights) now rather than at garbage collection."""
+        for c in (getattr(self, "_ctxs", None) or [])[1:]:
+            c.close()
+        self._ctxs = None
+        self.engine.close()
+        self._loaded = False
+
+    # ---- several requests in flight (serving / the TSV task) -----------------------------------------------------------------
+    def set_pipeline(self, contexts: int = 4, encoder_chains: int = 2) -> None:
+        """Keep up to `contexts` requests in flight: context i (a clone that borrows the packed weights, gitmi_clone) runs on a
+        HIP stream of its own, so the latency-bound decode steps of one request overlap the MFMA-bound image encoder of the
+        next; at most `encoder_chains` encoders run at a time (gitmi_set_encode_after) -- the schedule bench.py measures.
+        submit() then rotates over the contexts; model(batch) keeps using context 0 synchronously."""
+        if not self._loaded:
+            raise RuntimeError("weights not loaded (call load_state_dict first)")
+        contexts = max(1, int(contexts))
+        if getattr(self, "_ctxs", None) and len(self._ctxs) == contexts:
+            return
+        for c in getattr(self, "_ctxs", [])[1:]:
+            c.close()
+        if contexts > 1:
+            self.engine.set_shared_device(True)          # kernel shapes by whole-device cost (bit-identical results)
+        self._ctxs = [self.engine] + [self.engine.clone() for _ in range(contexts - 1)]
+        self._streams = [torch.cuda.Stream() for _ in self._ctxs]
+        chains = max(1, int(encoder_chains))
+        if len(self._ctxs) > chains:
+            for i, c in enumerate(self._ctxs):
+                c.set_encode_after(self._ctxs[i - chains])
+        self._next = 0
+
+    def _context(self):
+        """-> (engine context, its stream or None) of the next submission"""
+        if not getattr(self, "_ctxs", None):
+            return self.engine, None
+        i = self._next % len(self._ctxs)
+        self._next += 1
+        return self._ctxs[i], self._streams[i]
+
+    def _prepare(self, eng, frames_is_list: bool):
+        eng.set_temporal_embedding(frames_is_list)                          # decoder.py:845-857: list branch only
+        if self.decoder.kind == "trie" and getattr(eng, "_trie_loaded", None) is not self.decoder.trie:
+            eng.set_trie(*self.decoder.trie.csr())
+            eng._trie_loaded = self.decoder.trie
+
+    def submit(self, batch: Mapping[str, Union[torch.Tensor, Sequence[torch.Tensor]]],
+               search_param: Optional[dict] = None) -> "Pending":
+        """Asynchronous model(batch): enqueue the request on the next context's stream and return at once; `.result()` waits
+        for it and returns what model(batch) returns.  The batch's tensors must have been produced on the CURRENT stream (the
+        context's stream waits for it)."""
         if not self._loaded:
             raise RuntimeError("weights not loaded (call load_state_dict first)")
         image = batch["image"]
         is_list = isinstance(image, (list, tuple))
         frames = list(image) if is_list else [image]
-        if self.cfg.num_frames == 0 and len(frames) > self.engine.c.max_frames:
+        eng, stream = self._context()
+        if self.cfg.num_frames == 0 and len(frames) > eng.c.max_frames:
             # the reference concatenates the features of every frame of a list, also on an image model
             raise ValueError(f"{len(frames)} frames on an image model: construct CaptioningModel(..., max_frames="
-                             f"{len(frames)}) (workspaces are sized at construction; now max_frames={self.engine.c.max_frames})")
-        self.engine.set_temporal_embedding(is_list)                       # decoder.py:845-857: list branch only
+                             f"{len(frames)}) (workspaces are sized at construction; now max_frames={eng.c.max_frames})")
+        self._prepare(eng, is_list)
         prefix = batch.get("prefix")
         if prefix is not None:
             assert len(prefix) == 1, "not supported"                       # decoder.py:988
         search = self._search_struct(search_param)
-        if self.decoder.kind == "trie" and getattr(self, "_trie_loaded", None) is not self.decoder.trie:
-            self.engine.set_trie(*self.decoder.trie.csr())
-            self._trie_loaded = self.decoder.trie
         P = 1 if prefix is None else int(prefix.numel())
         nret = int((search_param or {}).get("num_return_sequences", 1))
-        if nret != 1:
-            # decoder.py:1093-1097: every image's start tokens num_return_sequences times -- r sentences per image, each
-            # with its own beams (they differ only when sampling); rows b * r + j, as the reference returns them
-            B = int(frames[0].shape[0])
-            start = [int(self.cfg.sos)] if prefix is None else [int(t) for t in prefix.reshape(-1).tolist()]
-            if B * nret > self.engine.c.max_batch:
-                raise ValueError(f"{B} images x num_return_sequences={nret} exceed max_batch={self.engine.c.max_batch}")
-            tokens, logprobs, _, info = self.engine.generate_prefixed(
-                frames, search, [start] * (B * nret), image_of=[b for b in range(B) for _ in range(nret)])
-        else:
-            tokens, logprobs, info = self.engine.generate(frames, search, prefix=prefix)
-        seq_len, early, _, _ = info.tolist()
-        if self.decoder.kind in ("autoregressive", "trie"):
-            if early:                                                       # decoder.py:279-291 / trie_decoder.py:76-83
-                predictions = tokens[:, P:P + 1]
-                logprobs = logprobs[:, None]
+        kind = self.decoder.kind
+
+        def launch():
+            if nret != 1:
+                # decoder.py:1093-1097: every image's start tokens num_return_sequences times -- r sentences per image, each
+                # with its own beams (they differ only when sampling); rows b * r + j, as the reference returns them
+                B = int(frames[0].shape[0])
+                start = [int(self.cfg.sos)] if prefix is None else [int(t) for t in prefix.reshape(-1).tolist()]
+                if B * nret > eng.c.max_batch:
+                    raise ValueError(f"{B} images x num_return_sequences={nret} exceed max_batch={eng.c.max_batch}")
+                tokens, logprobs, _, info = eng.generate_prefixed(
+                    frames, search, [start] * (B * nret), image_of=[b for b in range(B) for _ in range(nret)], sync=False)
             else:
-                predictions = tokens[:, :seq_len]
-        else:
-            predictions = tokens                                            # [B, T], or [B, num_keep_best, T]
-            if logprobs.dim() == 1:
-                logprobs = logprobs[:, None]                                # [B, num_keep_best]
-        if prefix is not None:
-            predictions = predictions[:, P:]                                # decoder.py:1004-1006 (dim 1, whatever it is)
-        return {"predictions": predictions, "logprobs": logprobs}
+                tokens, logprobs, info = eng.generate(frames, search, prefix=prefix, sync=False)
+            return tokens, logprobs, info
+
+        def finish(out):
+            tokens, logprobs, info = out
+            eng.check_finite(info)
+            seq_len, early, _, _ = info.tolist()
+            if kind in ("autoregressive", "trie"):
+                if early:                                                       # decoder.py:279-291 / trie_decoder.py:76-83
+                    predictions = tokens[:, P:P + 1]
+                    logprobs = logprobs[:, None]
+                else:
+                    predictions = tokens[:, :seq_len]
+            else:
+                predictions = tokens                                            # [B, T], or [B, num_keep_best, T]
+                if logprobs.dim() == 1:
+                    logprobs = logprobs[:, None]                                # [B, num_keep_best]
+            if prefix is not None:
+                predictions = predictions[:, P:]                                # decoder.py:1004-1006 (dim 1, whatever it is)
+            return {"predictions": predictions, "logprobs": logprobs}
+
+        return Pending(stream, launch, finish, keep=(frames, prefix))
+
+    def forward(self, batch: Mapping[str, Union[torch.Tensor, Sequence[torch.Tensor]]],
+                search_param: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+        saved, self._ctxs = getattr(self, "_ctxs", None), None              # model(batch): context 0, the caller's stream
+        try:
+            return self.submit(batch, search_param).result()
+        finally:
+            self._ctxs = saved
 
     __call__ = forward
 
-    def answer(self, image: Union[torch.Tensor, Sequence[torch.Tensor]], prefixes: Sequence[Sequence[int]]):
-        """Several questions about ONE image in one engine call (batched ragged prefixes): each prefix is a list of
-        token ids starting with [CLS].  Returns, per question, the list of predicted token ids exactly as
-        ``model({'image': image, 'prefix': [prefix]})['predictions'][0]`` gives them -- the reference loop of
-        inference.py:172-199 without re-encoding the image per question."""
+    def submit_answers(self, images: Union[torch.Tensor, Sequence[torch.Tensor]], prefixes: Sequence[Sequence[int]],
+                       image_of: Optional[Sequence[int]] = None) -> "Pending":
+        """Questions about SEVERAL images of one resolution in one engine call (batched ragged prefixes): `images` [B,3,H,W]
+        (or a list of frames of that shape), question q = token ids starting with [CLS], about image image_of[q] (default: all
+        about image 0).  `.result()` returns, per question, the list of predicted token ids exactly as
+        ``model({'image': image, 'prefix': [prefix]})['predictions'][0]`` gives them for that image alone -- the reference loop
+        of inference.py:172-199 without re-encoding an image per question and without one call per image."""
         if not self._loaded:
             raise RuntimeError("weights not loaded (call load_state_dict first)")
-        is_list = isinstance(image, (list, tuple))
-        frames = list(image) if is_list else [image]
-        assert frames[0].shape[0] == 1, "answer() takes one image (or one clip)"
-        self.engine.set_temporal_embedding(is_list)
+        is_list = isinstance(images, (list, tuple))
+        frames = list(images) if is_list else [images]
         Q = len(prefixes)
-        if Q > self.engine.c.max_batch:
-            raise ValueError(f"{Q} questions exceed max_batch={self.engine.c.max_batch}")
-        if self.decoder.kind == "trie" and getattr(self, "_trie_loaded", None) is not self.decoder.trie:
-            self.engine.set_trie(*self.decoder.trie.csr())
-            self._trie_loaded = self.decoder.trie
-        tokens, logprobs, sent, info = self.engine.generate_prefixed(frames, self._search_struct(), prefixes,
-                                                                     image_of=[0] * Q)
-        tokens, sent = tokens.cpu(), sent.cpu()
-        out = []
-        for q, p in enumerate(prefixes):
-            P = len(p)
-            L, early = int(sent[q, 0]), int(sent[q, 1])
-            if self.decoder.kind in ("autoregressive", "trie"):
-                row = (tokens[q, P:P + 1] if early else tokens[q, :L])[P:]     # decoder.py:279-291, then :1004-1006
+        image_of = [0] * Q if image_of is None else [int(i) for i in image_of]
+        eng, stream = self._context()
+        if Q > eng.c.max_batch or int(frames[0].shape[0]) > eng.c.max_batch:
+            raise ValueError(f"{Q} questions / {int(frames[0].shape[0])} images exceed max_batch={eng.c.max_batch}")
+        self._prepare(eng, is_list)
+        search = self._search_struct()
+        kind = self.decoder.kind
+
+        def launch():
+            return eng.generate_prefixed(frames, search, prefixes, image_of=image_of, sync=False)
+
+        def finish(out):
+            tokens, logprobs, sent, info = out
+            eng.check_finite(info)
+            tokens, sent = tokens.cpu(), sent.cpu()
+            res = []
+            for q, p in enumerate(prefixes):
+                P = len(p)
+                L, early = int(sent[q, 0]), int(sent[q, 1])
+                if kind in ("autoregressive", "trie"):
+                    row = (tokens[q, P:P + 1] if early else tokens[q, :L])[P:]     # decoder.py:279-291, then :1004-1006
+                else:
+                    row = tokens[q, P:]
+                res.append(row.tolist())
+            return res
+
+        return Pending(stream, launch, finish, keep=(frames,))
+
+    def answer(self, image: Union[torch.Tensor, Sequence[torch.Tensor]], prefixes: Sequence[Sequence[int]]):
+        """Several questions about ONE image in one engine call: submit_answers(...).result() on context 0."""
+        frames = list(image) if isinstance(image, (list, tuple)) else [image]
+        assert frames[0].shape[0] == 1, "answer() takes one image (or one clip)"
+        saved, self._ctxs = getattr(self, "_ctxs", None), None
+        try:
+            return self.submit_answers(image, prefixes).result()
+        finally:
+            self._ctxs = saved
+
+
+class Pending:
+    """A request enqueued on a context's stream (CaptioningModel.submit / submit_answers)."""
+
+    def __init__(self, stream, launch, finish, keep=()):
+        self._finish, self._keep, self._done, self._value = finish, keep, False, None
+        if stream is None:
+            self._out = launch()
+            self._event = None
+        else:
+            stream.wait_stream(torch.cuda.current_stream())          # the inputs were produced on the caller's stream
+            with torch.cuda.stream(stream):
+                self._out = launch()
+                self._event = torch.cuda.Event()
+                self._event.record()
+
+    def result(self):
+        if not self._done:
+            if self._event is not None:
+                self._event.synchronize()
             else:
-                row = tokens[q, P:]
-            out.append(row.tolist())
-        return out
+                torch.cuda.current_stream().synchronize()
+            self._value = self._finish(self._out)
+            self._done, self._out, self._keep = True, None, ()
+        return self._value
 
 
 def get_git_model(tokenizer, param: Optional[dict], precision: str = "f16", max_batch: int = 64,

@@ -589,6 +589,16 @@ def test_task_function_single_tsv(tmp_path, monkeypatch):
         ref = O.caption(cfg, w, [torch.stack(imgs)], O.SearchConfig("greedy", 10, 1, 1), cached=True)
     for r, pred in zip(got, ref["predictions"].tolist()):
         assert json.loads(r[1])[0]["caption"] == I.IdTokenizer().decode(pred)
+    # pipelined (default: 4 contexts in flight, thread-pool decoding) == the serial loop, in the default 16-bit precision too
+    outs = {}
+    for name, kw in (("pipe", dict(contexts=4, batch_size=2)), ("serial", dict(contexts=1, batch_size=1))):
+        st = {}
+        monkeypatch.setenv("GIT_DECODE_THREADS", "4" if name == "pipe" else "0")
+        I.test_git_inference_single_tsv(str(tmp_path / "in.tsv"), "GIT_BASE", None, str(tmp_path / (name + ".tsv")), checkpoint=w,
+                                        stats=st, **kw)
+        assert st["precision"] == "f16" and st["images"] == 5
+        outs[name] = open(str(tmp_path / (name + ".tsv"))).read()
+    assert outs["pipe"] == outs["serial"]
 
 
 def test_task_function_vqa_tsv_variable_resolution(tmp_path, monkeypatch):
@@ -606,8 +616,12 @@ def test_task_function_vqa_tsv_variable_resolution(tmp_path, monkeypatch):
     cfg = dataclasses.replace(O.CONFIGS["GIT_BASE"], name="vqa_small", image_size=160)
     w = O.make_weights(cfg, seed=1241, tie_output=False, eos_bias=0.3)
     rng = np.random.RandomState(6)
-    sizes = [(300, 400), (500, 260), (333, 333)]                     # (h, w): landscape, portrait beyond the ratio cap, square
-    questions = [[("2054 2003 2023", 11)], [("2129 2116", 12), ("2054 3609", 13)], [("2003 2009 1037 4937", 14)]]
+    # (h, w): landscape, portrait beyond the ratio cap, square, and two more of the FIRST shape: images that share a resized
+    # shape are answered in ONE engine call (ragged questions about several images), the others in calls of their own; the
+    # rows still come out in input order
+    sizes = [(300, 400), (500, 260), (333, 333), (300, 400), (300, 400)]
+    questions = [[("2054 2003 2023", 11)], [("2129 2116", 12), ("2054 3609", 13)], [("2003 2009 1037 4937", 14)],
+                 [("2054 2003 2023", 15), ("2129 2116 1996", 16)], [("2003 2009", 17)]]
     img_rows, q_rows, want = [], [], []
     for i, ((h, wd), qs) in enumerate(zip(sizes, questions)):
         im = Image.fromarray(rng.randint(0, 255, (h, wd, 3), dtype=np.uint8))
@@ -634,6 +648,12 @@ def test_task_function_vqa_tsv_variable_resolution(tmp_path, monkeypatch):
     # one-column rows json_dump({"answer", "question_id"}) (inference.py:199), questions of an image answered in ONE engine call
     got = [(json.loads(s)["question_id"], json.loads(s)["answer"]) for s, in tsv_io.tsv_reader(out)]
     assert got == [(qid, ans) for _, qid, ans in want], (got, want)
+    # the serial loop of the reference (one image per call, nothing in flight) writes the same file
+    st = {}
+    out1 = str(tmp_path / "out_serial.tsv")
+    I.test_git_inference_single_tsv(str(tmp_path / "img.tsv"), "GIT_BASE_VQAv2", str(tmp_path / "q.tsv"), out1, checkpoint=w,
+                                    precision="f32", contexts=1, batch_size=1, stats=st)
+    assert open(out1).read() == open(out).read() and st["batches"] == 5 and st["questions"] == 7
 
 
 @pytest.mark.parametrize("kind", ["greedy", "beam"])

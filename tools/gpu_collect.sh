@@ -9,6 +9,7 @@
 #     suite    python -m pytest tests -m gpu -> TAG_pytest_gpu.txt, TAG_parity_measured.jsonl
 #     configs  bench lines of the other BASELINE configurations (beam 4, GIT_LARGE bs 32, VATEX 6 frames bs 16), bf16 and f16 builds
 #     smoke    __graft_entry__.smoke()
+#     attrib   tools/error_attribution.py on the benchmark's, the oracle's and the trained-statistics weights -> TAG_error_attribution_*.txt
 # Everything lands in gpurun_out/ (merged back by gpurun); copy what is cited into profiles/.
 set -u; mkdir -p gpurun_out; export PYTHONUNBUFFERED=1 HSA_ENABLE_IPC_MODE_LEGACY=0
 R=$PWD; TAG=${1:-collect}; shift || true; SECTIONS=${*:-pmc bench stats suite configs smoke}
@@ -36,7 +37,7 @@ stats)
     done ) ;;
 suite)
   rm -f gpurun_out/parity_measured.jsonl
-  t "pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.txt 2>&1; echo "rc=$?"; tail -n 3 gpurun_out/${TAG}_pytest_gpu.txt | cut -c1-250
+  t "pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.txt 2>&1; echo "rc=$?"; tail -n 3 gpurun_out/${TAG}_pytest_gpu.txt | cut -c1-250
   cp gpurun_out/parity_measured.jsonl gpurun_out/${TAG}_parity_measured.jsonl 2>/dev/null ;;
 configs)
   for c in "beam4:--search beam" "large_b32:--model GIT_LARGE --batch 32" "vatex_b16:--model GIT_BASE_VATEX --frames 6 --batch 16"; do
@@ -48,6 +49,11 @@ configs)
   t "base f16"; timeout 300 python bench.py --no-cpu-baseline --precision f16 > gpurun_out/${TAG}_base_f16_bench.json 2> /dev/null; line gpurun_out/${TAG}_base_f16_bench.json ;;
 smoke)
   t smoke; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.txt 2>&1; echo "rc=$?"; tail -n 2 gpurun_out/${TAG}_smoke.txt | cut -c1-200 ;;
+attrib)
+  for wt in bench oracle trained; do
+    t "error attribution: $wt weights"; timeout 300 python tools/error_attribution.py --weights $wt --out gpurun_out/${TAG}_error_attribution_$wt.txt > gpurun_out/${TAG}_attrib_$wt.log 2>&1; echo "rc=$?"
+    cat gpurun_out/${TAG}_error_attribution_$wt.txt | cut -c1-170
+  done ;;
 *) echo "unknown section $sec" ;;
 esac; done
 t done
