@@ -170,6 +170,26 @@ extern "C" int gitmi_preprocess_image(const uint8_t* rgb_hwc, int H, int W, int 
     return 0;
 }
 
+// a batch of decoded images in one staging buffer (include/gitmi.h)
+extern "C" int gitmi_preprocess_batch(const uint8_t* rgb, size_t rgb_bytes, const int64_t* desc_host, int n, int crop, uint8_t* tmp,
+                                      size_t tmp_bytes, float* out, void* stream) {
+    if (!rgb || !desc_host || !out || n < 1 || crop < 1 || crop > 4096) return fail("preprocess_batch: bad argument");
+    for (int i = 0; i < n; ++i) {
+        const int64_t off = desc_host[3 * i], H = desc_host[3 * i + 1], W = desc_host[3 * i + 2];
+        if (H < 1 || W < 1 || H > 65535 || W > 65535 || off < 0 || (uint64_t)off + (uint64_t)H * W * 3 > rgb_bytes ||
+            (uint64_t)off + (uint64_t)H * W * 3 > 0xffffffffull)
+            return fail("preprocess_batch: image %d (offset %lld, %lld x %lld) does not fit the staging buffer of %zu bytes", i,
+                        (long long)off, (long long)H, (long long)W, rgb_bytes);
+        const double r = W <= H ? (double)H / W : (double)W / H;
+        if (r * crop > 65535.0) return fail("preprocess_batch: image %d: aspect ratio too extreme", i);
+    }
+    const size_t need = preprocess_batch_workspace((const long long*)desc_host, n, crop);
+    if (need > 0 && (!tmp || tmp_bytes < need)) return fail("preprocess_batch: workspace must hold %zu bytes", need);
+    if (need > 0xffffffffull) return fail("preprocess_batch: batch too large for one call");
+    HIPCK(launch_preprocess_batch(rgb, (const long long*)desc_host, n, crop, tmp, out, (hipStream_t)stream));
+    return 0;
+}
+
 // MinMaxResizeForTest (inference.py:29-64) output: a plain resize to out_h x out_w (no crop) + ToTensor + Normalize.
 // The caller computes (out_h, out_w) with the reference's get_size() rule (generativeimage2text_amd/inference.py).
 extern "C" int gitmi_preprocess_image_to(const uint8_t* rgb_hwc, int H, int W, int out_h, int out_w, uint8_t* tmp,

@@ -169,6 +169,131 @@ hipError_t launch_resize_crop_norm(const uint8_t* rgb, int H, int W, int nh, int
     return hipGetLastError();
 }
 
+// ---- a BATCH of decoded images of any sizes in one staging buffer -> [n, 3, crop, crop] ---------------------------------------
+// At serving rates (~10k images/s per GPU) the per-image form costs the host more than the device: two launches, two
+// allocations and one upload per image on the submitting thread.  Here the decoded images of a batch lie behind each other in ONE
+// buffer (one upload), and the two passes run as ONE launch pair per chunk of PRE_CHUNK images: the per-image geometry and
+// coefficient tables travel in the kernel arguments (no descriptor upload, nothing whose lifetime the caller must manage).
+// Same arithmetic, instruction for instruction, as the per-image kernels above.
+namespace {
+constexpr int PRE_CHUNK = 24;
+struct ImgDesc {
+    const int* kk_h; const int* b_h; const int* kk_v; const int* b_v;
+    unsigned int src_off, tmp_off;                     // bytes into the staging buffer / the workspace
+    unsigned short H, W, nw, top, left, ks_h, ks_v, flags;   // flags: 1 = no horizontal pass, 2 = no vertical pass
+};
+struct ImgChunk { ImgDesc d[PRE_CHUNK]; };
+
+__global__ void resize_h_batch_kernel(const uint8_t* __restrict__ base, uint8_t* __restrict__ tmp, ImgChunk c) {
+    const ImgDesc& d = c.d[blockIdx.z];
+    const int xo = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if ((d.flags & 1) || xo >= d.nw || y >= d.H) return;
+    const int xmin = d.b_h[2 * xo], xmax = d.b_h[2 * xo + 1];
+    const int* k = d.kk_h + (size_t)xo * d.ks_h;
+    const uint8_t* row = base + d.src_off + ((size_t)y * d.W + xmin) * 3;
+    int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    for (int x = 0; x < xmax; ++x) {
+        const int cf = k[x];
+        s0 += row[3 * x] * cf;
+        s1 += row[3 * x + 1] * cf;
+        s2 += row[3 * x + 2] * cf;
+    }
+    uint8_t* o = tmp + d.tmp_off + ((size_t)y * d.nw + xo) * 3;
+    o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
+}
+
+__global__ void resize_v_crop_norm_batch_kernel(const uint8_t* __restrict__ base, const uint8_t* __restrict__ tmp,
+                                                float* __restrict__ out, int crop, ImgChunk c, float m0, float m1, float m2,
+                                                float d0, float d1, float d2) {
+    const ImgDesc& d = c.d[blockIdx.z];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= crop) return;
+    const uint8_t* in = (d.flags & 1) ? base + d.src_off : tmp + d.tmp_off;      // Pillow skips a pass whose size does not change
+    const int yo = y + d.top, xi = x + d.left, W = d.nw;
+    int p0, p1, p2;
+    if (d.flags & 2) {
+        const uint8_t* px = in + ((size_t)yo * W + xi) * 3;
+        p0 = px[0]; p1 = px[1]; p2 = px[2];
+    } else {
+        const int ymin = d.b_v[2 * yo], ymax = d.b_v[2 * yo + 1];
+        const int* k = d.kk_v + (size_t)yo * d.ks_v;
+        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        for (int t = 0; t < ymax; ++t) {
+            const uint8_t* px = in + ((size_t)(ymin + t) * W + xi) * 3;
+            const int cf = k[t];
+            s0 += px[0] * cf;
+            s1 += px[1] * cf;
+            s2 += px[2] * cf;
+        }
+        p0 = clip8(s0); p1 = clip8(s1); p2 = clip8(s2);
+    }
+    const size_t plane = (size_t)crop * crop, o = (size_t)blockIdx.z * 3 * plane + (size_t)y * crop + x;
+    out[o] = ((float)p0 / 255.0f - m0) / d0;
+    out[plane + o] = ((float)p1 / 255.0f - m1) / d1;
+    out[2 * plane + o] = ((float)p2 / 255.0f - m2) / d2;
+}
+}  // namespace
+
+// workspace bytes the horizontal passes of a batch need: sum of H_i * nw_i * 3 (64-byte aligned each)
+size_t preprocess_batch_workspace(const long long* desc, int n, int crop) {
+    size_t t = 0;
+    for (int i = 0; i < n; ++i) {
+        const int H = (int)desc[3 * i + 1], W = (int)desc[3 * i + 2];
+        const int nw = W <= H ? crop : (int)((double)crop * W / H);
+        if (nw != W) t += ((size_t)H * nw * 3 + 63) / 64 * 64;
+    }
+    return t;
+}
+
+// desc: HOST int64 [n][3] = (byte offset of image i in `rgb`, H, W).  out: fp32 [n, 3, crop, crop].
+hipError_t launch_preprocess_batch(const uint8_t* rgb, const long long* desc, int n, int crop, uint8_t* tmp, float* out,
+                                   hipStream_t s) {
+    auto pyround = [](double v) { return (int)std::nearbyint(v); };
+    size_t tmp_off = 0;
+    for (int c0 = 0; c0 < n; c0 += PRE_CHUNK) {
+        const int nc = n - c0 < PRE_CHUNK ? n - c0 : PRE_CHUNK;
+        ImgChunk ch;
+        int maxH = 1, maxnw = 1;
+        bool any_h = false;
+        for (int i = 0; i < nc; ++i) {
+            const long long off = desc[3 * (c0 + i)];
+            const int H = (int)desc[3 * (c0 + i) + 1], W = (int)desc[3 * (c0 + i) + 2];
+            int nw, nh;
+            if (W <= H) { nw = crop; nh = (int)((double)crop * H / W); }
+            else { nw = (int)((double)crop * W / H); nh = crop; }
+            ImgDesc& d = ch.d[i];
+            d = ImgDesc{};
+            d.src_off = (unsigned int)off;
+            d.H = (unsigned short)H; d.W = (unsigned short)W; d.nw = (unsigned short)nw;
+            d.left = (unsigned short)pyround((nw - crop) / 2.0);
+            d.top = (unsigned short)pyround((nh - crop) / 2.0);
+            if (nw != W) {
+                Coeffs k;
+                hipError_t e = get_coeffs(W, nw, &k);
+                if (e != hipSuccess) return e;
+                d.kk_h = k.kk; d.b_h = k.bounds; d.ks_h = (unsigned short)k.ksize;
+                d.tmp_off = (unsigned int)tmp_off;
+                tmp_off += ((size_t)H * nw * 3 + 63) / 64 * 64;
+                any_h = true;
+                if (H > maxH) maxH = H;
+                if (nw > maxnw) maxnw = nw;
+            } else d.flags |= 1;
+            if (nh != H) {
+                Coeffs k;
+                hipError_t e = get_coeffs(H, nh, &k);
+                if (e != hipSuccess) return e;
+                d.kk_v = k.kk; d.b_v = k.bounds; d.ks_v = (unsigned short)k.ksize;
+            } else d.flags |= 2;
+        }
+        if (any_h)
+            hipLaunchKernelGGL(resize_h_batch_kernel, dim3((maxnw + 127) / 128, maxH, nc), dim3(128), 0, s, rgb, tmp, ch);
+        hipLaunchKernelGGL(resize_v_crop_norm_batch_kernel, dim3((crop + 127) / 128, crop, nc), dim3(128), 0, s, rgb, tmp,
+                           out + (size_t)c0 * 3 * crop * crop, crop, ch, 0.48145466f, 0.4578275f, 0.40821073f, 0.26862954f,
+                           0.26130258f, 0.27577711f);
+    }
+    return hipGetLastError();
+}
+
 // Resize(crop, BICUBIC) -> CenterCrop(crop) -> ToTensor -> Normalize (inference.py:118-131)
 hipError_t launch_preprocess(const uint8_t* rgb, int H, int W, int crop, uint8_t* tmp, float* out, hipStream_t s) {
     // torchvision Resize(int): shorter side -> crop, the other int(crop * long / short)

@@ -189,6 +189,9 @@ hipError_t launch_load_ids(const long long* tokens, int R, int t, int* ids, int*
 
 // GPU image transform (Pillow-exact bicubic resize + centre crop + CLIP normalisation)
 hipError_t launch_preprocess(const unsigned char* rgb, int H, int W, int crop, unsigned char* tmp, float* out, hipStream_t s);
+hipError_t launch_preprocess_batch(const unsigned char* rgb, const long long* desc, int n, int crop, unsigned char* tmp, float* out,
+                                   hipStream_t s);
+size_t preprocess_batch_workspace(const long long* desc, int n, int crop);
 hipError_t launch_resize_crop_norm(const uint8_t* rgb, int H, int W, int nh, int nw, int top, int left, int ch, int cw,
                                    uint8_t* tmp, float* out, hipStream_t s);
 

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_op_gemm", "gitmi_op_layernorm", "gitmi_op_attention", "gitmi_op_dgemm", "gitmi_op_dgemm_res",
     "gitmi_op_vocab_topm", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
     "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after", "gitmi_op_sample_rows",
-    "gitmi_search_done_count", "gitmi_set_trie", "gitmi_operand_dtype", "gitmi_set_shared_device",
+    "gitmi_search_done_count", "gitmi_set_trie", "gitmi_operand_dtype", "gitmi_set_shared_device", "gitmi_preprocess_batch",
 ]
 # libgitmi_exp.so only (include/gitmi_experiment.h): schedules that measured slower than the default, debug hooks
 EXPERIMENT_SYMBOLS = [
@@ -128,6 +128,7 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     lib.gitmi_clone.argtypes = [vp, C.POINTER(vp)]
     lib.gitmi_preprocess_image.argtypes = [vp, i32, i32, i32, vp, C.c_size_t, vp, vp]
     lib.gitmi_preprocess_image_to.argtypes = [vp, i32, i32, i32, i32, vp, C.c_size_t, vp, vp]
+    lib.gitmi_preprocess_batch.argtypes = [vp, C.c_size_t, i64p, i32, i32, vp, C.c_size_t, vp, vp]
     lib.gitmi_set_image_shape.argtypes = [vp, i32, i32, vp]
     lib.gitmi_op_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_kv_repack.argtypes = [vp, vp, vp, i32, i32, i32, vp]
@@ -140,7 +141,7 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     for name in EXPORTED_SYMBOLS + (EXPERIMENT_SYMBOLS if operands == "exp" else []):
         if name not in ("gitmi_last_error", "gitmi_destroy"):
             getattr(lib, name).restype = C.c_int
-    if lib.gitmi_abi_version() != 7:
+    if lib.gitmi_abi_version() != 8:
         raise GitmiError("libgitmi.so ABI version mismatch")
     lib.gitmi_operand_dtype.restype = C.c_int
     if lib.gitmi_operand_dtype() != {"bf16": DTYPE_BF16, "f16": DTYPE_F16, "exp": DTYPE_BF16}[operands]:
@@ -704,4 +705,24 @@ def preprocess_image_to(rgb_hwc: torch.Tensor, out_h: int, out_w: int) -> torch.
     out = torch.empty(3, out_h, out_w, dtype=torch.float32, device=rgb_hwc.device)
     _ck(lib.gitmi_preprocess_image_to(rgb_hwc.data_ptr(), H, W, int(out_h), int(out_w), tmp.data_ptr(), tmp.numel(),
                                       out.data_ptr(), _stream()), lib)
+    return out
+
+
+def preprocess_batch(staging: torch.Tensor, desc: Sequence[Tuple[int, int, int]], crop: int = 224) -> torch.Tensor:
+    """A batch of decoded images in ONE uint8 device buffer -> fp32 [n, 3, crop, crop] (gitmi_preprocess_batch: the reference's
+    Resize(BICUBIC) -> CenterCrop -> ToTensor -> Normalize, bit-exact with Pillow, one launch pair per 24 images).
+    desc: (byte offset, H, W) of every image in `staging`."""
+    lib = load_library()
+    assert staging.is_cuda and staging.dtype == torch.uint8 and staging.is_contiguous()
+    n = len(desc)
+    table = (C.c_int64 * (3 * n))(*[int(v) for d in desc for v in d])
+    need = 0
+    for _, H, W in desc:
+        nw = crop if W <= H else int(crop * W / H)
+        if nw != W:
+            need += (H * nw * 3 + 63) // 64 * 64
+    tmp = torch.empty(max(need, 64), dtype=torch.uint8, device=staging.device)
+    out = torch.empty(n, 3, crop, crop, dtype=torch.float32, device=staging.device)
+    _ck(lib.gitmi_preprocess_batch(staging.data_ptr(), staging.numel(), table, n, int(crop), tmp.data_ptr(), tmp.numel(),
+                                   out.data_ptr(), _stream()), lib)
     return out

@@ -16,7 +16,8 @@ Differences forced by the environment, not by design:
     logit tolerance (1e-3 of the logit span) on every weight family incl. trained-checkpoint statistics, and the one bench.py's
     headline measures.  "f32" = token ids bit-identical to the reference's fp32 run; "bf16" = BASELINE.json's named operand
     format (+2 % captions/s, 5e-3 of the span on trained-like weights).  Environment read by this module (and by nothing in the
-    shared libraries): GIT_VOCAB (vocabulary file or "ids"), GIT_DECODE_THREADS (host JPEG-decode threads of the TSV task), the
+    shared libraries): GIT_VOCAB (vocabulary file or "ids"), GIT_DECODE_THREADS / GIT_DECODE_PROCS / GIT_DECODE_SLOT_MB (host JPEG decoding of the TSV task: threads of the
+    per-image path, worker processes and slot size of the pooled captioning path), the
     launcher's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (and OMPI_COMM_WORLD_*).
 """
 from __future__ import annotations
@@ -355,7 +356,7 @@ def prefetch_ordered(n: int, load, threads: int, window: int):
 def run_tsv_inference(image_tsv: str, question_tsv: Optional[str], out_tsv: str, *, transform, caption_batch,
                       answer_questions, batch_size: int, rank: Optional[int] = None, world: Optional[int] = None,
                       poll_s: float = 0.2, decode=None, decode_threads: int = 0, submit_captions=None, submit_answers=None,
-                      in_flight: int = 1, stats: Optional[dict] = None) -> None:
+                      in_flight: int = 1, stats: Optional[dict] = None, batch_source=None) -> None:
     """Everything of test_git_inference_single_tsv (inference.py:134-225) except the model: shard the rows by
     rank (:165-169), write this rank's rows, and deliver the complete, ordered `out_tsv` on rank 0 --
     through ONE RCCL gather when a process group exists or can be formed, else through the reference's
@@ -371,6 +372,8 @@ def run_tsv_inference(image_tsv: str, question_tsv: Optional[str], out_tsv: str,
       submit_answers (optional): (list of same-shape images, list of question lists) -> handle whose .result() is one answer
       list per image; images are bucketed BY SHAPE (aspect-preserving resize: a COCO-style set has two or three shapes) up to
       `batch_size` images or questions per call instead of one call per image; rows are written in input order.
+      batch_source (optional, captioning only): callable(start, end) -> iterator of (keys, device batch) in input order,
+      replacing the decode / transform loop of this function (pooled_caption_batches: worker processes + batched GPU transform).
     Row formats are the reference's: `key \t json_dump([{"caption": ...}])` (:212) and the ONE-column
     `json_dump({"answer": ..., "question_id": ...})` (:199) that convert_tsv_to_vqa_json (:227-229) reads."""
     import collections
@@ -429,6 +432,12 @@ def run_tsv_inference(image_tsv: str, question_tsv: Optional[str], out_tsv: str,
         vqa_pending.append((idxs, submit_answers(imgs, qs)))
         vqa_drain(max(0, in_flight - 1))
 
+    if batch_source is not None and questions is None:
+        for bkeys, batch in batch_source(start, end):
+            if stats is not None:
+                stats["images"] += len(bkeys)
+            flush(bkeys, batch)
+        start = end                                 # nothing left for the per-image loop below
     keys, imgs = [], []
     for j, (key, item) in enumerate(prefetch_ordered(end - start, load, decode_threads if decode is not None else 0,
                                                      window=max(2 * batch_size, 8))):
@@ -483,6 +492,83 @@ def run_tsv_inference(image_tsv: str, question_tsv: Optional[str], out_tsv: str,
         _wait_and_concat_shards(out_tsv, world, poll_s=poll_s)
 
 
+def pooled_caption_batches(image_tsv: str, start: int, end: int, batch_size: int, procs: int, crop: int, in_flight: int,
+                           slot_bytes: int = 2 << 20, stats: Optional[dict] = None):
+    """The host side of the captioning task at the engine's rate: rows [start, end) of `image_tsv` as (keys, fp32 batch
+    [n, 3, crop, crop] on the device) in input order.  `procs` worker processes decode straight into a shared staging buffer
+    (decode_pool.DecodePool), `in_flight + 2` batches of slots deep; a finished batch is uploaded image by image into ONE
+    device buffer (only the bytes used) and transformed by ONE launch pair per 24 images (gitmi_preprocess_batch) --
+    bit-identical to load_image_by_pil + gpu_image_transform per image."""
+    from .decode_pool import DecodePool
+    from .engine import preprocess_batch
+    ring = max(2, in_flight) + 2
+    n_rows = end - start
+    n_batches = (n_rows + batch_size - 1) // batch_size
+    pool = DecodePool(image_tsv, procs, slots=ring * batch_size, slot_bytes=slot_bytes)
+    host = torch.from_numpy(pool.buffer)
+    pinned = False
+    try:                                            # page-lock the staging buffer: uploads become asynchronous DMA
+        pinned = int(torch.cuda.cudart().cudaHostRegister(host.data_ptr(), host.numel(), 0)) == 0
+    except Exception:
+        pinned = False
+    if stats is not None:
+        stats.update(decode_procs=procs, staging_pinned=pinned, staging_mb=host.numel() >> 20)
+    tsv = None
+    try:
+        meta = {}                                   # batch -> {position: (key, H, W)}
+        uploaded = {}                               # ring buffer -> event after its last upload
+        dispatched = 0
+
+        def rows_of(b):
+            return range(b * batch_size, min((b + 1) * batch_size, n_rows))
+
+        for b in range(n_batches):
+            while dispatched < n_batches and dispatched < b + ring - 1:
+                ev = uploaded.pop(dispatched % ring, None)
+                if ev is not None:
+                    ev.synchronize()                # the slots are free once the previous occupant has been uploaded
+                for r in rows_of(dispatched):
+                    pool.submit((dispatched % ring) * batch_size + r % batch_size, start + r)
+                meta[dispatched] = {}
+                dispatched += 1
+            want = len(rows_of(b))
+            while len(meta[b]) < want:
+                slot, row, key, h, w = pool.next_result()
+                r = row - start
+                meta[r // batch_size][r % batch_size] = (key, h, w, slot)
+            items = [meta[b][j] for j in range(want)]
+            del meta[b]
+            sizes = [abs(h) * abs(w) * 3 for _, h, w, _ in items]
+            offs = [0]
+            for n in sizes:
+                offs.append(offs[-1] + (n + 63) // 64 * 64)
+            dev = torch.empty(offs[-1], dtype=torch.uint8, device="cuda")
+            desc = []
+            for j, (key, h, w, slot) in enumerate(items):
+                if h < 0:                           # did not fit its slot: decoded here (rare; GIT_DECODE_SLOT_MB raises the size)
+                    if tsv is None:
+                        tsv = TSVFile(image_tsv)
+                    arr = decode_to_array(base64.b64decode(tsv[start + b * batch_size + j][1]))
+                    h, w = arr.shape[0], arr.shape[1]
+                    dev[offs[j]: offs[j] + sizes[j]].copy_(torch.from_numpy(arr).reshape(-1), non_blocking=False)
+                else:
+                    dev[offs[j]: offs[j] + sizes[j]].copy_(host[slot * slot_bytes: slot * slot_bytes + sizes[j]], non_blocking=True)
+                desc.append((offs[j], h, w))
+            ev = torch.cuda.Event()
+            ev.record()
+            uploaded[b % ring] = ev
+            yield [it[0] for it in items], preprocess_batch(dev, desc, crop)
+    finally:
+        if pinned:
+            try:
+                torch.cuda.synchronize()
+                torch.cuda.cudart().cudaHostUnregister(host.data_ptr())
+            except Exception:
+                pass
+        del host
+        pool.close()
+
+
 class _Mapped:
     """handle.result() post-processed (token ids -> strings)"""
 
@@ -522,14 +608,17 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
     def decode_ids(preds) -> List[str]:
         return [tokenizer.decode(pred, skip_special_tokens=True) for pred in preds]
 
+    def as_batch(imgs):
+        return imgs.cuda() if isinstance(imgs, torch.Tensor) else torch.stack(list(imgs)).cuda()
+
     def caption_batch(imgs: Sequence[torch.Tensor]) -> List[str]:
         with torch.no_grad():
-            res = model({"image": torch.stack(list(imgs)).cuda()})
+            res = model({"image": as_batch(imgs)})
         return decode_ids(res["predictions"].tolist())
 
     def submit_captions(imgs: Sequence[torch.Tensor]):
         with torch.no_grad():
-            h = model.submit({"image": torch.stack(list(imgs)).cuda()})
+            h = model.submit({"image": as_batch(imgs)})
         return _Mapped(h, lambda res: decode_ids(res["predictions"].tolist()))
 
     def answer_questions(img: torch.Tensor, qs: Sequence[str]) -> List[str]:
@@ -563,6 +652,16 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
     # the reference); the transform itself (upload + resize kernels) stays on this thread and this device
     threads = int(os.environ.get("GIT_DECODE_THREADS", str(min(16, os.cpu_count() or 1))))
     can_batch_vqa = hasattr(model, "submit_answers")
+    # captioning on the engine: worker PROCESSES decode into a shared staging buffer, one upload + one launch pair per batch
+    # (GIT_DECODE_PROCS, default min(24, cores / 2); 0 = the thread pool above).  Aspect-preserving models and VQA keep the
+    # per-image path (every image has its own output shape).
+    procs = int(os.environ.get("GIT_DECODE_PROCS", str(min(24, max(1, (os.cpu_count() or 2) // 2)))))
+    batch_source = None
+    if procs > 0 and not is_vqa and "test_respect_ratio_max" not in param and hasattr(model, "engine"):
+        crop = int(param.get("test_crop_size", 224))
+        slot = int(os.environ.get("GIT_DECODE_SLOT_MB", "2")) << 20
+        batch_source = lambda s_, e_: pooled_caption_batches(image_tsv, s_, e_, batch_size, procs, crop,
+                                                             contexts if pipelined else 1, slot_bytes=slot, stats=stats)
     t_run = time.perf_counter()
     # decode on the pool all the way to the uint8 array the GPU transform uploads (stand-in models of the CPU tests keep PIL images)
     decode = decode_to_array if hasattr(model, "engine") else load_image_by_pil
@@ -570,7 +669,7 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
                       transform=transforms, caption_batch=caption_batch, answer_questions=answer_questions,
                       batch_size=batch_size, submit_captions=submit_captions if pipelined else None,
                       submit_answers=submit_answers if (can_batch_vqa and is_vqa) else None,
-                      in_flight=contexts if pipelined else 1, stats=stats)
+                      in_flight=contexts if pipelined else 1, stats=stats, batch_source=batch_source)
     if stats is not None:
         stats.update(build_s=t_run - t_build, run_s=time.perf_counter() - t_run, decode_threads=threads,
                      contexts=contexts if pipelined else 1, precision=precision, batch_size=batch_size)

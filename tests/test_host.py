@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(engine.EXPORTED_SYMBOLS) == declared
-    assert lib.gitmi_abi_version() == 7
+    assert lib.gitmi_abi_version() == 8
     assert len(declared) <= 40                  # the product ABI stays small: schedules that lost and debug hooks live elsewhere
 
 
@@ -365,7 +365,7 @@ def test_both_operand_builds_load_and_identify_themselves():
     same ABI, every declared symbol, and each says which 16-bit operand type it was built for."""
     a, b = engine.load_library("bf16"), engine.load_library("f16")
     assert a.gitmi_operand_dtype() == engine.DTYPE_BF16 and b.gitmi_operand_dtype() == engine.DTYPE_F16
-    assert a.gitmi_abi_version() == b.gitmi_abi_version() == 7
+    assert a.gitmi_abi_version() == b.gitmi_abi_version() == 8
     for name in engine.EXPORTED_SYMBOLS:
         getattr(b, name)
 
@@ -820,3 +820,45 @@ def test_teacher_forced_parity_counts_and_violations():
         assert P.tf_bounds("f16", span)["thr"] == pytest.approx(2e-3 * span)      # ONE constant for every fixture
         if name.startswith("full_trained"):          # every margin >= 2 x the headline build's bound: identity is REQUIRED
             assert P.identity_required("f16", span, float(g["step_margin"].min())), name
+
+
+def test_decode_pool_writes_the_pixels_pil_decodes(tmp_path):
+    """decode_pool.DecodePool (the host side of the TSV task at the engine's rate): spawned worker processes read their rows from
+    the TSV themselves, decode (PNG and JPEG) and write the RGB pixels into the shared staging buffer slot the parent named;
+    the parent sees exactly the array load_image_by_pil gives.  An image larger than a slot comes back flagged (negative
+    size) for the parent to decode itself; a row that cannot be decoded raises in the parent instead of hanging it."""
+    from PIL import Image
+    from generativeimage2text_amd.decode_pool import DecodePool
+    rng = np.random.RandomState(4)
+    rows, arrays = [], []
+    for i in range(11):
+        h, w = 40 + 7 * i, 90 - 3 * i
+        arr = rng.randint(0, 255, (h, w, 3), dtype=np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(arr).save(buf, format="PNG" if i % 2 else "JPEG", quality=90)
+        rows.append(["k%d" % i, base64.b64encode(buf.getvalue()).decode()])
+        arrays.append(np.asarray(inference.load_image_by_pil(buf.getvalue())))
+    rows.append(["broken", base64.b64encode(b"not an image").decode()])
+    tsv_io.tsv_writer(rows, str(tmp_path / "img.tsv"))
+    slot_bytes = 6000 * 3                                       # the four largest images (> 6000 pixels) do not fit
+    pool = DecodePool(str(tmp_path / "img.tsv"), workers=3, slots=11, slot_bytes=slot_bytes)
+    try:
+        for i in range(11):
+            pool.submit(slot=(i * 4) % 11, row=i)               # any slot order
+        seen = {}
+        for _ in range(11):
+            slot, row, key, h, w = pool.next_result(timeout=60)
+            assert key == "k%d" % row and slot == (row * 4) % 11
+            seen[row] = (h, w)
+            if h > 0:
+                got = pool.buffer[slot * slot_bytes: slot * slot_bytes + h * w * 3].reshape(h, w, 3)
+                assert np.array_equal(got, arrays[row]), row
+        assert sorted(seen) == list(range(11))
+        too_big = [r for r, (h, w) in seen.items() if h < 0]
+        assert too_big == [r for r in range(11) if arrays[r].size > slot_bytes] and len(too_big) >= 1
+        assert all((-seen[r][0], -seen[r][1]) == arrays[r].shape[:2] for r in too_big)
+        pool.submit(slot=0, row=11)
+        with pytest.raises(RuntimeError, match="row 11"):
+            pool.next_result(timeout=60)
+    finally:
+        pool.close()

@@ -71,3 +71,30 @@ def test_gpu_minmax_transform_bit_exact(h, w, mn, mx):
     got = I.gpu_minmax_image_transform(img, mn, mx).cpu()
     assert got.shape == ref.shape
     assert torch.equal(got, ref), (got - ref).abs().max()
+
+
+@pytest.mark.gpu
+def test_gpu_batch_transform_bit_exact_with_the_reference_transform():
+    """gitmi_preprocess_batch: the decoded images of a batch, of ANY sizes, behind each other in ONE device buffer -> one launch
+    pair per 24 images.  Every image must come out float for float as the reference's PIL + torch transform gives it (and
+    therefore as the per-image kernels do): landscape, portrait, no-resize, one-pass-only and tiny images, more images than
+    one launch chunk holds, unaligned offsets."""
+    from generativeimage2text_amd import engine as E, inference as I
+    rng = np.random.RandomState(3)
+    sizes = SIZES + [(224, 300), (300, 224), (480, 640)] * 6 + [(225, 224), (64, 64)]          # 29 images: two launch chunks
+    imgs = [rng.randint(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    offs, total = [], 0
+    for im in imgs:
+        offs.append(total)
+        total += im.size + 7                       # deliberately unaligned
+    host = np.zeros(total, dtype=np.uint8)
+    for o, im in zip(offs, imgs):
+        host[o:o + im.size] = im.reshape(-1)
+    out = E.preprocess_batch(torch.from_numpy(host).cuda(), [(o, im.shape[0], im.shape[1]) for o, im in zip(offs, imgs)], 224).cpu()
+    assert out.shape == (len(imgs), 3, 224, 224)
+    for i, im in enumerate(imgs):
+        ref = I.image_transform(Image.fromarray(im), 224)
+        assert torch.equal(out[i], ref), (i, im.shape, (out[i] - ref).abs().max())
+    # an image that does not lie inside the staging buffer is refused, not read
+    with pytest.raises(E.GitmiError, match="does not fit the staging buffer"):
+        E.preprocess_batch(torch.from_numpy(host).cuda(), [(total - 10, 64, 64)], 224)

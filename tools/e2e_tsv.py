@@ -12,7 +12,7 @@ synthetic 640x480 JPEG rows, GIT_BASE, random-init weights, the id-passthrough t
     threads one GPU needs; plus the check that the pipelined task writes exactly the rows the serial one-image-per-call path
     (contexts = 1, batch_size = 1, no decode threads: the reference's loop) writes.
 
-    python tools/e2e_tsv.py [--rows 2048] [--threads 8,16,32,64] [--precision f16] [--out profiles/rNN_e2e_tsv.json]
+    python tools/e2e_tsv.py [--rows 2048] [--procs 8,16,32,48] [--threads 16] [--precision f16] [--out profiles/rNN_e2e_tsv.json]
     python bench.py --e2e-tsv 2048
 """
 from __future__ import annotations
@@ -52,7 +52,8 @@ def make_jpeg_rows(n_rows: int, distinct: int = 128, seed: int = 0):
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=2048)
-    ap.add_argument("--threads", default="8,16,32,64")
+    ap.add_argument("--procs", default="8,16,32,48", help="worker-process counts of the pooled path (GIT_DECODE_PROCS)")
+    ap.add_argument("--threads", default="16", help="thread counts of the per-image thread-pool path (GIT_DECODE_PROCS=0)")
     ap.add_argument("--precision", default="f16")
     ap.add_argument("--contexts", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64)
@@ -66,7 +67,9 @@ def main(argv=None):
     from generativeimage2text_amd.synthetic import random_state_dict
 
     cfg = config_for_model("GIT_BASE")
-    weights = random_state_dict(cfg, seed=1234)
+    # the wide-margin weight family (tests/golden/full_wide_*): decisions are decidable for a 16-bit pipeline, so "the pipelined
+    # task writes the rows the serial path writes" is a meaningful check; throughput does not depend on the weights' values
+    weights = random_state_dict(cfg, seed=1250, successor=1.0)
     real_build = I.build_model
     # BASELINE's workload: greedy, max_len 20 (the task's shipped default is beam 4 / 1024 steps: model.py:34-40)
     I.build_model = lambda name, tok, c, **kw: real_build(
@@ -85,28 +88,32 @@ def main(argv=None):
 
     runs = []
     out_first = None
-    for th in [int(t) for t in args.threads.split(",")]:
-        os.environ["GIT_DECODE_THREADS"] = str(th)
+    settings = [("procs", int(t)) for t in args.procs.split(",") if t] + [("threads", int(t)) for t in args.threads.split(",") if t]
+    for kind, n in settings:
+        os.environ["GIT_DECODE_PROCS"] = str(n) if kind == "procs" else "0"
+        os.environ["GIT_DECODE_THREADS"] = str(n) if kind == "threads" else "16"
         st = {}
-        out = os.path.join(tmp, "out_%d.tsv" % th)
+        out = os.path.join(tmp, "out_%s_%d.tsv" % (kind, n))
         I.test_git_inference_single_tsv(in_tsv, "GIT_BASE", None, out, checkpoint=weights, batch_size=args.batch,
                                         precision=args.precision, contexts=args.contexts, stats=st)
-        runs.append({"decode_threads": th, "captions_per_s": round(st["images"] / st["run_s"], 1), "run_s": round(st["run_s"], 3),
-                     "build_s": round(st["build_s"], 2), "batches": st["batches"]})
-        print("threads %3d: %.1f captions/s end to end (%.2f s for %d rows)" % (th, runs[-1]["captions_per_s"], st["run_s"],
-                                                                               st["images"]), file=sys.stderr, flush=True)
+        runs.append({"host_path": "worker processes + batched GPU transform" if kind == "procs" else "thread pool + per-image GPU transform",
+                     kind: n, "captions_per_s": round(st["images"] / st["run_s"], 1), "run_s": round(st["run_s"], 3),
+                     "build_s": round(st["build_s"], 2), "batches": st["batches"], "staging_pinned": st.get("staging_pinned")})
+        print("%s %3d: %.1f captions/s end to end (%.2f s for %d rows)" % (kind, n, runs[-1]["captions_per_s"], st["run_s"],
+                                                                          st["images"]), file=sys.stderr, flush=True)
         got = [r for r in tsv_io.tsv_reader(out)]
         assert [r[0] for r in got] == [r[0] for r in rows], "row order"
         if out_first is None:
             out_first = got
         else:
-            assert got == out_first, "the task's output must not depend on the number of decode threads"
+            assert got == out_first, "the task's output must not depend on how the host side decodes"
 
     # the serial path of the reference: one image per model call, no thread pool, one context
     n_chk = min(args.check_rows, args.rows)
     chk_tsv = os.path.join(tmp, "chk.tsv")
     tsv_io.tsv_writer(rows[:n_chk], chk_tsv)
     os.environ["GIT_DECODE_THREADS"] = "0"
+    os.environ["GIT_DECODE_PROCS"] = "0"
     st1 = {}
     I.test_git_inference_single_tsv(chk_tsv, "GIT_BASE", None, os.path.join(tmp, "chk_out.tsv"), checkpoint=weights, batch_size=1,
                                     precision=args.precision, contexts=1, stats=st1)
@@ -139,11 +146,13 @@ def main(argv=None):
                    % (args.contexts, args.batch),
            "rows": args.rows, "image": "640x480 JPEG q90, %d KB mean" % (jpeg_bytes // 1024), "precision": args.precision,
            "host_cpus": os.cpu_count(), "runs": runs,
-           "e2e_captions_per_s": best["captions_per_s"], "e2e_decode_threads": best["decode_threads"],
+           "e2e_captions_per_s": best["captions_per_s"], "e2e_host_setting": {k: best[k] for k in ("procs", "threads") if k in best},
            "gpu_only_captions_per_s": round(gpu_only, 1),
            "gpu_busy_fraction": round(best["captions_per_s"] / gpu_only, 3),
            "one_host_thread_images_per_s": round(one_thread, 1),
-           "host_threads_to_saturate_one_gpu": int(np.ceil(gpu_only / one_thread)),
+           "host_cores_to_saturate_one_gpu": int(np.ceil(gpu_only / one_thread)),
+           "host_cores_note": "GPU-only rate / what one core decodes (base64 + JPEG -> RGB); the measured runs above show where the "
+                              "parent process (result queue, uploads, launches) becomes the limit instead",
            "serial_path": {"what": "contexts=1, batch_size=1, no decode threads: one image per model call, as the reference's loop",
                            "rows": n_chk, "captions_per_s": round(st1["images"] / st1["run_s"], 1),
                            "rows_identical_to_pipelined_output": same}}
