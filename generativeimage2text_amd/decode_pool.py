@@ -5,7 +5,7 @@ the other.  At the engine's rate (~10k captions/s per GPU) the host side has to 
 cannot (PIL hands the interpreter lock back only inside the entropy decoder: measured 1.4k images/s for 8 ... 64 threads on a
 256-thread host, profiles/r06_b_e2e_tsv.json).  So:
 
-  * N worker processes (spawned; they import numpy + PIL only, never torch) each read their rows from the TSV file themselves
+  * N worker processes (forked; they run PIL + numpy code only) each read their rows from the TSV file themselves
     (seek by the .lineidx.8b offsets), base64-decode, JPEG-decode to RGB and write the uint8 [H, W, 3] pixels into the slot the
     parent named -- a region of ONE shared staging buffer (a file in /dev/shm mapped by every process; the parent page-locks it
     for DMA when it can);
@@ -68,6 +68,9 @@ def _worker(tsv_path: str, shm_path: str, shm_size: int, slot_bytes: int, tasks,
         except Exception as exc:                                # a broken row must not hang the parent
             results.put((slot, row, "", 0, 0, "%s: %s" % (type(exc).__name__, exc)))
     fp.close()
+    results.close()
+    results.join_thread()                                   # flush what this worker still has to say
+    os._exit(0)                                              # no interpreter teardown in a forked copy of the parent
 
 
 class DecodePool:
@@ -85,7 +88,10 @@ class DecodePool:
         os.close(fd)
         self._mem = _map_shared(self.path, size)
         self.buffer = np.frombuffer(self._mem, dtype=np.uint8)                # the staging buffer, [slots * slot_bytes]
-        ctx = mp.get_context("spawn")                       # never fork a process that has initialised the GPU runtime
+        # fork, as torch's DataLoader workers: a child runs _worker only (PIL + numpy, its own mapping of the staging file) and never
+        # touches the GPU runtime it inherited; it leaves through os._exit.  (spawn would re-import the parent's __main__ -- torch
+        # and all -- in every worker: measured 48 workers = 5 s of start-up and a slower pool than 8.)
+        ctx = mp.get_context("fork")
         self.tasks, self.results = ctx.Queue(), ctx.Queue()
         self.procs = [ctx.Process(target=_worker, args=(tsv_path, self.path, size, self.slot_bytes, self.tasks, self.results),
                                   daemon=True) for _ in range(max(1, int(workers)))]

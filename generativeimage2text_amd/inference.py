@@ -356,7 +356,8 @@ def prefetch_ordered(n: int, load, threads: int, window: int):
 def run_tsv_inference(image_tsv: str, question_tsv: Optional[str], out_tsv: str, *, transform, caption_batch,
                       answer_questions, batch_size: int, rank: Optional[int] = None, world: Optional[int] = None,
                       poll_s: float = 0.2, decode=None, decode_threads: int = 0, submit_captions=None, submit_answers=None,
-                      in_flight: int = 1, stats: Optional[dict] = None, batch_source=None) -> None:
+                      in_flight: int = 1, stats: Optional[dict] = None, batch_source=None,
+                      max_questions: Optional[int] = None) -> None:
     """Everything of test_git_inference_single_tsv (inference.py:134-225) except the model: shard the rows by
     rank (:165-169), write this rank's rows, and deliver the complete, ordered `out_tsv` on rank 0 --
     through ONE RCCL gather when a process group exists or can be formed, else through the reference's
@@ -464,7 +465,7 @@ def run_tsv_inference(image_tsv: str, question_tsv: Optional[str], out_tsv: str,
             continue
         shape = tuple(img.shape)
         b = buckets.get(shape)
-        if b is not None and (len(b[0]) + 1 > batch_size or sum(len(q) for q in b[2]) + len(qs) > batch_size):
+        if b is not None and (len(b[0]) + 1 > batch_size or sum(len(q) for q in b[2]) + len(qs) > (max_questions or batch_size)):
             vqa_flush(shape)
             b = None
         if b is None:
@@ -598,7 +599,9 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
     tokenizer = get_tokenizer()
     torch.cuda.set_device(get_mpi_local_rank())                             # inference.py:152
     is_vqa = bool(question_tsv)
-    model = build_model(model_name, tokenizer, checkpoint, max_batch=batch_size, precision=precision,
+    # sentences per engine call: images when captioning; questions (of up to batch_size images) when answering
+    max_batch = max(batch_size, MAX_VQA_QUESTIONS) if is_vqa else batch_size
+    model = build_model(model_name, tokenizer, checkpoint, max_batch=max_batch, precision=precision,
                         **({"param": param} if from_file else {}))
     transforms = get_image_transform(param, gpu=True)
     pipelined = contexts > 1 and hasattr(model, "set_pipeline")
@@ -631,6 +634,10 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
         return out
 
     def submit_answers(imgs: Sequence[torch.Tensor], qss: Sequence[Sequence[str]]):
+        if sum(len(qs) for qs in qss) > max_batch:          # one image with more questions than an engine call takes
+            assert len(qss) == 1
+            img0, texts = imgs[0], answer_questions(imgs[0], qss[0])
+            return _Mapped(type("Done", (), {"result": lambda self: None})(), lambda _: [texts])
         prefixes, image_of = [], []
         for b, qs in enumerate(qss):
             for q in qs:
@@ -669,7 +676,7 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
                       transform=transforms, caption_batch=caption_batch, answer_questions=answer_questions,
                       batch_size=batch_size, submit_captions=submit_captions if pipelined else None,
                       submit_answers=submit_answers if (can_batch_vqa and is_vqa) else None,
-                      in_flight=contexts if pipelined else 1, stats=stats, batch_source=batch_source)
+                      in_flight=contexts if pipelined else 1, stats=stats, batch_source=batch_source, max_questions=max_batch)
     if stats is not None:
         stats.update(build_s=t_run - t_build, run_s=time.perf_counter() - t_run, decode_threads=threads,
                      contexts=contexts if pipelined else 1, precision=precision, batch_size=batch_size)
