@@ -5,12 +5,12 @@ the other.  At the engine's rate (~10k captions/s per GPU) the host side has to 
 cannot (PIL hands the interpreter lock back only inside the entropy decoder: measured 1.4k images/s for 8 ... 64 threads on a
 256-thread host, profiles/r06_b_e2e_tsv.json).  So:
 
-  * N worker processes (forked; they run PIL + numpy code only) each read their rows from the TSV file themselves
+  * N worker processes (fresh interpreters that import numpy + PIL only) each read their rows from the TSV file themselves
     (seek by the .lineidx.8b offsets), base64-decode, JPEG-decode to RGB and write the uint8 [H, W, 3] pixels into the slot the
     parent named -- a region of ONE shared staging buffer (a file in /dev/shm mapped by every process; the parent page-locks it
     for DMA when it can);
-  * the parent receives (slot, key, H, W) messages, and once the slots of a batch are filled uploads the batch with ONE copy and
-    runs the resize / crop / normalise for all of it in one launch pair (gitmi_preprocess_batch).
+  * the parent receives (slot, row, key, H, W) records over one pipe, and once the slots of a batch are filled uploads the batch
+    and runs the resize / crop / normalise for all of it in one launch pair per 24 images (gitmi_preprocess_batch).
 
 Nothing here touches the GPU; `tests/test_host.py` runs it on the CPU.
 """
@@ -19,7 +19,6 @@ from __future__ import annotations
 import base64
 import io
 import mmap
-import multiprocessing as mp
 import os
 import struct
 import tempfile
@@ -43,16 +42,41 @@ def _map_shared(path: str, size: int):
         os.close(fd)
 
 
-def _worker(tsv_path: str, shm_path: str, shm_size: int, slot_bytes: int, tasks, results) -> None:
+TASK = struct.Struct("<qq")                       # (slot, row); slot < 0: stop
+RESULT_BYTES = 256
+RESULT_HEAD = struct.Struct("<qqiii")             # slot, row, H, W, length of the key (or of an error text when H == W == 0)
+KEY_MAX = RESULT_BYTES - RESULT_HEAD.size
+
+
+def _read_exact(fd: int, n: int) -> bytes:
+    buf = b""
+    while len(buf) < n:
+        chunk = os.read(fd, n - len(buf))
+        if not chunk:
+            return b""
+        buf += chunk
+    return buf
+
+
+def worker_main(tsv_path: str, shm_path: str, shm_size: int, slot_bytes: int, task_fd: int, result_fd: int) -> None:
+    """One worker: fixed-size task records in (shared pipe, one record per read), pixels into the shared staging buffer, one
+    fixed-size result record out (a write below PIPE_BUF is atomic: all workers share one result pipe)."""
     from PIL import Image
     mem = _map_shared(shm_path, shm_size)
     offsets = _offsets_of(tsv_path)
     fp = open(tsv_path, "rb")
+
+    def reply(slot, row, h, w, text: bytes):
+        text = text[:KEY_MAX]
+        os.write(result_fd, (RESULT_HEAD.pack(slot, row, h, w, len(text)) + text).ljust(RESULT_BYTES, b"\0"))
+
     while True:
-        task = tasks.get()
-        if task is None:
+        rec = _read_exact(task_fd, TASK.size)
+        if not rec:
+            break                                               # the parent closed the task pipe (or died)
+        slot, row = TASK.unpack(rec)
+        if slot < 0:
             break
-        slot, row = task
         try:
             fp.seek(offsets[row])
             line = fp.readline()
@@ -60,23 +84,30 @@ def _worker(tsv_path: str, shm_path: str, shm_size: int, slot_bytes: int, tasks,
             img = Image.open(io.BytesIO(base64.b64decode(b64))).convert("RGB")       # load_image_by_pil
             w, h = img.size
             n = h * w * 3
+            if len(key) > KEY_MAX:
+                key = b""                                       # the parent reads long keys itself
             if n > slot_bytes:                                   # the parent decodes this one itself
-                results.put((slot, row, key.decode(), -h, -w, None))
+                reply(slot, row, -h, -w, key)
                 continue
             mem[slot * slot_bytes: slot * slot_bytes + n] = img.tobytes()       # raw RGB, row-major [H, W, 3]
-            results.put((slot, row, key.decode(), h, w, None))
+            reply(slot, row, h, w, key)
         except Exception as exc:                                # a broken row must not hang the parent
-            results.put((slot, row, "", 0, 0, "%s: %s" % (type(exc).__name__, exc)))
+            reply(slot, row, 0, 0, ("%s: %s" % (type(exc).__name__, exc)).encode("utf-8", "replace"))
     fp.close()
-    results.close()
-    results.join_thread()                                   # flush what this worker still has to say
-    os._exit(0)                                              # no interpreter teardown in a forked copy of the parent
 
 
 class DecodePool:
-    """slots: number of image slots of `slot_bytes` bytes each in the shared staging buffer."""
+    """slots: number of image slots of `slot_bytes` bytes each in the shared staging buffer.
+
+    Workers are fresh interpreters (`python -m generativeimage2text_amd.decode_pool`, started through subprocess: vfork + exec),
+    NOT forks of this process and not multiprocessing children: forking a process that drives a GPU write-protects its whole
+    address space (copy-on-write), the driver's MMU notifiers answer by evicting and restoring the process's GPU queues, and the
+    engine stalls for seconds (measured: 24 forked workers = 0.5k captions/s end to end, the parent blocked in kernel launches);
+    multiprocessing's spawn re-imports the parent's __main__ -- torch and all -- in every worker."""
 
     def __init__(self, tsv_path: str, workers: int, slots: int, slot_bytes: int = 1 << 20):
+        import subprocess
+        import sys
         if not os.path.isfile(os.path.splitext(tsv_path)[0] + ".lineidx.8b"):
             from .tsv_io import build_lineidx
             build_lineidx(tsv_path)
@@ -88,39 +119,55 @@ class DecodePool:
         os.close(fd)
         self._mem = _map_shared(self.path, size)
         self.buffer = np.frombuffer(self._mem, dtype=np.uint8)                # the staging buffer, [slots * slot_bytes]
-        # fork, as torch's DataLoader workers: a child runs _worker only (PIL + numpy, its own mapping of the staging file) and never
-        # touches the GPU runtime it inherited; it leaves through os._exit.  (spawn would re-import the parent's __main__ -- torch
-        # and all -- in every worker: measured 48 workers = 5 s of start-up and a slower pool than 8.)
-        ctx = mp.get_context("fork")
-        self.tasks, self.results = ctx.Queue(), ctx.Queue()
-        self.procs = [ctx.Process(target=_worker, args=(tsv_path, self.path, size, self.slot_bytes, self.tasks, self.results),
-                                  daemon=True) for _ in range(max(1, int(workers)))]
-        for p in self.procs:
-            p.start()
+        task_r, self._task_w = os.pipe()
+        self._result_r, result_w = os.pipe()
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        cmd = [sys.executable, "-m", "generativeimage2text_amd.decode_pool", tsv_path, self.path, str(size), str(self.slot_bytes),
+               str(task_r), str(result_w)]
+        self.procs = [subprocess.Popen(cmd, env=env, pass_fds=(task_r, result_w), stdin=subprocess.DEVNULL)
+                      for _ in range(max(1, int(workers)))]
+        os.close(task_r)
+        os.close(result_w)
         self._closed = False
 
     def submit(self, slot: int, row: int) -> None:
-        self.tasks.put((int(slot), int(row)))
+        os.write(self._task_w, TASK.pack(int(slot), int(row)))
 
     def next_result(self, timeout: Optional[float] = 120.0) -> Tuple[int, int, str, int, int]:
         """-> (slot, row, key, H, W) of the next finished image (any order); H, W negative: the image did not fit its slot (the
-        caller decodes that row itself); raises on a row that could not be decoded."""
-        slot, row, key, h, w, err = self.results.get(timeout=timeout)
-        if err is not None:
-            raise RuntimeError("row %d: %s" % (row, err))
-        return slot, row, key, h, w
+        caller decodes that row itself); key "" : longer than a result record holds (the caller reads it from the TSV); raises on
+        a row that could not be decoded, on a dead pool and on a timeout."""
+        import select
+        if timeout is not None and not select.select([self._result_r], [], [], timeout)[0]:
+            raise TimeoutError("decode pool: no result within %.0f s" % timeout)
+        rec = _read_exact(self._result_r, RESULT_BYTES)
+        if not rec:
+            raise RuntimeError("decode pool: every worker has exited")
+        slot, row, h, w, n = RESULT_HEAD.unpack_from(rec)
+        text = rec[RESULT_HEAD.size: RESULT_HEAD.size + n].decode("utf-8", "replace")
+        if h == 0 and w == 0:
+            raise RuntimeError("row %d: %s" % (row, text))
+        return slot, row, text, h, w
 
     def close(self) -> None:
         """Stop the workers and remove the backing file (the mapping itself goes when its last view does)."""
         if self._closed:
             return
         self._closed = True
-        for _ in self.procs:
-            self.tasks.put(None)
+        try:
+            os.close(self._task_w)                           # EOF on the task pipe: the workers leave their loops
+        except OSError:
+            pass
         for p in self.procs:
-            p.join(timeout=10)
-            if p.is_alive():
-                p.terminate()
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
+        try:
+            os.close(self._result_r)
+        except OSError:
+            pass
         self.buffer = None
         try:
             os.unlink(self.path)
@@ -132,3 +179,9 @@ class DecodePool:
             self.close()
         except Exception:
             pass
+
+
+if __name__ == "__main__":
+    import sys
+    _a = sys.argv[1:]
+    worker_main(_a[0], _a[1], int(_a[2]), int(_a[3]), int(_a[4]), int(_a[5]))

@@ -500,6 +500,7 @@ def pooled_caption_batches(image_tsv: str, start: int, end: int, batch_size: int
     (decode_pool.DecodePool), `in_flight + 2` batches of slots deep; a finished batch is uploaded image by image into ONE
     device buffer (only the bytes used) and transformed by ONE launch pair per 24 images (gitmi_preprocess_batch) --
     bit-identical to load_image_by_pil + gpu_image_transform per image."""
+    import time
     from .decode_pool import DecodePool
     from .engine import preprocess_batch
     ring = max(2, in_flight) + 2
@@ -533,10 +534,16 @@ def pooled_caption_batches(image_tsv: str, start: int, end: int, batch_size: int
                 meta[dispatched] = {}
                 dispatched += 1
             want = len(rows_of(b))
+            t_a = time.perf_counter()
             while len(meta[b]) < want:
                 slot, row, key, h, w = pool.next_result()
                 r = row - start
+                if not key:                         # longer than a result record holds
+                    if tsv is None:
+                        tsv = TSVFile(image_tsv)
+                    key = tsv[row][0]
                 meta[r // batch_size][r % batch_size] = (key, h, w, slot)
+            t_b = time.perf_counter()
             items = [meta[b][j] for j in range(want)]
             del meta[b]
             sizes = [abs(h) * abs(w) * 3 for _, h, w, _ in items]
@@ -558,7 +565,13 @@ def pooled_caption_batches(image_tsv: str, start: int, end: int, batch_size: int
             ev = torch.cuda.Event()
             ev.record()
             uploaded[b % ring] = ev
-            yield [it[0] for it in items], preprocess_batch(dev, desc, crop)
+            t_c = time.perf_counter()
+            out = preprocess_batch(dev, desc, crop)
+            if stats is not None:           # where the parent's time goes: waiting for the workers / uploads / the transform launches
+                stats["wait_decode_s"] = stats.get("wait_decode_s", 0.0) + (t_b - t_a)
+                stats["upload_s"] = stats.get("upload_s", 0.0) + (t_c - t_b)
+                stats["transform_s"] = stats.get("transform_s", 0.0) + (time.perf_counter() - t_c)
+            yield [it[0] for it in items], out
     finally:
         if pinned:
             try:

@@ -98,7 +98,8 @@ def main(argv=None):
                                         precision=args.precision, contexts=args.contexts, stats=st)
         runs.append({"host_path": "worker processes + batched GPU transform" if kind == "procs" else "thread pool + per-image GPU transform",
                      kind: n, "captions_per_s": round(st["images"] / st["run_s"], 1), "run_s": round(st["run_s"], 3),
-                     "build_s": round(st["build_s"], 2), "batches": st["batches"], "staging_pinned": st.get("staging_pinned")})
+                     "build_s": round(st["build_s"], 2), "batches": st["batches"], "staging_pinned": st.get("staging_pinned"),
+                     "parent_s": {k: round(st[k], 3) for k in ("wait_decode_s", "upload_s", "transform_s") if k in st}})
         print("%s %3d: %.1f captions/s end to end (%.2f s for %d rows)" % (kind, n, runs[-1]["captions_per_s"], st["run_s"],
                                                                           st["images"]), file=sys.stderr, flush=True)
         got = [r for r in tsv_io.tsv_reader(out)]
