@@ -99,7 +99,7 @@ def worker_main(tsv_path: str, shm_path: str, shm_size: int, slot_bytes: int, ta
 class DecodePool:
     """slots: number of image slots of `slot_bytes` bytes each in the shared staging buffer.
 
-    Workers are fresh interpreters (`python -m generativeimage2text_amd.decode_pool`, started through subprocess: vfork + exec),
+    Workers are fresh interpreters (`python -m generativeimage2text_amd.decode_pool`, started by one small launcher process),
     NOT forks of this process and not multiprocessing children: forking a process that drives a GPU write-protects its whole
     address space (copy-on-write), the driver's MMU notifiers answer by evicting and restoring the process's GPU queues, and the
     engine stalls for seconds (measured: 24 forked workers = 0.5k captions/s end to end, the parent blocked in kernel launches);
@@ -123,10 +123,11 @@ class DecodePool:
         self._result_r, result_w = os.pipe()
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        cmd = [sys.executable, "-m", "generativeimage2text_amd.decode_pool", tsv_path, self.path, str(size), str(self.slot_bytes),
-               str(task_r), str(result_w)]
-        self.procs = [subprocess.Popen(cmd, env=env, pass_fds=(task_r, result_w), stdin=subprocess.DEVNULL)
-                      for _ in range(max(1, int(workers)))]
+        # ONE child of this (large) process: a launcher that starts the N workers itself -- starting a child costs this process
+        # ~60 ms each (its page tables are copied for the fork in front of the exec), a small launcher starts them in ~1 ms each
+        cmd = [sys.executable, "-m", "generativeimage2text_amd.decode_pool", str(max(1, int(workers))), tsv_path, self.path,
+               str(size), str(self.slot_bytes), str(task_r), str(result_w)]
+        self.procs = [subprocess.Popen(cmd, env=env, pass_fds=(task_r, result_w), stdin=subprocess.DEVNULL)]
         os.close(task_r)
         os.close(result_w)
         self._closed = False
@@ -182,6 +183,15 @@ class DecodePool:
 
 
 if __name__ == "__main__":
+    import subprocess
     import sys
     _a = sys.argv[1:]
-    worker_main(_a[0], _a[1], int(_a[2]), int(_a[3]), int(_a[4]), int(_a[5]))
+    _n = int(_a[0])
+    if _n > 0:                                                  # launcher: start the workers, wait for them
+        _fds = (int(_a[5]), int(_a[6]))
+        _kids = [subprocess.Popen([sys.executable, "-m", "generativeimage2text_amd.decode_pool", "0"] + _a[1:], pass_fds=_fds,
+                                  stdin=subprocess.DEVNULL) for _ in range(_n)]
+        for _fd in _fds:
+            os.close(_fd)
+        sys.exit(max(k.wait() for k in _kids))
+    worker_main(_a[1], _a[2], int(_a[3]), int(_a[4]), int(_a[5]), int(_a[6]))

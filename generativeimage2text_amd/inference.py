@@ -506,6 +506,7 @@ def pooled_caption_batches(image_tsv: str, start: int, end: int, batch_size: int
     ring = max(2, in_flight) + 2
     n_rows = end - start
     n_batches = (n_rows + batch_size - 1) // batch_size
+    t_pool = time.perf_counter()
     pool = DecodePool(image_tsv, procs, slots=ring * batch_size, slot_bytes=slot_bytes)
     host = torch.from_numpy(pool.buffer)
     pinned = False
@@ -514,7 +515,8 @@ def pooled_caption_batches(image_tsv: str, start: int, end: int, batch_size: int
     except Exception:
         pinned = False
     if stats is not None:
-        stats.update(decode_procs=procs, staging_pinned=pinned, staging_mb=host.numel() >> 20)
+        stats.update(decode_procs=procs, staging_pinned=pinned, staging_mb=host.numel() >> 20,
+                     pool_start_s=time.perf_counter() - t_pool, t_pool_started=time.perf_counter())
     tsv = None
     try:
         meta = {}                                   # batch -> {position: (key, H, W)}
@@ -544,6 +546,9 @@ def pooled_caption_batches(image_tsv: str, start: int, end: int, batch_size: int
                     key = tsv[row][0]
                 meta[r // batch_size][r % batch_size] = (key, h, w, slot)
             t_b = time.perf_counter()
+            if stats is not None and b == 0:
+                stats["first_batch_ready_s"] = t_b - stats["t_pool_started"]      # interpreter start-up of the workers + one batch
+                stats["t_first_batch"] = t_b
             items = [meta[b][j] for j in range(want)]
             del meta[b]
             sizes = [abs(h) * abs(w) * 3 for _, h, w, _ in items]
@@ -691,6 +696,9 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
                       submit_answers=submit_answers if (can_batch_vqa and is_vqa) else None,
                       in_flight=contexts if pipelined else 1, stats=stats, batch_source=batch_source, max_questions=max_batch)
     if stats is not None:
+        if "t_first_batch" in stats and stats.get("images", 0) > batch_size:
+            # rate once the workers are up: everything after the first batch became ready
+            stats["steady_captions_per_s"] = (stats["images"] - batch_size) / (time.perf_counter() - stats["t_first_batch"])
         stats.update(build_s=t_run - t_build, run_s=time.perf_counter() - t_run, decode_threads=threads,
                      contexts=contexts if pipelined else 1, precision=precision, batch_size=batch_size)
     if hasattr(model, "close"):
