@@ -99,7 +99,7 @@ def worker_main(tsv_path: str, shm_path: str, shm_size: int, slot_bytes: int, ta
 class DecodePool:
     """slots: number of image slots of `slot_bytes` bytes each in the shared staging buffer.
 
-    Workers are fresh interpreters (`python -m generativeimage2text_amd.decode_pool`, started by one small launcher process),
+    Workers are forks of ONE small launcher interpreter (`python -m generativeimage2text_amd.decode_pool`, numpy + PIL only),
     NOT forks of this process and not multiprocessing children: forking a process that drives a GPU write-protects its whole
     address space (copy-on-write), the driver's MMU notifiers answer by evicting and restoring the process's GPU queues, and the
     engine stalls for seconds (measured: 24 forked workers = 0.5k captions/s end to end, the parent blocked in kernel launches);
@@ -119,21 +119,30 @@ class DecodePool:
         os.close(fd)
         self._mem = _map_shared(self.path, size)
         self.buffer = np.frombuffer(self._mem, dtype=np.uint8)                # the staging buffer, [slots * slot_bytes]
-        task_r, self._task_w = os.pipe()
+        n_workers = max(1, int(workers))
+        # one task pipe PER worker (tasks go round robin): dozens of readers blocked on one shared pipe scale negatively (measured on
+        # the 256-thread host: 7.8k images/s with 16 workers, 4.1k with 128); one result pipe for all (atomic 256-byte writes)
+        task_pipes = [os.pipe() for _ in range(n_workers)]
+        self._task_w = [w for _, w in task_pipes]
+        self._next = 0
         self._result_r, result_w = os.pipe()
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        # ONE child of this (large) process: a launcher that starts the N workers itself -- starting a child costs this process
-        # ~60 ms each (its page tables are copied for the fork in front of the exec), a small launcher starts them in ~1 ms each
-        cmd = [sys.executable, "-m", "generativeimage2text_amd.decode_pool", str(max(1, int(workers))), tsv_path, self.path,
-               str(size), str(self.slot_bytes), str(task_r), str(result_w)]
-        self.procs = [subprocess.Popen(cmd, env=env, pass_fds=(task_r, result_w), stdin=subprocess.DEVNULL)]
-        os.close(task_r)
+        # ONE child of this (large) process: a launcher that imports numpy + PIL once and FORKS the N workers -- starting a child
+        # costs this process tens of ms each (its page tables are copied for the fork in front of the exec); the small launcher
+        # forks a worker in about a millisecond
+        task_r = [r for r, _ in task_pipes]
+        cmd = [sys.executable, "-m", "generativeimage2text_amd.decode_pool", tsv_path, self.path, str(size), str(self.slot_bytes),
+               str(result_w)] + [str(fd) for fd in task_r]
+        self.procs = [subprocess.Popen(cmd, env=env, pass_fds=tuple(task_r) + (result_w,), stdin=subprocess.DEVNULL)]
+        for fd in task_r:
+            os.close(fd)
         os.close(result_w)
         self._closed = False
 
     def submit(self, slot: int, row: int) -> None:
-        os.write(self._task_w, TASK.pack(int(slot), int(row)))
+        os.write(self._task_w[self._next], TASK.pack(int(slot), int(row)))
+        self._next = (self._next + 1) % len(self._task_w)
 
     def next_result(self, timeout: Optional[float] = 120.0) -> Tuple[int, int, str, int, int]:
         """-> (slot, row, key, H, W) of the next finished image (any order); H, W negative: the image did not fit its slot (the
@@ -156,10 +165,11 @@ class DecodePool:
         if self._closed:
             return
         self._closed = True
-        try:
-            os.close(self._task_w)                           # EOF on the task pipe: the workers leave their loops
-        except OSError:
-            pass
+        for fd in self._task_w:                              # EOF on its task pipe: a worker leaves its loop
+            try:
+                os.close(fd)
+            except OSError:
+                pass
         for p in self.procs:
             try:
                 p.wait(timeout=10)
@@ -183,15 +193,24 @@ class DecodePool:
 
 
 if __name__ == "__main__":
-    import subprocess
+    # the launcher: argv = tsv, staging file, its size, slot bytes, result fd, one task fd per worker
     import sys
+    from PIL import Image  # noqa: F401  (imported once here; the forked workers share it)
     _a = sys.argv[1:]
-    _n = int(_a[0])
-    if _n > 0:                                                  # launcher: start the workers, wait for them
-        _fds = (int(_a[5]), int(_a[6]))
-        _kids = [subprocess.Popen([sys.executable, "-m", "generativeimage2text_amd.decode_pool", "0"] + _a[1:], pass_fds=_fds,
-                                  stdin=subprocess.DEVNULL) for _ in range(_n)]
-        for _fd in _fds:
-            os.close(_fd)
-        sys.exit(max(k.wait() for k in _kids))
-    worker_main(_a[1], _a[2], int(_a[3]), int(_a[4]), int(_a[5]), int(_a[6]))
+    _result_fd, _task_fds = int(_a[4]), [int(v) for v in _a[5:]]
+    _kids = []
+    for _i, _fd in enumerate(_task_fds):
+        _pid = os.fork()
+        if _pid == 0:
+            for _other in _task_fds:
+                if _other != _fd:
+                    os.close(_other)
+            try:
+                worker_main(_a[0], _a[1], int(_a[2]), int(_a[3]), _fd, _result_fd)
+            finally:
+                os._exit(0)
+        _kids.append(_pid)
+    for _fd in _task_fds + [_result_fd]:
+        os.close(_fd)
+    for _pid in _kids:
+        os.waitpid(_pid, 0)

@@ -854,7 +854,7 @@ def test_decode_pool_writes_the_pixels_pil_decodes(tmp_path):
                 got = pool.buffer[slot * slot_bytes: slot * slot_bytes + h * w * 3].reshape(h, w, 3)
                 assert np.array_equal(got, arrays[row]), row
         assert sorted(seen) == list(range(11))
-        too_big = [r for r, (h, w) in seen.items() if h < 0]
+        too_big = sorted(r for r, (h, w) in seen.items() if h < 0)
         assert too_big == [r for r in range(11) if arrays[r].size > slot_bytes] and len(too_big) >= 1
         assert all((-seen[r][0], -seen[r][1]) == arrays[r].shape[:2] for r in too_big)
         pool.submit(slot=0, row=11)
