@@ -1537,10 +1537,13 @@ static int generate_run(gitmi_engine* e, const float* const* frames, int F, int 
         e->split_encode_ms += a; e->split_decode_ms += b; e->split_calls += 1; e->split_steps += sp->max_steps - 1;
     }
     const size_t nout = (size_t)Q * (size_t)(sp->num_keep_best > 1 ? sp->num_keep_best : 1);      // sequences returned
-    HIPCK(hipMemcpyAsync(tokens_out, e->out_tokens, nout * sp->max_steps * sizeof(long long), hipMemcpyDeviceToDevice, x));
-    HIPCK(hipMemcpyAsync(logprob_out, e->out_lp, nout * sizeof(float), hipMemcpyDeviceToDevice, x));
-    HIPCK(hipMemcpyAsync(info_out, e->out_info, 4 * sizeof(int), hipMemcpyDeviceToDevice, x));
-    if (sent_out) HIPCK(hipMemcpyAsync(sent_out, e->out_sent, (size_t)Q * 2 * sizeof(int), hipMemcpyDeviceToDevice, x));
+    // the caller's buffers: device memory or PAGE-LOCKED host memory (hipMemcpyDefault: the results then arrive on the host as part
+    // of the request itself -- a server reads them after the stream's event without enqueueing anything more, which matters when
+    // its other streams keep the device's queues full: a separate small read-back waits milliseconds for a queue slot)
+    HIPCK(hipMemcpyAsync(tokens_out, e->out_tokens, nout * sp->max_steps * sizeof(long long), hipMemcpyDefault, x));
+    HIPCK(hipMemcpyAsync(logprob_out, e->out_lp, nout * sizeof(float), hipMemcpyDefault, x));
+    HIPCK(hipMemcpyAsync(info_out, e->out_info, 4 * sizeof(int), hipMemcpyDefault, x));
+    if (sent_out) HIPCK(hipMemcpyAsync(sent_out, e->out_sent, (size_t)Q * 2 * sizeof(int), hipMemcpyDefault, x));
     if (x != s) {
         HIPCK(hipEventRecord(e->fence_out, x));
         HIPCK(hipStreamWaitEvent(s, e->fence_out, 0));

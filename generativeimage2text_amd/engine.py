@@ -317,21 +317,24 @@ class Engine:
         return s
 
     @staticmethod
-    def _out(n_sent: int, search: GitmiSearch, dev):
+    def _out(n_sent: int, search: GitmiSearch, dev, host: bool = False):
         """Output buffers of a search over n_sent sentences: [n, T] / [n], or [n, num_keep_best, T] / [n, num_keep_best]
-        when GeneratorWithBeamSearch keeps more than one hypothesis (decoder.py:1283-1290)."""
+        when GeneratorWithBeamSearch keeps more than one hypothesis (decoder.py:1283-1290).  host: page-locked host tensors."""
         nh = max(1, int(search.num_keep_best))
         shape = (n_sent,) if nh == 1 else (n_sent, nh)
-        return (torch.empty(*shape, search.max_steps, device=dev, dtype=torch.int64),
-                torch.empty(*shape, device=dev, dtype=torch.float32))
+        kw = dict(pin_memory=True) if host else dict(device=dev)
+        return (torch.empty(*shape, search.max_steps, dtype=torch.int64, **kw),
+                torch.empty(*shape, dtype=torch.float32, **kw))
 
     def generate(self, frames: Sequence[torch.Tensor], search: GitmiSearch,
-                 prefix: Optional[torch.Tensor] = None, sync: bool = True):
-        """-> (tokens int64 [B, max_steps] incl. start tokens / EOS padded, logprobs fp32 [B], info int32 [4])"""
+                 prefix: Optional[torch.Tensor] = None, sync: bool = True, host_out: bool = False):
+        """-> (tokens int64 [B, max_steps] incl. start tokens / EOS padded, logprobs fp32 [B], info int32 [4]).
+        host_out: the three come back as PAGE-LOCKED HOST tensors, filled by the request itself (valid once the stream has reached
+        the end of the call): a server with other requests in flight reads them without enqueueing a read-back."""
         arr, keep, B = self._frames_arg(frames)
         dev = keep[0].device
-        tokens, logprobs = self._out(B, search, dev)
-        info = torch.empty(4, device=dev, dtype=torch.int32)
+        tokens, logprobs = self._out(B, search, dev, host_out)
+        info = torch.empty(4, dtype=torch.int32, pin_memory=True) if host_out else torch.empty(4, device=dev, dtype=torch.int32)
         P, pfx = 1, None
         if prefix is not None:
             pfx = prefix.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
@@ -344,11 +347,11 @@ class Engine:
             self.check_finite(info)
         return tokens, logprobs, info
 
-    def check_finite(self, info: torch.Tensor) -> None:
+    def check_finite(self, info) -> None:
         """info[3] of a finished call (include/gitmi.h): sequences with a non-finite log-prob -- an activation left the range
         of the 16-bit operand format (fp16 tops out at 65504).  Raises instead of handing back garbage ids; callers of
         generate(sync=False) call this once the stream has been synchronised."""
-        bad = int(info[3].item())
+        bad = int(info[3]) if isinstance(info, (list, tuple)) else int(info[3].item())
         if bad:
             raise GitmiError(f"{bad} sequence(s) came back with a non-finite log-probability: an activation overflowed the "
                              f"{self.precision} operand range of this build -- run this checkpoint with precision='bf16' or 'f32'")
@@ -373,7 +376,8 @@ class Engine:
         return out, info
 
     def generate_prefixed(self, frames: Sequence[torch.Tensor], search: GitmiSearch,
-                          prefixes: Sequence[Sequence[int]], image_of: Optional[Sequence[int]] = None, sync: bool = True):
+                          prefixes: Sequence[Sequence[int]], image_of: Optional[Sequence[int]] = None, sync: bool = True,
+                          host_out: bool = False):
         """Batched VQA: sentence q starts from its own prefix `prefixes[q]` (token ids incl. [CLS], any lengths) and
         attends to image `image_of[q]` of the encoded batch (default: sentence q <-> image q).  Every sentence gets
         exactly what a batch-1 reference call with that image and prefix returns (decoder.py:984-1006).
@@ -387,9 +391,10 @@ class Engine:
         for q, p in enumerate(prefixes):
             table[q, :len(p)] = torch.as_tensor(list(p), dtype=torch.int64)
         table = table.to(dev)
-        tokens, logprobs = self._out(Q, search, dev)
-        sent = torch.empty(Q, 2, device=dev, dtype=torch.int32)
-        info = torch.empty(4, device=dev, dtype=torch.int32)
+        tokens, logprobs = self._out(Q, search, dev, host_out)
+        hk = dict(pin_memory=True) if host_out else dict(device=dev)
+        sent = torch.empty(Q, 2, dtype=torch.int32, **hk)
+        info = torch.empty(4, dtype=torch.int32, **hk)
         lens_c = (C.c_int32 * Q)(*lens)
         img_c = None if image_of is None else (C.c_int32 * Q)(*[int(i) for i in image_of])
         self._ck(self.lib.gitmi_generate_prefixed(self._h, arr, len(keep), B, table.data_ptr(), ld, lens_c, img_c, Q,

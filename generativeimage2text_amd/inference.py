@@ -389,11 +389,17 @@ def run_tsv_inference(image_tsv: str, question_tsv: Optional[str], out_tsv: str,
     if stats is not None:
         stats.update(images=0, batches=0, questions=0)
 
+    import time
+
     def drain(limit):
         while len(pending) > limit:
             keys, handle = pending.popleft()
-            for key, cap in zip(keys, handle.result()):
+            t0 = time.perf_counter()
+            caps = handle.result()
+            for key, cap in zip(keys, caps):
                 rows.append([key, json_dump([{"caption": cap}])])
+            if stats is not None:
+                stats["result_s"] = stats.get("result_s", 0.0) + (time.perf_counter() - t0)
 
     def flush(keys, imgs):
         if stats is not None:
@@ -402,7 +408,10 @@ def run_tsv_inference(image_tsv: str, question_tsv: Optional[str], out_tsv: str,
             for key, cap in zip(keys, caption_batch(imgs)):
                 rows.append([key, json_dump([{"caption": cap}])])
             return
+        t0 = time.perf_counter()
         pending.append((keys, submit_captions(imgs)))
+        if stats is not None:
+            stats["submit_s"] = stats.get("submit_s", 0.0) + (time.perf_counter() - t0)
         drain(in_flight if in_flight > 1 else 0)
 
     import threading
@@ -690,15 +699,24 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
     t_run = time.perf_counter()
     # decode on the pool all the way to the uint8 array the GPU transform uploads (stand-in models of the CPU tests keep PIL images)
     decode = decode_to_array if hasattr(model, "engine") else load_image_by_pil
-    run_tsv_inference(image_tsv, question_tsv, out_tsv, decode=decode, decode_threads=threads,
-                      transform=transforms, caption_batch=caption_batch, answer_questions=answer_questions,
-                      batch_size=batch_size, submit_captions=submit_captions if pipelined else None,
-                      submit_answers=submit_answers if (can_batch_vqa and is_vqa) else None,
-                      in_flight=contexts if pipelined else 1, stats=stats, batch_source=batch_source, max_questions=max_batch)
+    # the host side (uploads, transform kernels, torch ops) gets a stream of its own when requests are kept in flight: work on the
+    # DEFAULT stream synchronises with every blocking stream of the process (legacy null-stream semantics), streams a running
+    # hipGraph executes on included -- measured: uploads on the default stream serialise with the requests in flight
+    import contextlib
+    side = torch.cuda.stream(torch.cuda.Stream()) if pipelined else contextlib.nullcontext()
+    with side:
+        run_tsv_inference(image_tsv, question_tsv, out_tsv, decode=decode, decode_threads=threads,
+                          transform=transforms, caption_batch=caption_batch, answer_questions=answer_questions,
+                          batch_size=batch_size, submit_captions=submit_captions if pipelined else None,
+                          submit_answers=submit_answers if (can_batch_vqa and is_vqa) else None,
+                          in_flight=contexts if pipelined else 1, stats=stats, batch_source=batch_source, max_questions=max_batch)
     if stats is not None:
         if "t_first_batch" in stats and stats.get("images", 0) > batch_size:
             # rate once the workers are up: everything after the first batch became ready
             stats["steady_captions_per_s"] = (stats["images"] - batch_size) / (time.perf_counter() - stats["t_first_batch"])
+        from .model import Pending
+        stats["device_wait_s"] = Pending.wait_s
+        Pending.wait_s = 0.0
         stats.update(build_s=t_run - t_build, run_s=time.perf_counter() - t_run, decode_threads=threads,
                      contexts=contexts if pipelined else 1, precision=precision, batch_size=batch_size)
     if hasattr(model, "close"):

@@ -434,15 +434,18 @@ class CaptioningModel:
                 if B * nret > eng.c.max_batch:
                     raise ValueError(f"{B} images x num_return_sequences={nret} exceed max_batch={eng.c.max_batch}")
                 tokens, logprobs, _, info = eng.generate_prefixed(
-                    frames, search, [start] * (B * nret), image_of=[b for b in range(B) for _ in range(nret)], sync=False)
+                    frames, search, [start] * (B * nret), image_of=[b for b in range(B) for _ in range(nret)], sync=False,
+                    host_out=stream is not None)
             else:
-                tokens, logprobs, info = eng.generate(frames, search, prefix=prefix, sync=False)
+                # requests in flight on other streams: results straight into page-locked host memory (no read-back to enqueue)
+                tokens, logprobs, info = eng.generate(frames, search, prefix=prefix, sync=False, host_out=stream is not None)
             return tokens, logprobs, info
 
         def finish(out):
             tokens, logprobs, info = out
-            eng.check_finite(info)
-            seq_len, early, _, _ = info.tolist()
+            info_h = info.tolist()                                              # ONE small read-back for the four fields
+            eng.check_finite(info_h)
+            seq_len, early, _, _ = info_h
             if kind in ("autoregressive", "trie"):
                 if early:                                                       # decoder.py:279-291 / trie_decoder.py:76-83
                     predictions = tokens[:, P:P + 1]
@@ -490,11 +493,11 @@ class CaptioningModel:
         kind = self.decoder.kind
 
         def launch():
-            return eng.generate_prefixed(frames, search, prefixes, image_of=image_of, sync=False)
+            return eng.generate_prefixed(frames, search, prefixes, image_of=image_of, sync=False, host_out=stream is not None)
 
         def finish(out):
             tokens, logprobs, sent, info = out
-            eng.check_finite(info)
+            eng.check_finite(info.tolist())
             tokens, sent = tokens.cpu(), sent.cpu()
             res = []
             for q, p in enumerate(prefixes):
@@ -524,7 +527,7 @@ class Pending:
     """A request enqueued on a context's stream (CaptioningModel.submit / submit_answers)."""
 
     def __init__(self, stream, launch, finish, keep=()):
-        self._finish, self._keep, self._done, self._value = finish, keep, False, None
+        self._finish, self._keep, self._done, self._value, self._stream = finish, keep, False, None, stream
         if stream is None:
             self._out = launch()
             self._event = None
@@ -535,12 +538,17 @@ class Pending:
                 self._event = torch.cuda.Event()
                 self._event.record()
 
+    wait_s = 0.0            # class-wide: seconds spent waiting for the device in result() (diagnostics of the TSV task)
+
     def result(self):
         if not self._done:
+            import time
+            t0 = time.perf_counter()
             if self._event is not None:
                 self._event.synchronize()
             else:
                 torch.cuda.current_stream().synchronize()
+            Pending.wait_s += time.perf_counter() - t0
             self._value = self._finish(self._out)
             self._done, self._out, self._keep = True, None, ()
         return self._value

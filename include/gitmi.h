@@ -202,6 +202,9 @@ int  gitmi_step_logits(gitmi_engine* e, const int64_t* tokens, int R, int t,
  *   prefix       : int64 [P] starting with [CLS], or NULL for captioning (P ignored);
  *                  the reference requires B==1 with a prefix (decoder.py:988) -- here a
  *                  single prefix is shared by all B images.
+ *   tokens_out, logprob_out, info_out (and sent_out of gitmi_generate_prefixed): device buffers OR page-locked host buffers
+ *                  (hipHostMalloc / a pinned torch tensor): with host buffers the results are on the host when the stream reaches
+ *                  the end of the call, no read-back has to be enqueued afterwards.
  *   tokens_out   : int64 [B, max_steps]; sequences INCLUDE the start tokens, EOS-padded.
  *   logprob_out  : fp32 [B]  (AUTOREGRESSIVE: sum/num_valid, decoder.py:429-438;
  *                              GENERATOR: length-normalised score, decoder.py:1310-1320)

@@ -101,7 +101,7 @@ def main(argv=None):
                      "build_s": round(st["build_s"], 2), "batches": st["batches"], "staging_pinned": st.get("staging_pinned"),
                      "steady_captions_per_s": round(st["steady_captions_per_s"], 1) if "steady_captions_per_s" in st else None,
                      "parent_s": {k: round(st[k], 3) for k in ("pool_start_s", "first_batch_ready_s", "wait_decode_s", "upload_s",
-                                                                "transform_s") if k in st}})
+                                                                "transform_s", "submit_s", "result_s", "device_wait_s") if k in st}})
         print("%s %3d: %.1f captions/s end to end (%.2f s for %d rows; steady state %s)" % (
             kind, n, runs[-1]["captions_per_s"], st["run_s"], st["images"], runs[-1]["steady_captions_per_s"]), file=sys.stderr, flush=True)
         got = [r for r in tsv_io.tsv_reader(out)]
