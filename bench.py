@@ -89,14 +89,20 @@ def cpu_baseline(sample_batch: int, max_steps: int, threads: int = 0, repeats: i
     /root/reference does not exist on the GPU box, so the reference modules themselves cannot be timed there:
     kind = "port"."""
     cores = os.cpu_count() or 1
+    try:
+        from generativeimage2text_amd.inference import effective_cpus
+        usable = effective_cpus()                        # affinity mask capped by the cgroup CPU quota
+    except Exception:
+        usable = cores
     threads = threads or min(cores, 16)
     _cpu_run(min(2, sample_batch), max_steps, threads)                    # warm-up (thread pool, allocator, first-touch)
     runs = [_cpu_run(sample_batch, max_steps, threads) for _ in range(max(1, repeats))]
     med = sorted(runs, key=lambda r: r["captions_per_s"])[len(runs) // 2]
     out = {"value": round(med["captions_per_s"], 4), "unit": "captions/s", "cores": threads, "kind": "port",
            "threads_note": "16 threads is the FASTEST setting of the sweep on the GPU box's 256-thread host (profiles/r02_d_cpu_sweep.json: "
-                           "16 / 32 / 64 / 128 threads; torch's CPU kernels oversubscribe beyond it), not an arbitrary cap",
-           "host_cpus": cores, "vit_s": round(med["vit_s"], 2), "decode_s": round(med["decode_s"], 2),
+                           "16 / 32 / 64 / 128 threads) -- the box's container has a cgroup CPU quota of 16 cores (host_cpus_usable; "
+                           "cpu.max = 1600000 100000, found in round 6), so 16 threads is every core this process may use",
+           "host_cpus": cores, "host_cpus_usable": usable, "vit_s": round(med["vit_s"], 2), "decode_s": round(med["decode_s"], 2),
            "runs": [round(r["captions_per_s"], 4) for r in runs],
            "sample": f"GIT_BASE fp32 bs={sample_batch} greedy {med['steps']} decode steps, full recompute per step "
                      f"(reference semantics): median of {len(runs)} passes after one warm-up, {med['wall_s']:.1f}s each on "

@@ -64,6 +64,30 @@ def shard_range(num_rows: int, rank: int, world: int):
     return start, min(start + per, num_rows)
 
 
+def effective_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota (a container on a 256-thread host
+    is routinely limited to a few cores' worth of time: cpu.max = "1600000 100000" is 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", ):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // p_))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 # ---- tokenizer --------------------------------------------------------------------------------
 class IdTokenizer:
     """Explicit opt-in (GIT_VOCAB=ids) for machines without a WordPiece vocabulary: ids in, ids out."""
@@ -684,12 +708,12 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
 
     # JPEG decoding on a few host threads ahead of the GPU (GIT_DECODE_THREADS, default min(16, cores); 0 = serial as in
     # the reference); the transform itself (upload + resize kernels) stays on this thread and this device
-    threads = int(os.environ.get("GIT_DECODE_THREADS", str(min(16, os.cpu_count() or 1))))
+    threads = int(os.environ.get("GIT_DECODE_THREADS", str(min(16, effective_cpus()))))
     can_batch_vqa = hasattr(model, "submit_answers")
     # captioning on the engine: worker PROCESSES decode into a shared staging buffer, one upload + one launch pair per batch
-    # (GIT_DECODE_PROCS, default min(24, cores / 2); 0 = the thread pool above).  Aspect-preserving models and VQA keep the
+    # (GIT_DECODE_PROCS, default min(32, usable cores - 2) with the cgroup's CPU quota counted; 0 = the thread pool above).  Aspect-preserving models and VQA keep the
     # per-image path (every image has its own output shape).
-    procs = int(os.environ.get("GIT_DECODE_PROCS", str(min(24, max(1, (os.cpu_count() or 2) // 2)))))
+    procs = int(os.environ.get("GIT_DECODE_PROCS", str(min(32, max(1, effective_cpus() - 2)))))
     batch_source = None
     if procs > 0 and not is_vqa and "test_respect_ratio_max" not in param and hasattr(model, "engine"):
         crop = int(param.get("test_crop_size", 224))

@@ -149,7 +149,9 @@ def main(argv=None):
                    "GIT_BASE greedy max_len 20 (ViT + prefill + 19 decode steps, %d batches of %d in flight) -> caption rows -> TSV"
                    % (args.contexts, args.batch),
            "rows": args.rows, "image": "640x480 JPEG q90, %d KB mean" % (jpeg_bytes // 1024), "precision": args.precision,
-           "host_cpus": os.cpu_count(), "runs": runs,
+           "host_cpus": os.cpu_count(), "host_cpus_usable": I.effective_cpus(),
+           "host_cpus_note": "usable = affinity mask capped by the cgroup CPU quota (cpu.max): what the workers AND the parent share",
+           "runs": runs,
            "e2e_captions_per_s": best["captions_per_s"], "e2e_host_setting": {k: best[k] for k in ("procs", "threads") if k in best},
            "e2e_steady_state_captions_per_s": steady,
            "steady_state_note": "rate after the first batch is ready, i.e. without the start-up of the worker interpreters (0.3-0.5 s: it "
@@ -158,9 +160,10 @@ def main(argv=None):
            "gpu_busy_fraction": round(best["captions_per_s"] / gpu_only, 3),
            "gpu_busy_fraction_steady_state": round(steady / gpu_only, 3),
            "one_host_thread_images_per_s": round(one_thread, 1),
-           "host_cores_to_saturate_one_gpu": int(np.ceil(gpu_only / one_thread)),
-           "host_cores_note": "GPU-only rate / what one core decodes (base64 + JPEG -> RGB); the measured runs above show where the "
-                              "parent process (result queue, uploads, launches) becomes the limit instead",
+           "host_cores_to_saturate_one_gpu": int(np.ceil(gpu_only / (steady / max(1, I.effective_cpus())))) if steady else None,
+           "host_cores_note": "GPU-only rate / (measured steady-state rate per usable core: workers, parent and the runtime's threads "
+                              "together); decode alone (GPU-only rate / one core's base64 + JPEG -> RGB rate) would be %d"
+                              % int(np.ceil(gpu_only / one_thread)),
            "serial_path": {"what": "contexts=1, batch_size=1, no decode threads: one image per model call, as the reference's loop",
                            "rows": n_chk, "captions_per_s": round(st1["images"] / st1["run_s"], 1),
                            "rows_identical_to_pipelined_output": same}}
