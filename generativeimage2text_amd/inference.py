@@ -711,9 +711,9 @@ def test_git_inference_single_tsv(image_tsv, model_name, question_tsv, out_tsv, 
     threads = int(os.environ.get("GIT_DECODE_THREADS", str(min(16, effective_cpus()))))
     can_batch_vqa = hasattr(model, "submit_answers")
     # captioning on the engine: worker PROCESSES decode into a shared staging buffer, one upload + one launch pair per batch
-    # (GIT_DECODE_PROCS, default min(32, usable cores - 2) with the cgroup's CPU quota counted; 0 = the thread pool above).  Aspect-preserving models and VQA keep the
+    # (GIT_DECODE_PROCS, default min(32, usable cores) with the cgroup's CPU quota counted; 0 = the thread pool above).  Aspect-preserving models and VQA keep the
     # per-image path (every image has its own output shape).
-    procs = int(os.environ.get("GIT_DECODE_PROCS", str(min(32, max(1, effective_cpus() - 2)))))
+    procs = int(os.environ.get("GIT_DECODE_PROCS", str(min(32, effective_cpus()))))
     batch_source = None
     if procs > 0 and not is_vqa and "test_respect_ratio_max" not in param and hasattr(model, "engine"):
         crop = int(param.get("test_crop_size", 224))
