@@ -502,6 +502,8 @@ def main(argv=None, engine_factory=None):
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-big-batch", type=int, default=0, help="also time ONE CPU pass at this batch size (64: ~75 s)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-ln-fold", action="store_true",
+                    help="A/B (f16 build): one LayerNorm launch per module in the encoder / prefill instead of the folded GEMM epilogues")
     ap.add_argument("--contexts", type=int, default=4,
                     help="engine contexts (shared weights) kept in flight on separate HIP streams")
     ap.add_argument("--free-run", action="store_true", help="do not chain the contexts' image encoders at all")
@@ -594,6 +596,8 @@ def main(argv=None, engine_factory=None):
         frames = random_frames(cfg, args.batch, args.frames, seed=rank)
     if args.no_graph:
         eng.set_graph(False)
+    if args.no_ln_fold and not standin:
+        eng.set_ln_fold(False)                  # before cloning: the clones inherit it
     if os.environ.get("BENCH_GEMM_IMPL"):       # measurement build: A/B of GEMM variants in situ (tools/gpu_ab.sh)
         from generativeimage2text_amd.engine import set_gemm_impl
         set_gemm_impl(int(os.environ["BENCH_GEMM_IMPL"]))
@@ -735,6 +739,7 @@ def main(argv=None, engine_factory=None):
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "decode_steps_per_caption": steps_run, "seq_len_returned": info_h[0],
                        "hip_graph": not args.no_graph, "contexts_in_flight": len(ctxs),
+                       "layernorm_folded": bool(args.precision == "f16" and not args.no_ln_fold and not args.experiment),
                        "library": ("libgitmi_exp.so (measurement build: " + " ".join(
                            f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("GITMI_")) + ")") if args.experiment
                        else {"bf16": "libgitmi.so", "f16": "libgitmi_f16.so"}.get(args.precision, "libgitmi.so"),

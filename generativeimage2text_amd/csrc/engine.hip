@@ -55,6 +55,10 @@ struct VitLayerW {
     void *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
     float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
     float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+    // LayerNorm folded into the consumer GEMM (fp16-operand build, kernels_gemm10.hip LNF): row-major f16(W . gamma),
+    // beta W^T + bias, column sums of the rounded matrix
+    void *wqkv_f = nullptr; float *bqkv_f = nullptr, *cs_qkv = nullptr;   // ln_1
+    void *w1_f = nullptr;   float *b1_f = nullptr,   *cs_1 = nullptr;     // ln_2
 };
 struct DecLayerW {
     void *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
@@ -66,6 +70,9 @@ struct DecLayerW {
     void *wqkv_f = nullptr; float *bqkv_f = nullptr, *cs_qkv = nullptr;   // previous layer's output LayerNorm (layer 0: plain, cs_qkv == nullptr)
     void *w1_f = nullptr;   float *b1_f = nullptr,   *cs_1 = nullptr;     // this layer's attention-output LayerNorm
     void *wo_p = nullptr, *w2_p = nullptr;                                 // plain, packed
+    // prefill (image rows, large M): the same two folds in ROW-MAJOR layout for gemm_p8_kernel (layer 0: the visual projection's LayerNorm)
+    void *wqkv_pf = nullptr; float *bqkv_pf = nullptr, *cs_qkv_p = nullptr;
+    void *w1_pf = nullptr;   float *b1_pf = nullptr,   *cs_1_p = nullptr;
 };
 
 struct TimedSpan { hipEvent_t a, b; int tag; double flops; };
@@ -173,6 +180,12 @@ struct gitmi_engine {
     // rounding.  Measured (profiles/r03_a_bench_f16_*.json, interleaved A/B): encode + prefill 5.31 -> 5.03 ms,
     // 9.48k -> 9.82k captions/s, logit error 0.01118 -> 0.01094, the same 50 of 64 rows identical to the reference.
     bool stream_f16 = false;
+    // LayerNorm folding in the encoder and the prefill (round 6; fp16-operand build only: the fp16 stream rows are the
+    // consumer GEMM's A operand as they are).  Row partials (sum, sumsq) per 256-column tile: [rows][4], ping-pong for
+    // the post-norm prefill (a producer tile reads the previous partials of a row while another tile writes the new ones).
+    bool ln_fold = false;
+    bool ln_fold_ready = false;         // folded matrices and partial buffers exist (decided at gitmi_create; gitmi_set_ln_fold switches the use)
+    float2 *v_part = nullptr, *p_part[2] = {nullptr, nullptr};
     hipEvent_t gev[3] = {nullptr, nullptr, nullptr};
     // serving schedule: this context's image encoder starts only after `enc_after`'s has finished (at most one encoder
     // in flight on the device; decode chains of the other contexts fill in beside it)
@@ -272,6 +285,47 @@ static int gemm_stream(gitmi_engine* e, hipStream_t s, const void* A, int lda, c
     HIPCK(launch_gemm(g, e->f32, !e->stream_f16, s));
     return 0;
 }
+// ---- folded LayerNorm (e->ln_fold): what a GEMM needs to know about the LayerNorm in front of it / of its residual
+struct LnRef {
+    const float2* part = nullptr; int nparts = 0; int D = 0; float eps = 0.f;
+    const float* gamma = nullptr; const float* beta = nullptr;       // residual form only
+};
+// consumer: C = act(LayerNorm(x) W^T + b) with x the raw stream rows, W / bias / colsum the folded set
+static int gemm_ln(gitmi_engine* e, hipStream_t s, const void* x, int ldx, const void* Wf, const float* bias_f, const float* colsum,
+                   const LnRef& ln, void* C, int ldc, int M, int N, int K, int act, int tag) {
+    GemmArgs g{};
+    g.A = x; g.W = Wf; g.bias = bias_f; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = ldx; g.ldc = ldc; g.act = act;
+    g.ln_part = ln.part; g.ln_nparts = ln.nparts; g.ln_colsum = colsum; g.ln_inv_d = 1.0f / (float)ln.D; g.ln_eps = ln.eps;
+    g.shared = gemm_tall_tiles(e, N) ? 1 : 0;
+    SpanGuard sp(e, s, tag, 2.0 * (double)M * (double)N * (double)K);
+    HIPCK(launch_gemm(g, false, false, s));
+    return 0;
+}
+// producer: stream rows C = A W^T + b (+ res, or + LayerNorm(res) when res_ln is given) and their row partials
+static int gemm_stream_part(gitmi_engine* e, hipStream_t s, const void* A, int lda, const void* W, const float* bias,
+                            const void* res, int ldr, const LnRef* res_ln, void* C, int ldc, float2* part_out, int M, int N, int K,
+                            int tag) {
+    GemmArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.res = (const float*)res; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldr; g.act = 0;
+    g.out_f16 = 1;
+    g.part_out = part_out;
+    if (res_ln) {
+        g.res_part = res_ln->part; g.res_nparts = res_ln->nparts; g.res_gamma = res_ln->gamma; g.res_beta = res_ln->beta;
+        g.res_inv_d = 1.0f / (float)res_ln->D; g.res_eps = res_ln->eps;
+    }
+    g.shared = gemm_tall_tiles(e, N) ? 1 : 0;
+    SpanGuard sp(e, s, tag, 2.0 * (double)M * (double)N * (double)K);
+    HIPCK(launch_gemm(g, false, false, s));
+    return 0;
+}
+// does a 16-bit GEMM of this shape run on gemm_p8_kernel (the only kernel with the folded epilogues)?
+static bool on_p8(const void* A, int lda, const void* W, const void* C, int ldc, int M, int N, int K, bool stream_out) {
+    GemmArgs g{};
+    g.A = A; g.W = W; g.C = const_cast<void*>(C); g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.out_f16 = stream_out ? 1 : 0;
+    return gemm_uses_p8(g, false, false);
+}
 // LayerNorm of stream rows x -> operand copy y_t (compute dtype) [+ stream copy y_s]
 static int ln_stream(gitmi_engine* e, hipStream_t s, const void* x, int ldx, const float* gamma, const float* beta, float eps,
                      void* y_t, int ld_t, void* y_s, int ld_s, int rows, int D) {
@@ -333,6 +387,9 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     e->Kp = 3 * c.patch * c.patch;
     e->Kp_pad = round_up(e->Kp, 64);
     e->stream_f16 = !e->f32;
+#ifdef GITMI_OPS_F16
+    e->ln_fold = !e->f32 && c.vit_width % 256 == 0 && c.dec_hidden % 256 == 0;
+#endif
 #ifdef GITMI_EXPERIMENT
     // measurement builds only (libgitmi_exp.so, `make exp`): kernel-shape overrides and work-skipping switches for A/B runs
     // and timing decompositions.  The product libraries read no environment.
@@ -354,6 +411,8 @@ extern "C" int gitmi_create(const gitmi_config* cfg, int device, gitmi_engine** 
     if (const char* env = getenv("GITMI_STREAM_F16")) e->stream_f16 = !e->f32 && atoi(env) != 0;
     if (const char* env = getenv("GITMI_GEMM_IMPL")) set_gemm_impl(atoi(env));
 #endif
+    e->ln_fold = e->ln_fold && e->stream_f16;
+    e->ln_fold_ready = e->ln_fold;
     if (attn_decode_configure() != hipSuccess) { delete e; return fail("hipFuncSetAttribute failed"); }
     *out = e;
     return 0;
@@ -518,6 +577,15 @@ static int alloc_workspaces(gitmi_engine* e) {
     RCK(dev_alloc(e, &e->v_ctx, Mv * D * esz));
     RCK(dev_alloc(e, &e->v_u, Mv * 4 * D * esz));
     RCK(dev_alloc(e, &e->feats, Mp * D * esz));
+    if (e->ln_fold_ready) {
+        // [row][4] (sum, sumsq) per 256-column tile; slots past the row width stay zero for ever
+        RCK(dev_alloc_t(e, &e->v_part, Mv * 4));
+        RCK(dev_alloc_t(e, &e->p_part[0], Mp * 4));
+        RCK(dev_alloc_t(e, &e->p_part[1], Mp * 4));
+        HIPCK(hipMemset(e->v_part, 0, Mv * 4 * sizeof(float2)));
+        HIPCK(hipMemset(e->p_part[0], 0, Mp * 4 * sizeof(float2)));
+        HIPCK(hipMemset(e->p_part[1], 0, Mp * 4 * sizeof(float2)));
+    }
     RCK(dev_alloc_t(e, &e->p_y, Mp * d));
     RCK(dev_alloc_t(e, &e->p_hf, Mp * d));
     RCK(dev_alloc(e, &e->p_ht, Mp * d * esz));
@@ -612,9 +680,10 @@ static inline float bf16_round(float f) {
 }
 #endif
 // W [rows, K], bias [rows], LayerNorm (gamma, beta) [K] in front of it  ->  device W' (bf16), folded bias, column sums
+// frag: fragment-major packing for the decode chain; else row-major for gemm_p8_kernel
 static int fold_layernorm(gitmi_engine* e, const std::vector<float>& W, const std::vector<float>& bias,
                           const std::vector<float>& gamma, const std::vector<float>& beta, int64_t rows, int K,
-                          void** Wf, float** bf, float** cs) {
+                          void** Wf, float** bf, float** cs, bool frag = true) {
     std::vector<float> wf((size_t)rows * K), b2((size_t)rows), c2((size_t)rows);
     float amax = 0.f;
     for (int64_t n = 0; n < rows; ++n) {
@@ -630,16 +699,17 @@ static int fold_layernorm(gitmi_engine* e, const std::vector<float>& W, const st
         c2[n] = (float)sum;
         b2[n] = (float)cst;
     }
-    RCK(operand_range_check(e, "a decoder matrix with its LayerNorm gain folded in (W . gamma)", amax));
+    RCK(operand_range_check(e, "a matrix with the LayerNorm gain in front of it folded in (W . gamma)", amax));
     const int64_t rows_pad = (rows + 127) / 128 * 128;       // the vocabulary head reads bias / colsum a workgroup (128 columns) at a time
     RCK(dev_alloc(e, Wf, (size_t)rows_pad * K * 2));
     float* tmp = nullptr;
     void* tmp_b = nullptr;
     HIPCK(hipMalloc((void**)&tmp, wf.size() * 4));
-    hipError_t err = hipMalloc(&tmp_b, wf.size() * 2);
+    hipError_t err = hipSuccess;
+    if (frag) err = hipMalloc(&tmp_b, wf.size() * 2);
     if (err == hipSuccess) err = hipMemcpy(tmp, wf.data(), wf.size() * 4, hipMemcpyHostToDevice);
-    if (err == hipSuccess) err = launch_convert_pad(tmp, tmp_b, false, (size_t)rows, K, K, 0);
-    if (err == hipSuccess) err = launch_frag_pack(tmp_b, *Wf, (int)rows, (int)rows_pad, K, 0);
+    if (err == hipSuccess) err = launch_convert_pad(tmp, frag ? tmp_b : *Wf, false, (size_t)rows, K, K, 0);
+    if (err == hipSuccess && frag) err = launch_frag_pack(tmp_b, *Wf, (int)rows, (int)rows_pad, K, 0);
     if (err == hipSuccess) err = hipDeviceSynchronize();
     hipFree(tmp);
     if (tmp_b) hipFree(tmp_b);
@@ -707,6 +777,57 @@ static int fold_decoder(gitmi_engine* e) {
     RCK(host_vec(e, "textual.output.weight", (size_t)V * d, &w));
     RCK(host_vec(e, "textual.output.bias", V, &bi));
     RCK(fold_layernorm(e, *w, *bi, *g, *b, V, d, &e->out_w_f, &e->out_b_f, &e->cs_out));
+    return 0;
+}
+
+// encoder and prefill GEMMs behind a LayerNorm (e->ln_fold): row-major folded copies next to the plain ones (small batches and
+// shapes outside gemm_p8_kernel's rules keep the LayerNorm launches and the plain matrices)
+static int fold_encoder_prefill(gitmi_engine* e) {
+    const gitmi_config& c = e->cfg;
+    const int D = c.vit_width, d = c.dec_hidden, f = c.dec_ffn;
+    const std::vector<float>*g, *b, *w, *bi;
+    for (int i = 0; i < c.vit_layers; ++i) {
+        const std::string pre = "image_encoder.transformer.resblocks." + std::to_string(i) + ".";
+        VitLayerW& L = e->vit[i];
+        RCK(host_vec(e, pre + "ln_1.weight", D, &g));
+        RCK(host_vec(e, pre + "ln_1.bias", D, &b));
+        RCK(host_vec(e, pre + "attn.in_proj_weight", (size_t)3 * D * D, &w));
+        RCK(host_vec(e, pre + "attn.in_proj_bias", (size_t)3 * D, &bi));
+        RCK(fold_layernorm(e, *w, *bi, *g, *b, 3 * D, D, &L.wqkv_f, &L.bqkv_f, &L.cs_qkv, false));
+        RCK(host_vec(e, pre + "ln_2.weight", D, &g));
+        RCK(host_vec(e, pre + "ln_2.bias", D, &b));
+        RCK(host_vec(e, pre + "mlp.c_fc.weight", (size_t)4 * D * D, &w));
+        RCK(host_vec(e, pre + "mlp.c_fc.bias", (size_t)4 * D, &bi));
+        RCK(fold_layernorm(e, *w, *bi, *g, *b, 4 * D, D, &L.w1_f, &L.b1_f, &L.cs_1, false));
+    }
+    const std::string base = "textual.transformer.encoder.layer.";
+    for (int i = 0; i < c.dec_layers; ++i) {
+        const std::string pre = base + std::to_string(i) + ".";
+        DecLayerW& L = e->dec[i];
+        if (i == 0) {
+            RCK(host_vec(e, "textual.visual_projection.1.weight", d, &g));
+            RCK(host_vec(e, "textual.visual_projection.1.bias", d, &b));
+        } else {
+            const std::string prev = base + std::to_string(i - 1) + ".";
+            RCK(host_vec(e, prev + "output.LayerNorm.weight", d, &g));
+            RCK(host_vec(e, prev + "output.LayerNorm.bias", d, &b));
+        }
+        std::vector<float> wq((size_t)3 * d * d), bq((size_t)3 * d);
+        const char* names[3] = {"query", "key", "value"};
+        for (int j = 0; j < 3; ++j) {
+            RCK(host_vec(e, pre + "attention.self." + names[j] + ".weight", (size_t)d * d, &w));
+            RCK(host_vec(e, pre + "attention.self." + names[j] + ".bias", d, &bi));
+            std::copy(w->begin(), w->end(), wq.begin() + (size_t)j * d * d);
+            std::copy(bi->begin(), bi->end(), bq.begin() + (size_t)j * d);
+        }
+        RCK(fold_layernorm(e, wq, bq, *g, *b, 3 * d, d, &L.wqkv_pf, &L.bqkv_pf, &L.cs_qkv_p, false));
+        if (i + 1 == c.dec_layers) break;            // the last layer's image rows stop at K / V
+        RCK(host_vec(e, pre + "attention.output.LayerNorm.weight", d, &g));
+        RCK(host_vec(e, pre + "attention.output.LayerNorm.bias", d, &b));
+        RCK(host_vec(e, pre + "intermediate.dense.weight", (size_t)f * d, &w));
+        RCK(host_vec(e, pre + "intermediate.dense.bias", f, &bi));
+        RCK(fold_layernorm(e, *w, *bi, *g, *b, f, d, &L.w1_pf, &L.b1_pf, &L.cs_1_p, false));
+    }
     return 0;
 }
 
@@ -793,6 +914,7 @@ extern "C" int gitmi_finalize_weights(gitmi_engine* e) {
     e->dec_weight_bytes = wbytes;
     if (!e->f32 && d % 32 == 0 && f % 32 == 0 && d <= 768 && V <= 32768) RCK(fold_decoder(e));      // the bf16 decode chain (else: generic GEMM + LayerNorm launches)
     else e->skinny = false;
+    if (e->ln_fold_ready) RCK(fold_encoder_prefill(e));
     e->host_w.clear();
     RCK(alloc_workspaces(e));
     HIPCK(hipDeviceSynchronize());
@@ -809,7 +931,7 @@ extern "C" int gitmi_clone(gitmi_engine* src, gitmi_engine** out) {
     if (!src->finalized) return fail("gitmi_clone: source weights not finalized");
     HIPCK(hipSetDevice(src->device));
     gitmi_engine* e = new gitmi_engine();
-    e->cfg = src->cfg; e->device = src->device; e->f32 = src->f32; e->esz = src->esz; e->stream_f16 = src->stream_f16;
+    e->cfg = src->cfg; e->device = src->device; e->f32 = src->f32; e->esz = src->esz; e->stream_f16 = src->stream_f16; e->ln_fold = src->ln_fold; e->ln_fold_ready = src->ln_fold_ready;
     e->attn_impl = src->attn_impl; e->Kp = src->Kp; e->Kp_pad = src->Kp_pad;
     // a clone starts at the native resolution (its own gitmi_set_image_shape state and resized table)
     e->N_nat = e->N = src->N_nat; e->g_nat = e->gh = e->gw = src->g_nat; e->H = e->W = src->cfg.image_size;
@@ -874,11 +996,23 @@ static int encode_frames_impl(gitmi_engine* e, const float* const* frames, int F
                             e->H, e->W, c.patch, e->Kp, e->Kp_pad, s));
     RCK(gemm(e, s, e->patches, e->Kp_pad, e->conv_w, nullptr, nullptr, 0, e->patch_out, D, true, BI * g2, D, e->Kp_pad, 0,
              TAG_GEMM_VIT));
-    HIPCK(launch_vit_assemble_ln(e->patch_out, e->cls, e->pos_cur, e->lnpre_g, e->lnpre_b, 1e-5f, e->v_x, e->stream_f16, BI, N, D, s));
+    // LayerNorm folding (fp16-operand build): ln_1 / ln_2 disappear into the GEMMs either side of them when every GEMM of the
+    // pass runs on gemm_p8_kernel (more than 512 rows); the stream rows v_x are then the QKV / c_fc GEMMs' A operand as they are
+    const bool fold = e->ln_fold && on_p8(e->v_x, D, e->vit[0].wqkv_f, e->v_qkv, 3 * D, M, 3 * D, D, false) &&
+                      on_p8(e->v_x, D, e->vit[0].w1_f, e->v_u, 4 * D, M, 4 * D, D, false) &&
+                      on_p8(e->v_ctx, D, e->vit[0].wo, e->v_x, D, M, D, D, true) && on_p8(e->v_u, 4 * D, e->vit[0].w2, e->v_x, D, M, D, 4 * D, true);
+    LnRef vln;
+    vln.part = e->v_part; vln.nparts = D / 256; vln.D = D; vln.eps = 1e-5f;
+    HIPCK(launch_vit_assemble_ln(e->patch_out, e->cls, e->pos_cur, e->lnpre_g, e->lnpre_b, 1e-5f, e->v_x, e->stream_f16, BI, N, D,
+                                 fold ? e->v_part : nullptr, D / 256, s));
     for (int l = 0; l < c.vit_layers; ++l) {
         const VitLayerW& L = e->vit[l];
-        RCK(ln_stream(e, s, e->v_x, D, L.ln1g, L.ln1b, 1e-5f, e->v_h, D, nullptr, 0, M, D));
-        RCK(gemm(e, s, e->v_h, D, L.wqkv, L.bqkv, nullptr, 0, e->v_qkv, 3 * D, e->f32, M, 3 * D, D, 0, TAG_GEMM_VIT));
+        if (fold) {
+            RCK(gemm_ln(e, s, e->v_x, D, L.wqkv_f, L.bqkv_f, L.cs_qkv, vln, e->v_qkv, 3 * D, M, 3 * D, D, 0, TAG_GEMM_VIT));
+        } else {
+            RCK(ln_stream(e, s, e->v_x, D, L.ln1g, L.ln1b, 1e-5f, e->v_h, D, nullptr, 0, M, D));
+            RCK(gemm(e, s, e->v_h, D, L.wqkv, L.bqkv, nullptr, 0, e->v_qkv, 3 * D, e->f32, M, 3 * D, D, 0, TAG_GEMM_VIT));
+        }
         AttnFullArgs a{};
         a.q = e->v_qkv;
         a.k = (char*)e->v_qkv + (size_t)D * e->esz;
@@ -888,6 +1022,13 @@ static int encode_frames_impl(gitmi_engine* e, const float* const* frames, int F
         a.ldo = D;
         a.N = N; a.H = c.vit_heads; a.scale = 0.125f;
         HIPCK(launch_attn_full(a, BI, e->f32, e->attn_impl, s));
+        if (fold) {     // pre-norm blocks: the residual is the raw stream; every producer leaves the partials of its rows
+            RCK(gemm_stream_part(e, s, e->v_ctx, D, L.wo, L.bo, e->v_x, D, nullptr, e->v_x, D, e->v_part, M, D, D, TAG_GEMM_VIT));
+            RCK(gemm_ln(e, s, e->v_x, D, L.w1_f, L.b1_f, L.cs_1, vln, e->v_u, 4 * D, M, 4 * D, D, 1, TAG_GEMM_VIT));
+            RCK(gemm_stream_part(e, s, e->v_u, 4 * D, L.w2, L.b2, e->v_x, D, nullptr, e->v_x, D, l + 1 < c.vit_layers ? e->v_part : nullptr,
+                                 M, D, 4 * D, TAG_GEMM_VIT));
+            continue;
+        }
         RCK(gemm_stream(e, s, e->v_ctx, D, L.wo, L.bo, e->v_x, D, e->v_x, D, M, D, D, TAG_GEMM_VIT));
         RCK(ln_stream(e, s, e->v_x, D, L.ln2g, L.ln2b, 1e-5f, e->v_h, D, nullptr, 0, M, D));
         RCK(gemm(e, s, e->v_h, D, L.w1, L.b1, nullptr, 0, e->v_u, 4 * D, e->f32, M, 4 * D, D, 1, TAG_GEMM_VIT));
@@ -930,6 +1071,51 @@ static int prefill_impl(gitmi_engine* e, hipStream_t s) {
     const int d = c.dec_hidden, ffn = c.dec_ffn, D = c.vit_width;
     const int B = e->cur_B, Nimg = e->cur_Nimg, M = B * Nimg;
     SpanGuard phase(e, s, TAG_PREFILL, 0);
+    const bool fold = e->ln_fold && on_p8(e->feats, D, e->vp_w, e->p_y, d, M, d, D, true) &&
+                      on_p8(e->p_y, d, e->dec[0].wqkv_pf, e->img_kv[0], 3 * d, M, 3 * d, d, false) &&
+                      on_p8(e->p_y, d, e->dec[0].wqkv_pf, e->img_kv[0], 3 * d, M, 2 * d, d, false) &&
+                      (c.dec_layers < 2 || (on_p8(e->p_y, d, e->dec[0].w1_pf, e->p_u, ffn, M, ffn, d, false) &&
+                                            on_p8(e->p_ctx, d, e->dec[0].wo, e->p_y, d, M, d, d, true) &&
+                                            on_p8(e->p_u, ffn, e->dec[0].w2, e->p_y, d, M, d, ffn, true)));
+    if (fold) {
+        // Post-norm layers with every LayerNorm folded: p_y holds the RAW sums (dense + residual) in place, the consumer GEMMs
+        // read it as their A operand, and the residual LayerNorm(previous raw row) is rebuilt inside the next producer's
+        // epilogue from the partials of the previous producer (ping-pong: tiles of one row run in different workgroups).
+        int cur = 0;
+        LnRef ln;                   // the LayerNorm that stands between p_y and its consumers right now
+        ln.nparts = d / 256; ln.D = d;
+        RCK(gemm_stream_part(e, s, e->feats, D, e->vp_w, e->vp_b, nullptr, 0, nullptr, e->p_y, d, e->p_part[cur], M, d, D, TAG_GEMM_OTHER));
+        ln.part = e->p_part[cur]; ln.eps = 1e-5f; ln.gamma = e->vp_lng; ln.beta = e->vp_lnb;
+        for (int l = 0; l < c.dec_layers; ++l) {
+            const DecLayerW& L = e->dec[l];
+            if (l + 1 == c.dec_layers) {      // only K and V of the last layer's image rows are ever read
+                RCK(gemm_ln(e, s, e->p_y, d, (char*)L.wqkv_pf + (size_t)d * d * e->esz, L.bqkv_pf + d, L.cs_qkv_p + d, ln,
+                            (char*)e->img_kv[l] + (size_t)d * e->esz, 3 * d, M, 2 * d, d, 0, TAG_GEMM_OTHER));
+                RCK(kv_repack(e, l, B, Nimg, s));
+                break;
+            }
+            RCK(gemm_ln(e, s, e->p_y, d, L.wqkv_pf, L.bqkv_pf, L.cs_qkv_p, ln, e->img_kv[l], 3 * d, M, 3 * d, d, 0, TAG_GEMM_OTHER));
+            RCK(kv_repack(e, l, B, Nimg, s));
+            AttnFullArgs a{};
+            a.q = e->img_kv[l];
+            a.k = (char*)e->img_kv[l] + (size_t)d * e->esz;
+            a.v = (char*)e->img_kv[l] + (size_t)2 * d * e->esz;
+            a.out = e->p_ctx;
+            a.ldq = a.ldk = a.ldv = 3 * d;
+            a.ldo = d;
+            a.N = Nimg; a.H = c.dec_heads; a.scale = 0.125f;
+            HIPCK(launch_attn_full(a, B, e->f32, e->attn_impl, s));
+            RCK(gemm_stream_part(e, s, e->p_ctx, d, L.wo, L.bo, e->p_y, d, &ln, e->p_y, d, e->p_part[cur ^ 1], M, d, d, TAG_GEMM_OTHER));
+            cur ^= 1;
+            ln.part = e->p_part[cur]; ln.eps = 1e-12f; ln.gamma = L.lnag; ln.beta = L.lnab;
+            RCK(gemm_ln(e, s, e->p_y, d, L.w1_pf, L.b1_pf, L.cs_1_p, ln, e->p_u, ffn, M, ffn, d, 2, TAG_GEMM_OTHER));
+            RCK(gemm_stream_part(e, s, e->p_u, ffn, L.w2, L.b2, e->p_y, d, &ln, e->p_y, d, e->p_part[cur ^ 1], M, d, ffn, TAG_GEMM_OTHER));
+            cur ^= 1;
+            ln.part = e->p_part[cur]; ln.eps = 1e-12f; ln.gamma = L.lnog; ln.beta = L.lnob;
+        }
+        e->have_prefill = true;
+        return 0;
+    }
     RCK(gemm_stream(e, s, e->feats, D, e->vp_w, e->vp_b, nullptr, 0, e->p_y, d, M, d, D, TAG_GEMM_OTHER));
     RCK(ln_stream(e, s, e->p_y, d, e->vp_lng, e->vp_lnb, 1e-5f, e->p_ht, d, e->p_hf, d, M, d));
     for (int l = 0; l < c.dec_layers; ++l) {
@@ -1656,6 +1842,22 @@ extern "C" int gitmi_set_shared_device(gitmi_engine* e, int on) {
         HIPCK(hipSetDevice(e->device));
         HIPCK(hipDeviceSynchronize());
         e->shared_device = on != 0;
+        destroy_graph(e);
+    }
+    return 0;
+}
+// LayerNorm folding of the encoder / prefill passes (fp16-operand build, on by default there): off = every LayerNorm is a launch
+// that materialises its output, as in the bf16 build.  Results differ by rounding only (one rounding of the normalised
+// rows less with the fold); the switch exists for A/B timing and for the parity tests that hold both forms to the same bound.
+extern "C" int gitmi_set_ln_fold(gitmi_engine* e, int on) {
+    if (!e) return fail("null engine");
+    if (on && !e->ln_fold_ready)
+        return fail("gitmi_set_ln_fold: not available (needs the fp16-operand library, the 16-bit engine mode and hidden sizes that are multiples of 256)");
+    if ((on != 0) != e->ln_fold) {
+        HIPCK(hipSetDevice(e->device));
+        HIPCK(hipDeviceSynchronize());
+        e->ln_fold = on != 0;
+        e->have_feats = e->have_prefill = false;
         destroy_graph(e);
     }
     return 0;

@@ -318,13 +318,18 @@ static bool gemm_fast_operands(const GemmArgs& g, bool in_f32, bool out_f32) {
 // (fp32 parity mode, small batches, odd shapes).  The three generations in between (128x128 direct-to-LDS, 256x128 and
 // 256x256x32 rings) were removed in round 4: no BASELINE configuration reached them any more.
 // impl (measurement builds: gitmi_debug_set_gemm_impl): -1 auto | 0 tile kernel only | 9 LDS-DMA kernel wherever it can run
+bool gemm_uses_p8(const GemmArgs& g, bool in_f32, bool out_f32) {
+    const bool fast_ok = g_gemm_impl != 0 && gemm_fast_operands(g, in_f32, out_f32) && gemm_p8_supports(g);
+    return fast_ok && (g.M > 512 || g_gemm_impl == 9);
+}
+
 hipError_t launch_gemm(const GemmArgs& g_in, bool in_f32, bool out_f32, hipStream_t s) {
     GemmArgs g = g_in;
     g.dbg = g_gemm_dbg;
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (g.out_f16 && (in_f32 || out_f32 || g.K % 64 != 0)) return hipErrorInvalidValue;     // fp16 residual-stream rows: bf16 engine mode
-    const bool fast_ok = g_gemm_impl != 0 && gemm_fast_operands(g, in_f32, out_f32) && gemm_p8_supports(g);
-    if (fast_ok && (g.M > 512 || g_gemm_impl == 9)) return launch_gemm_p8(g, out_f32, s);
+    if (gemm_uses_p8(g, in_f32, out_f32)) return launch_gemm_p8(g, out_f32, s);
+    if (g.ln_part || g.part_out || g.res_part) return hipErrorInvalidValue;                 // folded LayerNorm: gemm_p8_kernel only
     if (g.out_f16) return launch_gemm_tiles<bf16_t, f16_t>(g, s);
     if (in_f32) {
         if (g.K % 16 != 0) return hipErrorInvalidValue;

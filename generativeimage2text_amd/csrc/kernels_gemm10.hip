@@ -66,6 +66,32 @@ __device__ __forceinline__ float add_unfused(float a, float b) {
     return a + b;
 }
 
+// Sums of two values over each 32-lane half of a wave, valid in lanes 16..31 / 48..63: five v_add_f32 with a DPP source per
+// value (two quad permutes, two row rotations, then row 0's / row 2's total broadcast into the row above it) -- no LDS
+// traffic, no v_mov per step (what update_dpp + add compiles to: 2.9 -> us per launch measured, profiles/r06_i_*).  The two
+// chains are interleaved; a DPP read needs two wait states after the VALU write of its source (the other chain's add + s_nop 0).
+// The summation order is fixed.
+__device__ __forceinline__ void half_wave_sum2_hi(float& a, float& b) {
+    asm volatile(
+        "s_nop 1\n\t"                  // the compiler does not know these are DPP reads: its own writes of a / b may be 1 instruction old
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b));
+}
+
 // epilogue barrier: orders this workgroup's LDS traffic only.  __syncthreads() would also wait for every outstanding
 // global store of the wave (vmcnt(0)) -- the slab just written out -- before the next slab may even be staged.
 #define P8_LDS_BARRIER()                                   \
@@ -104,8 +130,14 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // that decides the rounds: the N = 768 GEMMs are 150 tiles of 256 rows (59 % of the CUs for one long round) but 237 tiles
 // of 160 rows (one round at 0.625 of the length).  Quadrants (1, *) then carry MH1 / 32 row fragments instead of MH / 32.
 // EPI (fp32 outputs only): 1 direct epilogue from the accumulators, 0 the LDS-staged one (A/B: dbg bit 256)
-template <typename TOut, int ACT, int DBG = 0, int MH = 128, int EPI = 1, int MH1 = MH>
+// LNF (round 6, fp16-operand build): LayerNorm folded into the GEMMs either side of it.  1 = CONSUMER: A is the raw fp16 stream,
+// W carries the gain, and the epilogue applies rstd_m (acc - mean_m colsum_n) + folded bias from the row partials the producer left.
+// 2 = PRODUCER (fp16 stream rows out): per row and 256-column tile the (sum, sumsq) of the values as stored, and -- post-norm
+// layers -- the residual rebuilt as LayerNorm(raw rows) from the previous partials.  No normalised tensor is materialised and the
+// encoder / prefill passes lose their LayerNorm launches (36 -> 1 per request on GIT_BASE).
+template <typename TOut, int ACT, int DBG = 0, int MH = 128, int EPI = 1, int MH1 = MH, int LNF = 0>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
+    static_assert(LNF == 0 || sizeof(TOut) == 2, "LayerNorm folding: 16-bit outputs only");
     static_assert(MH % 32 == 0 && MH1 % 32 == 0 && MH1 <= MH && MH <= 128, "half tiles: multiples of 32 rows, second <= first");
     constexpr int BM = MH + MH1, MI = MH / 32, MI1 = MH1 / 32;   // row fragments of a quadrant of half 0 / half 1
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
@@ -195,15 +227,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
     const int a_rd1 = grp * (MH1 / 2) * 128 + rowpart + HALF_BYTES;      //                     + i*2048 + ch  (half 1)
     const int w_rd = SLOT_B0 + wc * 32 * 128 + rowpart;            // + half*HALF_BYTES + j*2048 + ch
 
-    f32x4_t acc[2][2][2][MI];  // [qm][qn][j: n-frag][i: m-frag]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < MI; ++i) acc[a][b][j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[2][2][2][MI];  // [qm][qn][j: n-frag][i: m-frag]; zeroed right before the K loop (after the LNF 1 statistics
+                               // have been reduced: their raw partials and the accumulators are never live together)
 
     bf16x8_t af[MI][2], wf0[2][2], wf1[2][2];
 
@@ -273,10 +298,61 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         P8_BARRIER();
     };
 
+    // LNF 1: (mean, rstd) of this lane's 2 x MI output rows.  The row partials ([row][4] (sum, sumsq), 32 B per row) travel the
+    // way the tiles do: ONE direct-to-LDS load per wave, issued before the first half tiles -- wave (grp, wc) fetches the 2 x 16
+    // rows of fragment i = wc of its group's rows -- into the A1 slot of buffer 1, which the pipeline does not refill before
+    // phase 2 of K tile 0, two barriers after the last read below.  Being the oldest request it has landed when the
+    // prologue's vmcnt(8) is over (a register load would make the compiler wait for vmcnt(0): every prefetch in flight).  After
+    // the barrier lane group lg reduces rows (qm, i = lg) and the lane groups exchange (mean, rstd) by ds_bpermute (crossbar
+    // only): 4 x MI registers through the K loop, ~40 instructions in front of it.
+    float lmean[2][MI], lrstd[2][MI];
+    unsigned char* const ln_lds = smem + BUF_BYTES + SLOT_A1;
+    if constexpr (LNF == 1) {
+        const int r = lane >> 1, qm = r >> 4, l = r & 15;                        // 32 rows x two 16-byte halves
+        const int MHq = qm ? MH1 : MH, MIq = qm ? MI1 : MI;
+        const int ii = wc < MIq ? wc : MIq - 1;
+        const int m = m0 + qm * MH + grp * (MHq / 2) + ii * 16 + l;
+        const int mc = m < g.M ? m : g.M - 1;
+        const char* src = reinterpret_cast<const char*>(g.ln_part) + (size_t)mc * 32 + (lane & 1) * 16;
+        __builtin_amdgcn_global_load_lds((const void*)src, (lds_void_t*)(ln_lds + wave * 1024), 16, 0, 0);
+    }
+    auto ln_rows = [&]() {
+        if constexpr (LNF == 1) {
+#pragma unroll
+            for (int qm = 0; qm < 2; ++qm) {
+                const int MIq = qm ? MI1 : MI;
+                const int ii = lg < MIq ? lg : MIq - 1;
+                const unsigned char* pr = ln_lds + (grp * 4 + ii) * 1024 + (qm * 16 + l15) * 32;
+                const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(pr);
+                const f32x4_t p1 = *reinterpret_cast<const f32x4_t*>(pr + 16);
+                const float sx = (p0[0] + p0[2]) + (p1[0] + p1[2]);
+                const float sq = (p0[1] + p0[3]) + (p1[1] + p1[3]);
+                const float mean = sx * g.ln_inv_d;
+                const float rstd = rsqrtf(fmaxf(sq * g.ln_inv_d - mean * mean, 0.f) + g.ln_eps);
+#pragma unroll
+                for (int i = 0; i < MIq; ++i) {
+                    lmean[qm][i] = __shfl(mean, i * 16 + l15, 64);
+                    lrstd[qm][i] = __shfl(rstd, i * 16 + l15, 64);
+                    // pin the results HERE (first use is in the epilogue: the compiler would sink the arithmetic there)
+                    asm volatile("" : "+v"(lmean[qm][i]), "+v"(lrstd[qm][i]));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     const int nk = g.K / BK;                                       // >= 2 (launcher)
     issue(0, 0, 0); issue(1, 0, 0); issue(1, 1, 0); issue(0, 1, 0); issue(0, 0, 1); issue(1, 0, 1);
-    wait_vm<8>();                                                  // A0(0), B0(0) of this wave have landed
+    wait_vm<8>();                                                  // A0(0), B0(0) of this wave have landed (and, LNF 1, its row partials)
     P8_BARRIER();
+    ln_rows();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[a][b][j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (grp == 1) P8_BARRIER();                                    // group 1 runs one barrier behind
     stamp(1);
     for (int t = 0; t < nk - 2; ++t) ktile(std::integral_constant<int, 0>{}, t);
@@ -317,6 +393,20 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j)
             bias4[qn][j] = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + n0 + qn * 128 + wc * 32 + j * 16 + lg * 4)
                                   : f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // folded LayerNorm of the A rows (LNF 1): column sums of this lane's columns ((mean, rstd) of its rows: taken before the K loop)
+    f32x4_t cs4[2][2];
+    if constexpr (LNF == 1) {
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                cs4[qn][j] = *reinterpret_cast<const f32x4_t*>(g.ln_colsum + n0 + qn * 128 + wc * 32 + j * 16 + lg * 4);
+    }
+    auto ln_apply = [&](float a, int qm, int qn, int j, int i, int r) -> float {
+        if constexpr (LNF == 1) return lrstd[qm][i] * fmaf(-lmean[qm][i], cs4[qn][j][r], a);
+        else return a;
+    };
 
     if constexpr (sizeof(TOut) == 4 && EPI == 1) {
         // ---- direct fp32 epilogue.  acc[qm][qn][j][i][r] is C[m0 + qm*MH + grp*MH/2 + i*16 + l15][n0 + qn*128 +
@@ -367,6 +457,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
         return;
     }
 
+    float rgm[8], rbt[8];               // LNF 2, post-norm residual: gain / bias of this thread's 8 columns (the same in every slab row)
+    if constexpr (LNF == 2) {
+        if (g.res_part) {
+            ld8(g.res_gamma + n0 + (tid & 31) * 8, rgm);
+            ld8(g.res_beta + n0 + (tid & 31) * 8, rbt);
+        }
+    }
 #pragma unroll
     for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
@@ -382,7 +479,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                     for (int i = 0; i < MIq; ++i) {
                         float v[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = apply_act_t<ACT>(acc[qm][qn][j][i][r] + bias4[qn][j][r]);
+                        for (int r = 0; r < 4; ++r) v[r] = apply_act_t<ACT>(ln_apply(acc[qm][qn][j][i][r], qm, qn, j, i, r) + bias4[qn][j][r]);
                         TOut* p = ep + (grp * (MHq / 2) + i * 16 + l15) * EPS + nl;
                         if constexpr (sizeof(TOut) == 4) {
                             *reinterpret_cast<f32x4_t*>(p) = f32x4_t{v[0], v[1], v[2], v[3]};
@@ -410,6 +507,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                             v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
                         }
                         *reinterpret_cast<f32x4_t*>(C + (size_t)m * g.ldc + n) = v;
+                    } else if constexpr (LNF == 2) {
+                        // handled below (every lane takes part in the row reductions, rows past M included)
                     } else {
                         u32x4_t v = *reinterpret_cast<const u32x4_t*>(ep + row * EPS + cc * EPC);
                         if (g.res && !(DBG & 16)) {
@@ -444,6 +543,55 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
                             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(cp), "v"(v) : "memory");
                     }
                 }
+                if constexpr (LNF == 2) {
+                    // fp16 stream rows with their row partials: a row of the slab is the 32 chunks of one HALF wave
+                    static_assert(LNF != 2 || CPR == 32, "one stream row per half wave");
+                    const bool ok = m < g.M;
+                    const int mc = ok ? m : g.M - 1;
+                    u32x4_t v = *reinterpret_cast<const u32x4_t*>(ep + row * EPS + cc * EPC);
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) unpack2h(v[e], f[2 * e], f[2 * e + 1]);
+                    if (g.res) {
+                        float rs[8];
+                        const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const f16_t*>(g.res) + (size_t)mc * g.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) unpack2h(rr[e], rs[2 * e], rs[2 * e + 1]);
+                        if (g.res_part) {       // post-norm layer: the residual is LayerNorm(raw row), rebuilt here
+                            const f32x4_t* pp = reinterpret_cast<const f32x4_t*>(g.res_part + (size_t)mc * 4);
+                            const f32x4_t p0 = pp[0], p1 = pp[1];
+                            const float mean = ((p0[0] + p0[2]) + (p1[0] + p1[2])) * g.res_inv_d;
+                            const float rstd = rsqrtf(fmaxf(((p0[1] + p0[3]) + (p1[1] + p1[3])) * g.res_inv_d - mean * mean, 0.f) + g.res_eps);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) rs[e] = fmaf((rs[e] - mean) * rstd, rgm[e], rbt[e]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += rs[e];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = pack2h(f[2 * e], f[2 * e + 1]);
+                    }
+                    if (g.part_out) {           // statistics of the values AS STORED (what the consumer's MFMA will read)
+                        typedef __attribute__((ext_vector_type(2))) float f32x2_t;      // pairs: v_pk_add_f32 / v_pk_fma_f32
+                        f32x2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x0, x1;
+                            unpack2h(v[e], x0, x1);
+                            const f32x2_t x = {x0, x1};
+                            s2 += x;
+                            q2 = __builtin_elementwise_fma(x, x, q2);
+                        }
+                        float sx = s2[0] + s2[1], sq = q2[0] + q2[1];
+                        half_wave_sum2_hi(sx, sq);
+                        if (ok && cc == 16 && !(DBG & 1)) g.part_out[(size_t)m * 4 + tile_n] = float2{sx, sq};
+                    }
+                    if (ok && !(DBG & 1)) {
+                        TOut* cp = C + (size_t)m * g.ldc + n;
+                        // sc1 as for every 16-bit output; plain stores (the rows are the next GEMM's A operand) measured the same:
+                        // 53.3 vs 53.6 us for the consumer (profiles/r06_j_*)
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(cp), "v"(v) : "memory");
+                    }
+                }
             }
             P8_LDS_BARRIER();
         }
@@ -456,9 +604,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 
 }  // namespace
 
-template <typename TOut, int MH, int EPI = 1, int MH1 = MH>
+template <typename TOut, int MH, int EPI = 1, int MH1 = MH, int LNF = 0>
 static void launch_p8_t(const GemmArgs& g, hipStream_t s) {
-    if (g.dbg) {      // measurement builds (tools/gemm_dbg.py); act is ignored
+    if constexpr (LNF == 2) {       // stream rows: no activation
+        hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_NONE, 0, MH, EPI, MH1, LNF>), dim3(g.nwg), dim3(512), 0, s, g);
+        return;
+    } else {
+    if (g.dbg && LNF == 0) {      // measurement builds (tools/gemm_dbg.py); act is ignored
         if constexpr (MH == 128 && MH1 == 128) {
             switch (g.dbg) {
                 case 1: hipLaunchKernelGGL((gemm_p8_kernel<TOut, 0, 1>), dim3(g.nwg), dim3(512), 0, s, g); return;
@@ -478,11 +630,12 @@ static void launch_p8_t(const GemmArgs& g, hipStream_t s) {
     }
     switch (g.act) {
         case GITMI_ACT_QUICKGELU:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_QUICKGELU, 0, MH, EPI, MH1>), dim3(g.nwg), dim3(512), 0, s, g); break;
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_QUICKGELU, 0, MH, EPI, MH1, LNF>), dim3(g.nwg), dim3(512), 0, s, g); break;
         case GITMI_ACT_GELU_ERF:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_GELU_ERF, 0, MH, EPI, MH1>), dim3(g.nwg), dim3(512), 0, s, g); break;
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_GELU_ERF, 0, MH, EPI, MH1, LNF>), dim3(g.nwg), dim3(512), 0, s, g); break;
         default:
-            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_NONE, 0, MH, EPI, MH1>), dim3(g.nwg), dim3(512), 0, s, g); break;
+            hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_NONE, 0, MH, EPI, MH1, LNF>), dim3(g.nwg), dim3(512), 0, s, g); break;
+    }
     }
 }
 
@@ -545,6 +698,10 @@ int gemm_p8_cost(const GemmArgs& g, int bm) {
 
 template <int MH, int MH1>
 static void launch_p8_height(const GemmArgs& g, bool out_f32, bool staged, hipStream_t s) {
+#ifdef GITMI_OPS_F16        // LayerNorm folding: the stream rows ARE operands only when the operand type is fp16
+    if (g.ln_part) { launch_p8_t<bf16_t, MH, 1, MH1, 1>(g, s); return; }
+    if (g.part_out || g.res_part) { launch_p8_t<f16_t, MH, 1, MH1, 2>(g, s); return; }
+#endif
     if (g.out_f16) launch_p8_t<f16_t, MH, 1, MH1>(g, s);
     else if (!out_f32) launch_p8_t<bf16_t, MH, 1, MH1>(g, s);
     else if (staged) launch_p8_t<float, MH, 0, MH1>(g, s);
@@ -553,6 +710,15 @@ static void launch_p8_height(const GemmArgs& g, bool out_f32, bool staged, hipSt
 
 // g.out_f16: C (and the residual, if any) are f16_t rows -- the residual stream of the bf16 engine mode
 hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s) {
+    if (g.ln_part || g.part_out || g.res_part) {
+#ifndef GITMI_OPS_F16
+        return hipErrorInvalidValue;
+#endif
+        // consumer: 16-bit operand rows out, no residual; producer: fp16 stream rows out
+        if (g.ln_part && (out_f32 || g.out_f16 || g.res || !g.ln_colsum || g.ln_nparts < 1 || g.part_out || g.res_part)) return hipErrorInvalidValue;
+        if ((g.part_out || g.res_part) && (!g.out_f16 || out_f32 || g.act != 0 || g.N > 1024)) return hipErrorInvalidValue;
+        if (g.res_part && (!g.res || !g.res_gamma || !g.res_beta || g.res_nparts < 1)) return hipErrorInvalidValue;
+    }
     // tile height: the one with the lowest modelled launch time among 256 / 224 / 192 / 160 / 128 rows (ties: the taller tile,
     // it moves fewer operand bytes per FLOP).  dbg bits force a height (tests, A/B): 64 -> 192, 128 -> 256, 16384 -> 160,
     // 32768 -> 224, 65536 -> 128.

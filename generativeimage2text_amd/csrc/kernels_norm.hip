@@ -263,7 +263,8 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __res
                                                               const float* __restrict__ pos,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps,
-                                                              TS* __restrict__ X, int B, int N, int D) {
+                                                              TS* __restrict__ X, int B, int N, int D,
+                                                              float2* __restrict__ part, int nparts) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * N) return;
@@ -291,6 +292,23 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __res
     for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane + 64 * i;
         if (c < D) st<TS>(X + (size_t)row * D + c, (v[i] - mean) * rstd * gamma[c] + beta[c]);
+    }
+    // folded LayerNorm of the first block (kernels_gemm10.hip LNF): (sum, sumsq) of the row AS STORED in slot 0 of the row's
+    // four column-tile slots, zeros in the others
+    if (part) {
+        float sx = 0.f, sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                const float o = (float)(TS)((v[i] - mean) * rstd * gamma[c] + beta[c]);
+                sx += o;
+                sq = fmaf(o, o, sq);
+            }
+        }
+        sx = wave_sum(sx);
+        sq = wave_sum(sq);
+        if (lane < 4) part[(size_t)row * 4 + lane] = lane == 0 ? float2{sx, sq} : float2{0.f, 0.f};
     }
 }
 
@@ -462,14 +480,15 @@ hipError_t launch_pos_bicubic(const float* pos, float* out, int g, int gh, int g
 }
 
 hipError_t launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* gamma,
-                                  const float* beta, float eps, void* X, bool x_f16, int B, int N, int D, hipStream_t s) {
-    if (D > 64 * LN_MAXV) return hipErrorInvalidValue;
+                                  const float* beta, float eps, void* X, bool x_f16, int B, int N, int D, float2* part,
+                                  int nparts, hipStream_t s) {
+    if (D > 64 * LN_MAXV || (part && (!x_f16 || nparts < 1 || nparts > 64))) return hipErrorInvalidValue;
     if (x_f16)
         hipLaunchKernelGGL(vit_assemble_ln_kernel<f16_t>, dim3((B * N + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, gamma,
-                           beta, eps, (f16_t*)X, B, N, D);
+                           beta, eps, (f16_t*)X, B, N, D, part, nparts);
     else
         hipLaunchKernelGGL(vit_assemble_ln_kernel<float>, dim3((B * N + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, gamma,
-                           beta, eps, (float*)X, B, N, D);
+                           beta, eps, (float*)X, B, N, D, (float2*)nullptr, 0);
     return hipGetLastError();
 }
 

@@ -15,7 +15,18 @@ struct GemmArgs {
     int dbg;    // measurement builds only (gemm_p8_kernel): 1 no C stores, 2 no epilogue, 4 no MFMA, 8 no loads in loop
     int out_f16; // C and `res` are f16_t rows (residual stream of the bf16 engine mode); bf16 inputs, p8 + generic kernel only
     int shared;  // other contexts run beside this launch (serving schedule): tile choice by FLOP/byte, not by round fill
+    // ---- LayerNorm folded into the large-M GEMMs (gemm_p8_kernel, fp16-operand build; kernels_gemm10.hip) ----
+    // Row partials are [M][4] float2 (sum, sumsq), slot t = the 256-column tile t of the row (hidden sizes <= 1024; unused slots 0).
+    // consumer (QKV / c_fc / FFN1): A = the RAW fp16 residual-stream rows, W = f16(W . gamma), bias = beta W^T + b, and
+    //   C = act(rstd_m (A W^T - mean_m colsum) + bias); (mean, rstd) of row m from ln_part[m][0..4)
+    const float2* ln_part; int ln_nparts; const float* ln_colsum; float ln_inv_d, ln_eps;
+    // producer (N = hidden GEMMs writing stream rows): (sum, sumsq) of the STORED fp16 values of row m over the 256 columns
+    //   of tile t -> part_out[m][t]
+    float2* part_out;
+    // post-norm residual: `res` points at RAW rows, the residual added is LayerNorm(res) rebuilt from res_part / res_gamma / res_beta
+    const float2* res_part; int res_nparts; const float* res_gamma; const float* res_beta; float res_inv_d, res_eps;
 };
+bool gemm_uses_p8(const GemmArgs& g, bool in_f32, bool out_f32);   // would launch_gemm run this shape on gemm_p8_kernel?
 hipError_t launch_gemm(const GemmArgs& g, bool in_f32, bool out_f32, hipStream_t s);
 hipError_t launch_gemm_p8(GemmArgs g, bool out_f32, hipStream_t s);     // 256x256x64, half-tile pipeline, staggered wave groups
 bool gemm_p8_supports(const GemmArgs& g);
@@ -67,7 +78,8 @@ hipError_t launch_im2col(const float* img, void* out, bool out_f32, int B, int H
                          hipStream_t s);
 hipError_t launch_pos_bicubic(const float* pos, float* out, int g, int gh, int gw, int D, hipStream_t s);
 hipError_t launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* gamma,
-                                  const float* beta, float eps, void* X, bool x_f16, int B, int N, int D, hipStream_t s);
+                                  const float* beta, float eps, void* X, bool x_f16, int B, int N, int D, float2* part,
+                                  int nparts, hipStream_t s);   // part: row partials for the folded ln_1 of the first block (or nullptr)
 hipError_t launch_layernorm_s16(const void* x, int ldx, const float* gamma, const float* beta, float eps,
                                 const float* add_after, void* y_t, int ld_t, bool t_is_f32, void* y_s, int ld_s,
                                 int rows, int D, int map_n_in, int map_n_out, int map_off, hipStream_t s);

@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_op_vocab_topm", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
     "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after", "gitmi_op_sample_rows",
     "gitmi_search_done_count", "gitmi_set_trie", "gitmi_operand_dtype", "gitmi_set_shared_device", "gitmi_preprocess_batch",
+    "gitmi_set_ln_fold",
 ]
 # libgitmi_exp.so only (include/gitmi_experiment.h): schedules that measured slower than the default, debug hooks
 EXPERIMENT_SYMBOLS = [
@@ -117,6 +118,7 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     lib.gitmi_set_temporal_embedding.argtypes = [vp, i32]
     lib.gitmi_set_encode_after.argtypes = [vp, vp]
     lib.gitmi_set_shared_device.argtypes = [vp, i32]
+    lib.gitmi_set_ln_fold.argtypes = [vp, i32]
     lib.gitmi_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_attention.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
@@ -141,7 +143,7 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     for name in EXPORTED_SYMBOLS + (EXPERIMENT_SYMBOLS if operands == "exp" else []):
         if name not in ("gitmi_last_error", "gitmi_destroy"):
             getattr(lib, name).restype = C.c_int
-    if lib.gitmi_abi_version() != 8:
+    if lib.gitmi_abi_version() != 9:
         raise GitmiError("libgitmi.so ABI version mismatch")
     lib.gitmi_operand_dtype.restype = C.c_int
     if lib.gitmi_operand_dtype() != {"bf16": DTYPE_BF16, "f16": DTYPE_F16, "exp": DTYPE_BF16}[operands]:
@@ -493,6 +495,11 @@ class Engine:
         """on (default): frames come as a list -> frame i gets img_temperal_embedding[i]; off: a bare image tensor
         (decoder.py:845-857 adds the embedding only in the list branch)."""
         self._ck(self.lib.gitmi_set_temporal_embedding(self._h, 1 if on else 0))
+
+    def set_ln_fold(self, on: bool) -> None:
+        """fp16-operand library only: fold the encoder's / prefill's LayerNorms into the GEMMs either side of them (default
+        there) or run one LayerNorm launch per module.  Raises if `on` is asked of an engine that cannot fold."""
+        self._ck(self.lib.gitmi_set_ln_fold(self._h, 1 if on else 0))
 
     def set_graph(self, on: bool) -> None:
         self._ck(self.lib.gitmi_set_graph(self._h, 1 if on else 0))

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GITMI_ABI_VERSION 8
+#define GITMI_ABI_VERSION 9
 
 /* compute precision of GEMM/attention operands (accumulation, LayerNorm statistics,
  * softmax, residual stream and logits are fp32 in both modes) */
@@ -166,6 +166,13 @@ int  gitmi_set_encode_after(gitmi_engine* e, gitmi_engine* after);
  * column blocks (+1 %).
  * Results are bit-identical either way.  Clones inherit the setting of their source at clone time. */
 int  gitmi_set_shared_device(gitmi_engine* e, int on);
+/* (new, ABI 9) LayerNorm folding in the image encoder and the prefill -- replaces the LayerNorm modules of
+ * layers/CLIP/model.py:161-168,189-202 (ln_1 / ln_2) and layers/bert/modeling_bert.py:171-178,243-250 + layers/decoder.py:35
+ * (post-norm LayerNorms over the image rows) for passes of more than 512 rows in the fp16-operand library: the producer
+ * GEMM leaves (sum, sumsq) per row, the consumer GEMM reads the raw stream rows and applies the normalisation in its
+ * epilogue.  on = 1 is the default where it is available; on = 0 runs one LayerNorm launch per module instead (what
+ * libgitmi.so, the f32 mode and small batches always do).  Fails if on = 1 is asked of an engine that cannot fold. */
+int  gitmi_set_ln_fold(gitmi_engine* e, int on);
 
 /* ---- input resolution of the following encode/generate calls (default: image_size x image_size).
  * Replaces the run-time branch of VisualTransformer.forward for inputs that are not the native
