@@ -479,6 +479,15 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
     __shared__ int sel_src[SS_KMAX], sel_word[SS_KMAX];
     __shared__ float sel_score[SS_KMAX];
     __shared__ int s_nadd, s_add_slot[SS_CMAX * 2], s_add_row[SS_CMAX * 2];   // GENERATOR: hypotheses added this step (slot <- row)
+    // Per-sentence state of the search, staged by many threads at once (round 6): the bookkeeping of phase B is ONE thread
+    // walking a chain of dependent reads -- from global memory that was ~45 exposed round trips of a beam-4 step (36 us per
+    // launch); from LDS they cost a few cycles each.  What phase B changes is written back by the same thread.
+    __shared__ float s_score[SS_KMAX];
+    __shared__ int s_last[SS_KMAX];
+    __shared__ int s_done, s_hyp_n, s_hyp_cnt, s_stop;
+    __shared__ double s_hyp_worst, s_len_cur, s_len_last;
+    __shared__ double s_hscore[SS_NHMAX];
+    __shared__ int s_hseq[SS_NHMAX];
     __shared__ float s_part[8];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -491,6 +500,24 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
     const int M = st.kind == 0 ? (first ? k : pn) : (st.sampled ? pn : pn * k);   // candidates needed per row
 
     if (tid == 0) s_nadd = 0;
+    {   // staging loads: one thread per value, all in flight together with the candidate lists of phase A
+        const int t2 = tid - 64;                           // wave 1 (its lanes are idle until their row's lists arrive anyway)
+        if (t2 >= 0 && t2 < k) {
+            s_score[t2] = st.score[src][b * k + t2];
+            s_last[t2] = cur_len > 0 ? ids_at(st, src, b * k + t2, cur_len - 1) : -1;
+        }
+        if (t2 == 8) s_done = st.done[b];
+        if (t2 == 9) s_hyp_n = st.hyp_n[b];
+        if (t2 == 10) s_hyp_cnt = st.hyp_cnt[b];
+        if (t2 == 11) s_stop = st.stop[b];
+        if (t2 == 12) s_hyp_worst = st.hyp_worst[b];
+        if (t2 == 13) s_len_cur = st.len_norm[cur_len];
+        if (t2 == 14) s_len_last = st.len_norm[T - 1];
+        if (t2 >= 16 && t2 < 16 + st.nh) {
+            s_hscore[t2 - 16] = st.hyp_score[(size_t)b * st.nh + t2 - 16];
+            s_hseq[t2 - 16] = st.hyp_seq[(size_t)b * st.nh + t2 - 16];
+        }
+    }
 
     // ---- phase A: merged top-M log-probabilities of every beam row of the sentence.  ONE WAVE PER ROW (rows j = wave,
     // wave + 4): a lane holds the sorted partial lists of parts lane, lane + 64, lane + 128, lane + 192 in registers, a
@@ -572,11 +599,11 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
             for (int j = 0; j < k; ++j) { sel_src[j] = b * k + j; sel_word[j] = word; sel_score[j] = st.score[src][b * k + j]; }
         } else if (st.kind == 0) {
             // ---- AutoRegressiveBeamSearch -------------------------------------------------------------------
-            if (!first && st.stop[b] == 0) {
+            if (!first && s_stop == 0) {
                 // decoder.py:319: the loop stops once every beam's last token is EOS (later steps are idempotent)
                 int all_eos = 1;
                 for (int j = 0; j < k; ++j)
-                    if (ids_at(st, src, b * k + j, cur_len - 1) != st.eos) all_eos = 0;
+                    if (s_last[j] != st.eos) all_eos = 0;
                 if (all_eos) { st.stop[b] = cur_len; atomicAdd(&st.info[0], 1); }
             }
             if (first) {
@@ -592,7 +619,7 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
                     float best = 0.f; int bc = -1;
                     for (int c = 0; c < k * pn; ++c) {
                         if (used >> c & 1ull) continue;
-                        const float v = c_val[c / pn][c % pn] + st.score[src][b * k + c / pn];
+                        const float v = c_val[c / pn][c % pn] + s_score[c / pn];
                         if (bc < 0 || v > best) { best = v; bc = c; }
                     }
                     used |= 1ull << bc;
@@ -615,12 +642,12 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
                     // c % k: its beam offsets are arange(k) * V tiled per_node times over the flattened [k, pn] draws
                     // (beam_indices.repeat(batch, per_node_beam_size), decoder.py:1161-1164).  Reproduced as is.
                     const int j = c / pn, d = c % pn;
-                    n_score[c] = c_val[j][d] + st.score[src][b * k + j]; n_beam[c] = c % k; n_word[c] = c_idx[j][d];
+                    n_score[c] = c_val[j][d] + s_score[j]; n_beam[c] = c % k; n_word[c] = c_idx[j][d];
                 } else {
                     float best = 0.f; int bj = -1; long long bflat = 0;
                     for (int j = 0; j < k; ++j) {
                         if (headp[j] >= M) continue;
-                        const float v = c_val[j][headp[j]] + st.score[src][b * k + j];
+                        const float v = c_val[j][headp[j]] + s_score[j];
                         const long long flat = (long long)j * V + c_idx[j][headp[j]];
                         if (bj < 0 || v > best || (v == best && flat < bflat)) { best = v; bj = j; bflat = flat; }
                     }
@@ -633,13 +660,15 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
             double* h_score = st.hyp_score + (size_t)b * nh;
             int* h_len = st.hyp_len + (size_t)b * nh;
             int* h_seq = st.hyp_seq + (size_t)b * nh;
-            int is_done = st.done[b];
-            if (!is_done && st.hyp_n[b] >= nh) {
+            const int was_done = s_done;
+            int is_done = was_done;
+            int hyp_n = s_hyp_n, hyp_cnt = s_hyp_cnt;
+            double hyp_worst = s_hyp_worst;
+            if (!is_done && hyp_n >= nh) {
                 // BeamHypotheses.is_done(max next score); self.max_length = max_length - 1
-                is_done = st.hyp_worst[b] >= (double)n_max / st.len_norm[T - 1];
+                is_done = hyp_worst >= (double)n_max / s_len_last;
             }
-            if (is_done && !st.done[b]) atomicAdd(&st.info[0], 1);
-            st.done[b] = is_done;
+            if (is_done && !was_done) { atomicAdd(&st.info[0], 1); st.done[b] = is_done; }
             int nb = 0;
             if (!is_done) {
                 for (int c = 0; c < ncand && nb < k; ++c) {
@@ -649,25 +678,26 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
                         // BeamHypotheses.add (decoder.py:1316-1328): keep the nh best; a full list drops its lowest score
                         // (sorted() on (score, list index): the earliest-added of equal scores) and worst_score becomes the
                         // lowest score that is left
-                        const double sc = (double)n_score[c] / st.len_norm[cur_len];
-                        const int n = st.hyp_n[b];
-                        if (n < nh || sc > st.hyp_worst[b]) {
+                        const double sc = (double)n_score[c] / s_len_cur;
+                        const int n = hyp_n;
+                        if (n < nh || sc > hyp_worst) {
                             int slot = n;
                             if (n < nh) {
-                                st.hyp_n[b] = n + 1;
-                                st.hyp_worst[b] = sc < st.hyp_worst[b] ? sc : st.hyp_worst[b];
+                                hyp_n = n + 1;
+                                hyp_worst = sc < hyp_worst ? sc : hyp_worst;
                             } else {
                                 slot = 0;
                                 for (int i = 1; i < nh; ++i)
-                                    if (h_score[i] < h_score[slot] || (h_score[i] == h_score[slot] && h_seq[i] < h_seq[slot])) slot = i;
+                                    if (s_hscore[i] < s_hscore[slot] || (s_hscore[i] == s_hscore[slot] && s_hseq[i] < s_hseq[slot])) slot = i;
                                 double w = sc;
                                 for (int i = 0; i < nh; ++i)
-                                    if (i != slot && h_score[i] < w) w = h_score[i];
-                                st.hyp_worst[b] = w;
+                                    if (i != slot && s_hscore[i] < w) w = s_hscore[i];
+                                hyp_worst = w;
                             }
+                            s_hscore[slot] = sc; s_hseq[slot] = hyp_cnt;
                             h_score[slot] = sc;
                             h_len[slot] = cur_len;
-                            h_seq[slot] = st.hyp_cnt[b]++;
+                            h_seq[slot] = hyp_cnt++;
                             s_add_slot[s_nadd] = slot; s_add_row[s_nadd] = b * k + n_beam[c];
                             ++s_nadd;
                         }
@@ -676,6 +706,9 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
                         ++nb;
                     }
                 }
+                if (hyp_n != s_hyp_n) st.hyp_n[b] = hyp_n;
+                if (hyp_cnt != s_hyp_cnt) st.hyp_cnt[b] = hyp_cnt;
+                if (hyp_worst != s_hyp_worst) st.hyp_worst[b] = hyp_worst;
             }
             if (nb < k) {
                 // done sentence, or every candidate finished (cur_len + 1 == max_length): pad the batch with
@@ -694,28 +727,35 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
         int* ht = st.hyp_tok + ((size_t)b * st.nh + s_add_slot[a]) * T;
         for (int s = tid; s < cur_len; s += 256) ht[s] = ids_at(st, src, s_add_row[a], s);
     }
-    for (int j = 0; j < k; ++j) {
+    // all k rows in one sweep (one round trip, not k: the compiler cannot move row j + 1's loads above row j's stores)
+    for (int idx = tid; idx < k * cur_len; idx += 256) {
+        const int j = idx / cur_len, s = idx - j * cur_len;
         const int r = b * k + j, rs = sel_src[j];
-        for (int s = tid; s < cur_len; s += 256) {
-            st.ids[dst][(size_t)r * T + s] = st.ids[src][(size_t)rs * T + s];
-            st.kv_src[dst][(size_t)r * T + s] = st.kv_src[src][(size_t)rs * T + s];
-        }
-        if (tid == 0) {
-            st.ids[dst][(size_t)r * T + cur_len] = sel_word[j];
-            st.kv_src[dst][(size_t)r * T + cur_len] = r;
-            st.score[dst][r] = sel_score[j];
-        }
+        st.ids[dst][(size_t)r * T + s] = st.ids[src][(size_t)rs * T + s];
+        st.kv_src[dst][(size_t)r * T + s] = st.kv_src[src][(size_t)rs * T + s];
+    }
+    if (tid < k) {
+        const int r = b * k + tid;
+        st.ids[dst][(size_t)r * T + cur_len] = sel_word[tid];
+        st.kv_src[dst][(size_t)r * T + cur_len] = r;
+        st.score[dst][r] = sel_score[tid];
     }
 
     // ---- phase D: embedding + LayerNorm of the chosen tokens = input of the next decode step -----------------------
+    // One WAVE per beam row (rows j = wave, wave + 4), all rows at once: a lane owns the float4 chunks lane, lane + 64, ...
+    // of its row.  (Until round 6 the 256 threads took the rows one after the other, one exposed embedding-row fetch and three
+    // barriers each.)  The sums are formed exactly as before -- the partial of chunk group i is what wave i's wave_sum used to
+    // give, the groups are added in order -- so the rows are bit-identical to the earlier form and to embed_ln_kernel's.
     if (em.words == nullptr || cur_len + 1 >= T) return;
     const int D = em.D;
-    const int c = tid * 4;
-    const bool on = c < D;
-    for (int j = 0; j < k; ++j) {
-        const int r = b * k + j;
-        int tok = sel_word[j];
+    if (k == 1) {
+        // one row: the whole workgroup on it, one float4 per thread (a single wave would carry four reduction trees in a
+        // row: measured 8.8 -> 10.1 us per greedy step)
+        const int r = b;
+        int tok = sel_word[0];
         tok = tok < 0 ? 0 : (tok >= em.vocab ? em.vocab - 1 : tok);
+        const int c = tid * 4;
+        const bool on = c < D;
         f32x4_t a = {0.f, 0.f, 0.f, 0.f}, g4 = a, b4 = a;
         if (on) {
             const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(em.words + (size_t)tok * D + c);
@@ -725,7 +765,6 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = w4[q] + p4[q];
         }
-        __syncthreads();                                   // s_part reuse across rows
         const float sum = wave_sum(a[0] + a[1] + a[2] + a[3]);
         if (lane == 0) s_part[wave] = sum;
         __syncthreads();
@@ -753,6 +792,60 @@ __global__ __launch_bounds__(256) void search_step_kernel(SearchState st, int sr
                 t.y = pack2bf(o[2], o[3]);
                 const size_t off = em.frag ? frag_offset(r, c, D >> 5) : (size_t)r * D + c;
                 *reinterpret_cast<uint2*>(ht + off) = t;
+            }
+        }
+        return;
+    }
+    for (int j = wave; j < k; j += 4) {
+        const int r = b * k + j;
+        int tok = sel_word[j];
+        tok = tok < 0 ? 0 : (tok >= em.vocab ? em.vocab - 1 : tok);
+        f32x4_t a[4], g4[4], b4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            a[i] = g4[i] = b4[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (c < D) {
+                const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(em.words + (size_t)tok * D + c);
+                const f32x4_t p4 = *reinterpret_cast<const f32x4_t*>(em.positions + (size_t)cur_len * D + c);
+                g4[i] = *reinterpret_cast<const f32x4_t*>(em.gamma + c);
+                b4[i] = *reinterpret_cast<const f32x4_t*>(em.beta + c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[i][q] = w4[q] + p4[q];
+            }
+        }
+        float part[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[i] = wave_sum(a[i][0] + a[i][1] + a[i][2] + a[i][3]);
+        const float mean = (part[0] + part[1] + part[2] + part[3]) / (float)D;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float q2 = 0.f;
+            if ((lane + 64 * i) * 4 < D) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float d = a[i][q] - mean; q2 += d * d; }
+            }
+            part[i] = wave_sum(q2);
+        }
+        const float rstd = rsqrtf((part[0] + part[1] + part[2] + part[3]) / (float)D + em.eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < D) {
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (a[i][q] - mean) * rstd * g4[i][q] + b4[i][q];
+                *reinterpret_cast<f32x4_t*>(em.h_f + (size_t)r * D + c) = f32x4_t{o[0], o[1], o[2], o[3]};
+                TOut* ht = reinterpret_cast<TOut*>(em.h_t);
+                if constexpr (sizeof(TOut) == 4) {
+                    *reinterpret_cast<f32x4_t*>(ht + (size_t)r * D + c) = f32x4_t{o[0], o[1], o[2], o[3]};
+                } else {
+                    uint2 t;
+                    t.x = pack2bf(o[0], o[1]);
+                    t.y = pack2bf(o[2], o[3]);
+                    const size_t off = em.frag ? frag_offset(r, c, D >> 5) : (size_t)r * D + c;
+                    *reinterpret_cast<uint2*>(ht + off) = t;
+                }
             }
         }
     }

@@ -73,6 +73,31 @@ def test_gemm_bf16_p8_variant(M, N, K, act):
         assert all(torch.equal(a, b) for a, b in zip(hi, outs[9 | (bits << 8)])), bits
 
 
+@pytest.mark.usefixtures("experiment_build")
+@pytest.mark.parametrize("M,N,K", [(12608, 768, 768), (12608, 3072, 768), (8224, 1024, 4096), (6001, 2304, 768), (24272, 768, 3072)])
+def test_gemm_p8_automatic_tile_height_equals_the_256_row_tile(M, N, K):
+    """the tile height a context alone gets is picked by a time model (kernels_gemm10.hip: gemm_p8_cost) among
+    256 / 224 / 192 / 160 / 128 rows.  Whatever it picks at the encoder's real (ragged) row counts -- 64 x 197, 32 x 257,
+    16 x 6 x 197 ..., where the mixed-height instantiations (224 = 128 + 96, 160 = 96 + 64 rows) are what runs -- the result is
+    the 256-row tile's, bit for bit, for the 16-bit and the residual-stream epilogues."""
+    from generativeimage2text_amd import engine as E
+    A = _rand(M, K, seed=21).bfloat16().cuda()
+    W = _rand(N, K, seed=22, scale=K ** -0.5).bfloat16().cuda()
+    bias = _rand(N, seed=23).cuda()
+    res = _rand(M, N, seed=24).cuda()
+    outs = {}
+    try:
+        for tile in (-1, 9 | (128 << 8)):
+            E.set_gemm_impl(tile)
+            outs[tile] = (E.op_gemm(A, W, bias, None, 1, torch.bfloat16).cpu(), E.op_gemm(A, W, bias, res, 0, torch.float32).cpu())
+    finally:
+        E.set_gemm_impl(-1)
+    assert all(torch.equal(a, b) for a, b in zip(outs[-1], outs[9 | (128 << 8)]))
+    ref = (A[:64].double() @ W.double().t() + bias.double()).cpu()
+    ref = ref * torch.sigmoid(1.702 * ref)
+    assert (outs[-1][0][:64].double() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (64, 768, 3072), (300, 1002, 128), (1, 128, 64), (130, 70, 592)])
 def test_gemm_f32_exact_class(M, N, K):
     from generativeimage2text_amd import engine as E
