@@ -33,6 +33,34 @@ extern "C" int gitmi_op_gemm(const void* A, const void* W, const float* bias, co
     HIPCK(launch_gemm(g, in_f32, out_dtype == GITMI_DTYPE_F32, (hipStream_t)stream));
     return 0;
 }
+// the folded-LayerNorm forms of the large-M GEMM (kernels_gemm10.hip LNF; fp16-operand library, more than 512 rows), one launch
+extern "C" int gitmi_op_gemm_ln(const void* A, const void* W, const float* bias, const float* colsum, const float* ln_part,
+                                float ln_eps, const void* residual, const float* res_part, const float* res_gamma,
+                                const float* res_beta, float res_eps, void* C, float* part_out, int M, int N, int K, int act,
+                                void* stream) {
+    GemmArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N; g.ldr = N; g.act = act;
+    if (K % 64) return fail("op_gemm_ln: K must be a multiple of 64");
+    if (ln_part) {            // consumer: C = act(LayerNorm(A) W^T + b), A = raw fp16 rows, W / bias / colsum the folded set
+        if (!colsum || residual || part_out || res_part) return fail("op_gemm_ln: consumer form takes colsum and no residual / partial output");
+        g.ln_part = (const float2*)ln_part; g.ln_nparts = (K + 255) / 256; g.ln_colsum = colsum; g.ln_inv_d = 1.0f / (float)K; g.ln_eps = ln_eps;
+    } else {                  // producer: fp16 stream rows + their row partials
+        if (!part_out && !res_part) return fail("op_gemm_ln: neither a consumer (ln_part) nor a producer (part_out / res_part)");
+        g.out_f16 = 1;
+        g.res = (const float*)residual;
+        g.part_out = (float2*)part_out;
+        if (res_part) {
+            g.res_part = (const float2*)res_part; g.res_nparts = (N + 255) / 256; g.res_gamma = res_gamma; g.res_beta = res_beta;
+            g.res_inv_d = 1.0f / (float)N; g.res_eps = res_eps;
+        }
+    }
+    if (!gemm_uses_p8(g, false, false))
+        return fail("op_gemm_ln: the folded forms exist in gemm_p8_kernel only (more than 512 rows, N %% 256 == 0, K >= 128)");
+    if (launch_gemm(g, false, false, (hipStream_t)stream) != hipSuccess)
+        return fail("op_gemm_ln: launch refused (the folded forms are built into the fp16-operand library only)");
+    return 0;
+}
 extern "C" int gitmi_op_layernorm(const float* x, const float* gamma, const float* beta, float eps, void* y_t,
                                   float* y_f32, int rows, int D, int out_dtype, void* stream) {
     HIPCK(launch_layernorm(x, D, gamma, beta, eps, nullptr, y_t, D, out_dtype == GITMI_DTYPE_F32, y_f32, D, rows, D, 0, 0,

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "gitmi_op_vocab_topm", "gitmi_clone", "gitmi_op_attn_decode", "gitmi_preprocess_image",
     "gitmi_set_image_shape", "gitmi_preprocess_image_to", "gitmi_generate_prefixed", "gitmi_set_temporal_embedding", "gitmi_op_kv_repack", "gitmi_set_encode_after", "gitmi_op_sample_rows",
     "gitmi_search_done_count", "gitmi_set_trie", "gitmi_operand_dtype", "gitmi_set_shared_device", "gitmi_preprocess_batch",
-    "gitmi_set_ln_fold",
+    "gitmi_set_ln_fold", "gitmi_op_gemm_ln",
 ]
 # libgitmi_exp.so only (include/gitmi_experiment.h): schedules that measured slower than the default, debug hooks
 EXPERIMENT_SYMBOLS = [
@@ -120,6 +120,7 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     lib.gitmi_set_shared_device.argtypes = [vp, i32]
     lib.gitmi_set_ln_fold.argtypes = [vp, i32]
     lib.gitmi_op_gemm.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.gitmi_op_gemm_ln.argtypes = [vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, i32, vp]
     lib.gitmi_op_layernorm.argtypes = [vp, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp]
     lib.gitmi_op_attention.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.gitmi_op_dgemm.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, vp, i32, i32, i32, i32, i32, i32, vp]
@@ -143,7 +144,7 @@ def load_library(operands: str = "bf16") -> C.CDLL:
     for name in EXPORTED_SYMBOLS + (EXPERIMENT_SYMBOLS if operands == "exp" else []):
         if name not in ("gitmi_last_error", "gitmi_destroy"):
             getattr(lib, name).restype = C.c_int
-    if lib.gitmi_abi_version() != 9:
+    if lib.gitmi_abi_version() != 10:
         raise GitmiError("libgitmi.so ABI version mismatch")
     lib.gitmi_operand_dtype.restype = C.c_int
     if lib.gitmi_operand_dtype() != {"bf16": DTYPE_BF16, "f16": DTYPE_F16, "exp": DTYPE_BF16}[operands]:
@@ -517,6 +518,24 @@ def op_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = Non
     _ck(lib.gitmi_op_gemm(A.data_ptr(), W.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K, K, N,
                           _torch_dtype_code(A), _torch_dtype_code(out), act, _stream()), lib)
     return out
+
+
+def op_gemm_ln(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], *, colsum: Optional[torch.Tensor] = None,
+               ln_part: Optional[torch.Tensor] = None, ln_eps: float = 1e-5, residual: Optional[torch.Tensor] = None,
+               res_part: Optional[torch.Tensor] = None, res_gamma: Optional[torch.Tensor] = None,
+               res_beta: Optional[torch.Tensor] = None, res_eps: float = 1e-12, want_part: bool = False, act: int = ACT_NONE):
+    """The folded-LayerNorm forms of the large-M GEMM (fp16-operand library): consumer (ln_part given) or producer; returns C
+    (fp16 [M, N]) and, for a producer with want_part, the row partials float [M, 4, 2]."""
+    lib = load_library("f16")
+    assert A.dtype == torch.float16 and W.dtype == torch.float16 and A.is_contiguous() and W.is_contiguous()
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty(M, N, device=A.device, dtype=torch.float16)
+    part = torch.zeros(M, 4, 2, device=A.device, dtype=torch.float32) if want_part else None
+    _ck(lib.gitmi_op_gemm_ln(A.data_ptr(), W.data_ptr(), _ptr(bias), _ptr(colsum), _ptr(ln_part), ln_eps, _ptr(residual),
+                             _ptr(res_part), _ptr(res_gamma), _ptr(res_beta), res_eps, out.data_ptr(), _ptr(part), M, N, K, act,
+                             _stream()), lib)
+    return (out, part) if want_part else out
 
 
 def op_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GITMI_ABI_VERSION 9
+#define GITMI_ABI_VERSION 10
 
 /* compute precision of GEMM/attention operands (accumulation, LayerNorm statistics,
  * softmax, residual stream and logits are fp32 in both modes) */
@@ -285,6 +285,18 @@ int  gitmi_set_graph(gitmi_engine* e, int on);
 int  gitmi_op_gemm(const void* A, const void* W, const float* bias, const float* residual,
                    void* C, int M, int N, int K, int lda, int ldc, int in_dtype, int out_dtype,
                    int act, void* stream);
+/* (ABI 10) the folded-LayerNorm forms of the large-M GEMM, one launch (libgitmi_f16.so only; M > 512, N % 256 == 0, K % 64 == 0):
+ *  consumer (ln_part != NULL): C fp16 [M,N] = act(LayerNorm_K(A) W0^T + b0) computed from the RAW fp16 rows A [M,K] with the
+ *    folded set W = f16(W0 . gamma) [N,K], bias = beta W0^T + b0, colsum[n] = sum_k W[n][k], ln_part = float2 [M][4]: (sum, sumsq)
+ *    of row m over its 256-column tiles (unused slots 0);
+ *  producer (ln_part == NULL): fp16 stream rows C [M,N] = A W^T + bias + r, r = residual rows (fp16 [M,N], may be NULL) or
+ *    LayerNorm_N(residual rows) rebuilt from res_part / res_gamma / res_beta; part_out = float2 [M][4] of the rows as stored
+ *    (N <= 1024).  This is what replaces the LayerNorm modules between the GEMMs of CLIP/model.py:189-202 and
+ *    modeling_bert.py:171-178, 243-250 inside the engine (gitmi_set_ln_fold). */
+int  gitmi_op_gemm_ln(const void* A, const void* W, const float* bias, const float* colsum, const float* ln_part,
+                      float ln_eps, const void* residual, const float* res_part, const float* res_gamma,
+                      const float* res_beta, float res_eps, void* C, float* part_out, int M, int N, int K, int act,
+                      void* stream);
 /* y = LayerNorm(x) (biased variance, eps), x fp32 [rows, D]; y_t (in out_dtype) and/or y_f32 */
 int  gitmi_op_layernorm(const float* x, const float* gamma, const float* beta, float eps,
                         void* y_t, float* y_f32, int rows, int D, int out_dtype, void* stream);

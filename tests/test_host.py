@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(engine.EXPORTED_SYMBOLS) == declared
-    assert lib.gitmi_abi_version() == 9
+    assert lib.gitmi_abi_version() == 10
     assert len(declared) <= 40                  # the product ABI stays small: schedules that lost and debug hooks live elsewhere
 
 
@@ -365,7 +365,7 @@ def test_both_operand_builds_load_and_identify_themselves():
     same ABI, every declared symbol, and each says which 16-bit operand type it was built for."""
     a, b = engine.load_library("bf16"), engine.load_library("f16")
     assert a.gitmi_operand_dtype() == engine.DTYPE_BF16 and b.gitmi_operand_dtype() == engine.DTYPE_F16
-    assert a.gitmi_abi_version() == b.gitmi_abi_version() == 9
+    assert a.gitmi_abi_version() == b.gitmi_abi_version() == 10
     for name in engine.EXPORTED_SYMBOLS:
         getattr(b, name)
 
