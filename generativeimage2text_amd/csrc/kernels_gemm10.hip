@@ -35,6 +35,10 @@
 //     No LDS round trip and no barriers, so the waves of a tile drain independently.  Measured (profiles/r02_g_epi_ab.txt):
 //     isolated launches are not faster (a quarter wave touches 16 rows: 4x the requests of the staged copy loop; the
 //     phase is bound by the chip-wide read-modify-write of the residual stream anyway), the whole pass in situ is 1.4 %.
+//   * LayerNorm folding (round 6, template parameter LNF, fp16-operand build): the LayerNorm modules between these GEMMs
+//     (CLIP/model.py:189-202 ln_1 / ln_2; modeling_bert.py:171-178, 243-250 over the image rows) live in the epilogues --
+//     a PRODUCER of stream rows leaves (sum, sumsq) per row and 256-column tile, a CONSUMER multiplies the raw rows by
+//     W . gamma and applies rstd (acc - mean colsum) + (beta W^T + b).  See the comment at the kernel; K loop unchanged.
 #include "gitmi_common.h"
 #include "launchers.h"
 #include <type_traits>
@@ -68,7 +72,7 @@ __device__ __forceinline__ float add_unfused(float a, float b) {
 
 // Sums of two values over each 32-lane half of a wave, valid in lanes 16..31 / 48..63: five v_add_f32 with a DPP source per
 // value (two quad permutes, two row rotations, then row 0's / row 2's total broadcast into the row above it) -- no LDS
-// traffic, no v_mov per step (what update_dpp + add compiles to: 2.9 -> us per launch measured, profiles/r06_i_*).  The two
+// traffic, no v_mov per step (update_dpp + add compiled to v_mov + v_mov_dpp + s_nop + v_add per step: profiles/r06_i_*).  The two
 // chains are interleaved; a DPP read needs two wait states after the VALU write of its source (the other chain's add + s_nop 0).
 // The summation order is fixed.
 __device__ __forceinline__ void half_wave_sum2_hi(float& a, float& b) {
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs g) {
 
 template <typename TOut, int MH, int EPI = 1, int MH1 = MH, int LNF = 0>
 static void launch_p8_t(const GemmArgs& g, hipStream_t s) {
-    if constexpr (LNF == 2) {       // stream rows: no activation
+    if constexpr (LNF == 2) {       // stream rows: no activation (and no instantiation of the activation variants)
         hipLaunchKernelGGL((gemm_p8_kernel<TOut, GITMI_ACT_NONE, 0, MH, EPI, MH1, LNF>), dim3(g.nwg), dim3(512), 0, s, g);
         return;
     } else {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Static resource table of every kernel in csrc/ (no GPU needed): registers, scratch (spills), LDS, occupancy as reported
-by `hipcc -Rpass-analysis=kernel-resource-usage` for gfx950.    python tools/kernel_resources.py [out.txt]"""
+by `hipcc -Rpass-analysis=kernel-resource-usage` for gfx950.    python tools/kernel_resources.py [out.txt] [--f16]"""
 import glob
 import os
 import re
@@ -26,6 +26,8 @@ def demangle(names):
 
 def main(out_path=None):
     import bench
+    if "--f16" in sys.argv:               # the fp16-operand build (the folded-LayerNorm GEMM forms exist only there)
+        FLAGS.insert(-1, "-DGITMI_OPS_F16")
     rows = []
     for f in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
         r = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + [f, "-o", "/tmp/_kres.o"], capture_output=True, text=True)
