@@ -13,7 +13,7 @@ from typing import Dict, List, Mapping, Optional, Sequence, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgitmi.so")                 # bf16 operands: the benchmarked build
+LIB_PATH = os.path.join(_HERE, "libgitmi.so")                 # bf16 operands (BASELINE's named precision; bench.py: alt_precision)
 LIB_PATH_F16 = os.path.join(_HERE, "libgitmi_f16.so")         # the same sources built for fp16 operands (-DGITMI_OPS_F16)
 LIB_PATH_EXP = os.path.join(_HERE, "libgitmi_exp.so")         # measurement build of libgitmi.so (-DGITMI_EXPERIMENT): see use_experiment_build
 
@@ -194,7 +194,7 @@ class Engine:
         (MinMaxResizeForTest models); default: the model config's max_image_hw, else the native square."""
         if not torch.cuda.is_available():
             raise GitmiError("no GPU visible: the GIT engine runs on MI355X (gfx950) only, there is no CPU fallback")
-        # precision: "bf16" (benchmarked mode) / "f16" (the fp16-operand build of the same kernels) / "f32" (exact parity mode)
+        # precision: "f16" (the benchmarked build: fp16 operands) / "bf16" (the same kernels on bf16 operands) / "f32" (exact parity mode)
         self.lib = load_library("f16" if precision in ("f16", "fp16") else "bf16")
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.cfg = model_cfg

@@ -303,7 +303,7 @@ class CaptioningModel:
     """
 
     # precision: "f32" (reference-identical ids), "f16" (default 16-bit mode: fp16 operands, same MFMA rate as bf16 on gfx950,
-    # 8 x smaller logit error -- profiles/r05_a_parity_measured.jsonl) or "bf16" (BASELINE.json's benchmarked precision)
+    # 8 x smaller logit error: the build that meets the specification and the benchmarked one since round 6) or "bf16" (BASELINE.json's named precision)
     def __init__(self, cfg: GitModelConfig, decoder, precision: str = "f16", max_batch: int = 64,
                  max_frames: Optional[int] = None, max_text_len: Optional[int] = None,
                  device: Optional[int] = None):

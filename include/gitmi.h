@@ -32,7 +32,7 @@ extern "C" {
 
 /* compute precision of GEMM/attention operands (accumulation, LayerNorm statistics,
  * softmax, residual stream and logits are fp32 in both modes) */
-#define GITMI_PREC_BF16 0   /* bf16 MFMA -- the production / benchmarked path        */
+#define GITMI_PREC_BF16 0   /* 16-bit MFMA operands (the type of the library: below) */
 #define GITMI_PREC_F32  1   /* f32-input MFMA, exact fp32 -- parity-debug path        */
 
 /* tensor dtypes accepted by gitmi_load_tensor */
@@ -123,7 +123,7 @@ typedef struct gitmi_profile {
 /* ---- lifecycle ------------------------------------------------------------------- */
 int  gitmi_abi_version(void);
 /* The 16-bit operand type of the library's fast mode (GITMI_PREC_BF16 of gitmi_config.precision means "the 16-bit operand
- * mode of this build"): GITMI_DTYPE_BF16 for libgitmi.so -- the benchmarked build --, GITMI_DTYPE_F16 for libgitmi_f16.so,
+ * mode of this build"): GITMI_DTYPE_BF16 for libgitmi.so, GITMI_DTYPE_F16 for libgitmi_f16.so -- the benchmarked build since round 6 --,
  * the same sources built with -DGITMI_OPS_F16 (IEEE fp16 operands on v_mfma_f32_16x16x32_f16: same rate, 3 more
  * mantissa bits; 16-bit operands handed to the gitmi_op_* entry points are then fp16 too). */
 int  gitmi_operand_dtype(void);
