@@ -134,11 +134,13 @@ def _tile_partials(rows_f16):
     return out
 
 
-def _stream_rows(M, N, seed, outliers=True):
-    """raw residual-stream rows with what makes folding delicate: a mean comparable to the spread, a different scale per row, a few
-    channels two to three orders above the rest"""
+def _stream_rows(M, N, seed, outliers=True, offset=0.0):
+    """raw residual-stream rows with what makes folding delicate: a mean comparable to the spread (offset: a common offset many
+    times the spread), a different scale per row, a few channels two to three orders above the rest"""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(M, N, generator=g) * (0.5 + 2.0 * torch.rand(M, 1, generator=g)) + torch.randn(M, 1, generator=g) * 1.5
+    if offset:
+        x = x + offset * torch.sign(torch.randn(M, 1, generator=g))
     if outliers:
         x[:, 17] += 300.0
         x[:, 401] -= 100.0
@@ -209,6 +211,30 @@ def test_op_producer_gemm_stream_rows_and_partials_match_fp64(M, N, K, mode):
     assert torch.allclose(part[:, :, 0], want[:, :, 0], rtol=1e-5, atol=1e-3 * scale)
     assert torch.allclose(part[:, :, 1], want[:, :, 1], rtol=1e-5, atol=1e-3 * scale * scale)
     assert (part[:, N // 256:] == 0).all()
+
+
+def test_op_consumer_gemm_rows_with_a_mean_many_times_their_spread():
+    """The cancellation rstd (x W'^T - mean colsum) at |mean| / sigma ~ 10 ... 60 (a common offset of 30 on rows of spread
+    0.5 ... 2.5): the fp32 accumulator carries products ~30x larger than the result; the error against fp64 on the same fp16
+    inputs stays at the output-rounding level."""
+    from generativeimage2text_amd import engine as E
+    from test_gpu_ops import _rand
+    M, N, K = 1000, 2304, 768
+    X = _stream_rows(M, K, seed=51, outliers=False, offset=30.0)
+    W0 = _rand(N, K, seed=52, scale=K ** -0.5)
+    b0 = _rand(N, seed=53, scale=0.1)
+    gamma = torch.exp(_rand(K, seed=54) * 0.6)
+    beta = _rand(K, seed=55)
+    Wf = (W0 * gamma).half()
+    bias_f = (b0.double() + W0.double() @ beta.double()).float()
+    out = E.op_gemm_ln(X.cuda(), Wf.cuda(), bias_f.cuda(), colsum=Wf.float().sum(1).cuda(), ln_part=_tile_partials(X).float().cuda(),
+                       ln_eps=1e-5).cpu().double()
+    xd = X.double()
+    mean = xd.mean(1, keepdim=True)
+    ln = (xd - mean) / torch.sqrt(((xd - mean) ** 2).mean(1, keepdim=True) + 1e-5)
+    ref = ln @ Wf.double().t() + bias_f.double()
+    assert (mean.abs() / xd.std(1, keepdim=True)).median().item() > 10
+    assert (out - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
 
 
 def test_op_gemm_ln_refuses_what_it_cannot_run():
